@@ -1,0 +1,126 @@
+/*
+ * lmc_format.h -- on-the-wire layout of one encoded KV chunk ("blob").
+ *
+ * Shared by the HIP product (lmcache_amd/csrc), the CPU oracle (oracle/) and
+ * host-side parsers.  Plain C, no dependencies.
+ *
+ * What the blob replaces in the reference: the pickled
+ * CacheGenGPUEncoderOutput {data_chunks[{bytestream, bytestream_lengths,
+ * ntokens}], cdf, max_tensors_key, max_tensors_value, num_heads, head_size}
+ * (lmcache/storage_backend/serde/cachegen_basics.py:109-142).  The byte format
+ * is private to the serializer/deserializer pair: the backends treat it as
+ * opaque bytes (lmcache/storage_backend/remote_backend.py:124-125,164-168).
+ *
+ * Plane order follows the reference's encode_input / cdf tensors
+ * (cachegen_encoder.py:284,290): plane p = kv * L + layer, i.e. all K planes
+ * first, then all V planes.  A plane is a [T tokens, C = H*D channels] matrix.
+ *
+ * All integers little-endian.  Every section starts on a 16-byte boundary.
+ *
+ *   header   128 B          struct lmc_blob_header
+ *   bins     u8  [P]        quantisation bins of each plane (32 or 16 ...)
+ *   scales   u16 [P][T]     per-(plane,token) absmax, raw bits of the KV dtype
+ *                           (= max_tensors_key ++ max_tensors_value)
+ *   cdf      u16 [P][C][LP] 16-bit CDF per (plane, channel); LP = 33.
+ *                           Same layout and values as the reference's `cdf`
+ *                           tensor; entry LP-1 is 65536 stored as 0.
+ *   gend     u32 [P][G]     EXACT end offset (bytes, relative to the streams
+ *                           section) of group stream (p,g); G = ceil(C/64).
+ *                           Stream (p,g) starts at roundup16(gend[prev]) (0 for
+ *                           the first) -- so every stream starts 16-B aligned.
+ *   streams  bytes          group streams in (p,g) order, each padded with
+ *                           zero bytes to a multiple of 16.
+ *
+ * Group stream = interleaved rANS over 64 adjacent channels ("lanes"),
+ * 32-bit state, 16-bit renormalisation words, 16-bit probabilities:
+ *
+ *   [ u16 words, in the order the ENCODER emitted them ][ u32 state[64] ]
+ *
+ * The encoder walks tokens T-1 .. 0; at each token the lanes that must
+ * renormalise append their low 16 state bits in ascending lane order.  The
+ * decoder starts from the tail (states), walks tokens 0 .. T-1 and pops words
+ * from the end, again in ascending lane order inside one token step.  See
+ * DESIGN.md "Entropy coder" for the exact recurrences.
+ */
+#ifndef LMC_FORMAT_H
+#define LMC_FORMAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMC_BLOB_MAGIC 0x31434D4Cu /* "LMC1" */
+#define LMC_BLOB_VERSION 1u
+#define LMC_HEADER_BYTES 128u
+
+#define LMC_DTYPE_BF16 0
+#define LMC_DTYPE_FP16 1
+
+#define LMC_LANES 64        /* channels per group stream = wavefront width  */
+#define LMC_MAX_BINS 32     /* torchac_cuda.calculate_cdf(sym, 32)          */
+#define LMC_LP 33           /* CDF entries per channel = max_bins + 1       */
+#define LMC_PROB_BITS 16
+#define LMC_RANS_L (1u << 16) /* lower bound of the normalised state interval */
+#define LMC_CDF_SCALE (65536u - (LMC_LP - 1u)) /* 2^16 - (Lp-1), cachegen_encoder.py:117-119 */
+
+typedef struct lmc_blob_header {
+  uint32_t magic;
+  uint16_t version;
+  uint16_t header_bytes;
+  uint32_t dtype;       /* LMC_DTYPE_* of the encoded KV (and of `scales`) */
+  uint32_t num_layers;  /* L */
+  uint32_t ntokens;     /* T */
+  uint32_t num_heads;   /* H */
+  uint32_t head_size;   /* D */
+  uint32_t nchannels;   /* C = H*D */
+  uint32_t nplanes;     /* P = 2L */
+  uint32_t ngroups;     /* G = ceil(C/64) */
+  uint32_t lp;          /* LMC_LP */
+  uint32_t off_bins;
+  uint32_t off_scales;
+  uint32_t off_cdf;
+  uint32_t off_gend;
+  uint32_t off_streams;
+  uint32_t stream_bytes; /* padded size of the streams section */
+  uint32_t total_bytes;  /* off_streams + stream_bytes */
+  uint32_t reserved[14];
+} lmc_blob_header;
+
+static inline uint32_t lmc_r16(uint32_t x) { return (x + 15u) & ~15u; }
+
+/* Static section offsets for a chunk geometry (everything but stream sizes). */
+static inline void lmc_blob_layout(uint32_t L, uint32_t T, uint32_t H, uint32_t D,
+                                   lmc_blob_header* h) {
+  uint32_t C = H * D, P = 2u * L, G = (C + LMC_LANES - 1u) / LMC_LANES;
+  h->magic = LMC_BLOB_MAGIC;
+  h->version = LMC_BLOB_VERSION;
+  h->header_bytes = LMC_HEADER_BYTES;
+  h->num_layers = L; h->ntokens = T; h->num_heads = H; h->head_size = D;
+  h->nchannels = C; h->nplanes = P; h->ngroups = G; h->lp = LMC_LP;
+  h->off_bins = LMC_HEADER_BYTES;
+  h->off_scales = h->off_bins + lmc_r16(P);
+  h->off_cdf = h->off_scales + lmc_r16(2u * P * T);
+  h->off_gend = h->off_cdf + lmc_r16(2u * P * C * LMC_LP);
+  h->off_streams = h->off_gend + lmc_r16(4u * P * G);
+}
+
+/* Capacity (bytes) reserved for one group stream while encoding.  Proof that it
+ * cannot overflow is in DESIGN.md ("stream bound"): every occurring symbol has
+ * freq >= count*65504/T, so a lane emits <= T*log2(31)+48 bits < 8*(T+8). */
+static inline uint32_t lmc_group_cap_bytes(uint32_t T) {
+  return lmc_r16(LMC_LANES * (T + 8u));
+}
+
+/* Worst-case blob size for a chunk geometry. */
+static inline uint64_t lmc_blob_bound(uint32_t L, uint32_t T, uint32_t H, uint32_t D) {
+  lmc_blob_header h;
+  lmc_blob_layout(L, T, H, D, &h);
+  return (uint64_t)h.off_streams + (uint64_t)h.nplanes * h.ngroups * lmc_group_cap_bytes(T);
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMC_FORMAT_H */

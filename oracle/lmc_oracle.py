@@ -1,0 +1,227 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/lmc_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``lmcache_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg use it, and only as the checker / timed CPU baseline.
+
+Each wrapper keeps the reference citation of the C function it calls; see the C
+file for the restated algorithm.  Arrays are numpy; 16-bit floats travel as raw
+``uint16`` bit patterns (dtype 0 = bf16, 1 = fp16).
+"""
+import ctypes
+import os
+import subprocess
+from typing import List, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblmc_oracle.so")
+
+BF16, FP16 = 0, 1
+LANES, MAX_BINS, LP = 64, 32, 33
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "lmc_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "lmc_format.h")
+    stale = (not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src)
+             or os.path.getmtime(_SO) < os.path.getmtime(hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liblmc_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+        L.lmco_sha256.argtypes = [vp, sz, vp]
+        L.lmco_prefix_hash.argtypes = [vp, sz, sz, vp]
+        L.lmco_prefix_hash.restype = sz
+        L.lmco_quantize.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
+        L.lmco_dequantize.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32]
+        L.lmco_cdf.argtypes = [vp, i32, i32, i32, i32, vp]
+        L.lmco_encode_group.argtypes = [vp, i32, i32, i32, vp, vp, sz]
+        L.lmco_encode_group.restype = sz
+        L.lmco_decode_group.argtypes = [vp, sz, i32, i32, i32, vp, vp]
+        L.lmco_decode_group.restype = i32
+        L.lmco_encode_blob.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, sz, vp]
+        L.lmco_encode_blob.restype = i32
+        L.lmco_decode_blob_symbols.argtypes = [vp, sz, vp]
+        L.lmco_decode_blob_symbols.restype = i32
+        L.lmco_decode_blob.argtypes = [vp, sz, vp, i32]
+        L.lmco_decode_blob.restype = i32
+        L.lmco_blob_bound.argtypes = [i32, i32, i32, i32]
+        L.lmco_blob_bound.restype = ctypes.c_uint64
+        L.lmco_h2f.argtypes = [ctypes.c_uint16, i32]
+        L.lmco_h2f.restype = ctypes.c_float
+        L.lmco_f2h.argtypes = [ctypes.c_float, i32]
+        L.lmco_f2h.restype = ctypes.c_uint16
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray) -> ctypes.c_void_p:
+    assert a.flags["C_CONTIGUOUS"]
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def sha256_hex(data: bytes) -> str:
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(0, np.uint8)
+    out = np.zeros(32, np.uint8)
+    lib().lmco_sha256(_p(np.ascontiguousarray(buf)), len(data), _p(out))
+    return out.tobytes().hex()
+
+
+def prefix_hash(tokens: np.ndarray, chunk_size: int) -> List[str]:
+    """cache_engine.py:58-96 -- tokens int64 1-D."""
+    tokens = np.ascontiguousarray(tokens, dtype=np.int64)
+    n = (len(tokens) + chunk_size - 1) // chunk_size
+    out = np.zeros(max(n, 1) * 65, np.uint8)
+    got = lib().lmco_prefix_hash(_p(tokens), len(tokens), chunk_size, _p(out))
+    assert got == n
+    return [out[i * 65:i * 65 + 64].tobytes().decode("ascii") for i in range(n)]
+
+
+def quantize(kv_bits: np.ndarray, dtype: int, bins: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """cachegen_encoder.py:40-61,278-285.  kv_bits uint16 [L,2,T,C] -> (sym int8 [2L,T,C], scale uint16 [2L,T])."""
+    L, two, T, C = kv_bits.shape
+    assert two == 2 and kv_bits.dtype == np.uint16
+    bins = np.ascontiguousarray(bins, dtype=np.int32)
+    assert bins.shape == (2 * L,)
+    sym = np.empty((2 * L, T, C), np.int8)
+    scale = np.empty((2 * L, T), np.uint16)
+    lib().lmco_quantize(_p(np.ascontiguousarray(kv_bits)), dtype, L, T, C, _p(bins), _p(sym), _p(scale))
+    return sym, scale
+
+
+def dequantize(sym: np.ndarray, scale: np.ndarray, scale_dtype: int, bins: np.ndarray,
+               out_dtype: int) -> np.ndarray:
+    """cachegen_decoder.py:24-35,177-200.  -> uint16 [L,2,T,C] in out_dtype."""
+    P, T, C = sym.shape
+    L = P // 2
+    bins = np.ascontiguousarray(bins, dtype=np.int32)
+    out = np.empty((L, 2, T, C), np.uint16)
+    lib().lmco_dequantize(_p(np.ascontiguousarray(sym)), _p(np.ascontiguousarray(scale)), scale_dtype,
+                          L, T, C, _p(bins), _p(out), out_dtype)
+    return out
+
+
+def cdf(sym: np.ndarray, max_bins: int = MAX_BINS) -> np.ndarray:
+    """cachegen_encoder.py:95-126,175-222 (in-tree spec of torchac_cuda.calculate_cdf).  -> uint16 [P,C,max_bins+1]."""
+    P, T, C = sym.shape
+    out = np.empty((P, C, max_bins + 1), np.uint16)
+    lib().lmco_cdf(_p(np.ascontiguousarray(sym)), P, T, C, max_bins, _p(out))
+    return out
+
+
+def group_cap_bytes(T: int) -> int:
+    return (LANES * (T + 8) + 15) & ~15
+
+
+def encode_group(sym_plane: np.ndarray, g: int, cdf_plane: np.ndarray) -> bytes:
+    """One 64-channel group stream (exact bytes, no padding)."""
+    T, C = sym_plane.shape
+    cap = group_cap_bytes(T)
+    out = np.zeros(cap // 2, np.uint16)
+    n = lib().lmco_encode_group(_p(np.ascontiguousarray(sym_plane)), T, C, g,
+                                _p(np.ascontiguousarray(cdf_plane)), _p(out), cap // 2)
+    assert n > 0, "group stream overflow"
+    return out.tobytes()[:n]
+
+
+def decode_group(stream: bytes, T: int, C: int, g: int, cdf_plane: np.ndarray,
+                 sym_plane: np.ndarray) -> int:
+    buf = np.frombuffer(stream, dtype=np.uint16).copy()
+    return lib().lmco_decode_group(_p(buf), len(stream), T, C, g, _p(np.ascontiguousarray(cdf_plane)),
+                                   _p(sym_plane))
+
+
+def blob_bound(L: int, T: int, H: int, D: int) -> int:
+    return int(lib().lmco_blob_bound(L, T, H, D))
+
+
+def encode_blob(kv_bits: np.ndarray, dtype: int, H: int, D: int, bins: np.ndarray) -> bytes:
+    """cachegen_encoder.py:266-325,352-389 with our container.  kv_bits uint16 [L,2,T,H*D]."""
+    L, two, T, C = kv_bits.shape
+    assert two == 2 and C == H * D
+    bins = np.ascontiguousarray(bins, dtype=np.int32)
+    cap = blob_bound(L, T, H, D)
+    blob = np.zeros(cap, np.uint8)
+    nbytes = ctypes.c_size_t(0)
+    rc = lib().lmco_encode_blob(_p(np.ascontiguousarray(kv_bits)), dtype, L, T, H, D, _p(bins), _p(blob),
+                                cap, ctypes.byref(nbytes))
+    assert rc == 0, f"lmco_encode_blob rc={rc}"
+    return blob[:nbytes.value].tobytes()
+
+
+def parse_header(blob: bytes) -> dict:
+    names = ["dtype", "num_layers", "ntokens", "num_heads", "head_size", "nchannels", "nplanes", "ngroups",
+             "lp", "off_bins", "off_scales", "off_cdf", "off_gend", "off_streams", "stream_bytes",
+             "total_bytes"]
+    head = np.frombuffer(blob[:128], dtype=np.uint32)
+    assert head[0] == 0x31434D4C, "bad magic"
+    d = {n: int(v) for n, v in zip(names, head[2:2 + len(names)])}
+    d["version"] = int(head[1] & 0xffff)
+    return d
+
+
+def decode_blob_symbols(blob: bytes) -> np.ndarray:
+    h = parse_header(blob)
+    sym = np.zeros((h["nplanes"], h["ntokens"], h["nchannels"]), np.int8)
+    buf = np.frombuffer(blob, dtype=np.uint8).copy()
+    rc = lib().lmco_decode_blob_symbols(_p(buf), len(blob), _p(sym))
+    assert rc == 0, f"lmco_decode_blob_symbols rc={rc}"
+    return sym
+
+
+def decode_blob(blob: bytes, out_dtype: int) -> np.ndarray:
+    """cachegen_decoder.py:142-202 (vllm layout).  -> uint16 [L,2,T,C] in out_dtype."""
+    h = parse_header(blob)
+    out = np.zeros((h["num_layers"], 2, h["ntokens"], h["nchannels"]), np.uint16)
+    buf = np.frombuffer(blob, dtype=np.uint8).copy()
+    rc = lib().lmco_decode_blob(_p(buf), len(blob), _p(out), out_dtype)
+    assert rc == 0, f"lmco_decode_blob rc={rc}"
+    return out
+
+
+# --- helpers shared by tests / bench -----------------------------------------
+def cachegen_bins(model_name: str) -> Tuple[np.ndarray, int]:
+    """Per-plane bins (key_bins ++ value_bins) restating CacheGenConfig.from_model_name and
+    make_key_bins/make_value_bins (cachegen_basics.py:32-78, cachegen_encoder.py:339-350)."""
+    if model_name in ("mistralai/Mistral-7B-Instruct-v0.2", "lmsys/longchat-7b-16k", "Qwen/Qwen-7B",
+                      "meta-llama/Llama-3.1-8B-Instruct"):
+        nl = 32
+    elif model_name == "THUDM/glm-4-9b-chat":
+        nl = 40
+    else:
+        raise ValueError(f"Model {model_name} is not supported")
+    kb = np.full(nl, 16, np.int32)
+    kb[:20] = 16
+    kb[:10] = 32
+    vb = np.full(nl, 16, np.int32)
+    vb[:2] = 32
+    return np.concatenate([kb, vb]), nl
+
+
+def torch_to_bits(t) -> Tuple[np.ndarray, int]:
+    """torch bf16/fp16 tensor -> (uint16 ndarray, dtype code)."""
+    import torch
+    code = BF16 if t.dtype == torch.bfloat16 else FP16
+    assert t.dtype in (torch.bfloat16, torch.float16)
+    return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16), code
+
+
+def bits_to_torch(a: np.ndarray, code: int):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a).view(np.int16))
+    return t.view(torch.bfloat16 if code == BF16 else torch.float16)

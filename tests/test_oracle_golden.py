@@ -1,0 +1,118 @@
+"""Pin the CPU oracle against fixtures produced by the reference itself
+(oracle/gen_golden.py -> tests/golden/).  CPU only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+def test_sha256_matches_hashlib(oracle):
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 2048, 2112):
+        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert oracle.sha256_hex(data) == hashlib.sha256(data).hexdigest()
+
+
+def test_prefix_hash_chain_golden(oracle, golden_dir):
+    with open(os.path.join(golden_dir, "hash_chain.json")) as f:
+        gold = json.load(f)
+    # KAT quoted in SURVEY.md 8(c)
+    c0 = gold["cases"][0]
+    assert c0["hashes"][0] == "bbd330b12e8159e117376ef24fa106413bc9fc18032a0d43e95c5dae5e47953f"
+    assert c0["hashes"][1] == "da67b0aaefba655d2edadd2cc5d11cd4564db9059ccf6264056d62d170b11ff5"
+    for case in gold["cases"]:
+        got = oracle.prefix_hash(np.array(case["tokens"], dtype=np.int64), case["chunk_size"])
+        assert got == case["hashes"], case["name"]
+
+
+@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+@pytest.mark.parametrize("kind", ["rand", "randn", "outlier"])
+def test_quantize_dequantize_golden(oracle, golden_dir, dname, kind):
+    z = np.load(os.path.join(golden_dir, "quant.npz"))
+    code = oracle.BF16 if dname == "bf16" else oracle.FP16
+    tag = f"{dname}_{kind}"
+    sym, scale = oracle.quantize(z[f"{tag}_kv"], code, z["bins"])
+    assert np.array_equal(sym, z[f"{tag}_sym"])
+    assert np.array_equal(scale, z[f"{tag}_scale"])
+    for out_name, out_code in (("bf16", oracle.BF16), ("fp16", oracle.FP16)):
+        deq = oracle.dequantize(sym, scale, code, z["bins"], out_code)
+        assert np.array_equal(deq, z[f"{tag}_deq_{out_name}"]), (tag, out_name)
+
+
+def test_quantize_edge_rows_golden(oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "quant_edge.npz"))
+    x = z["x"]  # [L=2, T, C] keys only; build a [L,2,T,C] chunk with V = K
+    kv = np.stack([x, x], axis=1)
+    bins = np.concatenate([z["bins"], z["bins"]])
+    sym, scale = oracle.quantize(kv, oracle.BF16, bins)
+    assert np.array_equal(sym[:2], z["sym"])
+    gs = z["scale"]
+    nan = (gs & 0x7fff) > 0x7f80
+    assert np.array_equal(scale[:2][~nan], gs[~nan])
+    assert (((scale[:2] & 0x7fff) > 0x7f80) == nan).all()
+    deq = oracle.dequantize(sym, scale, oracle.BF16, bins, oracle.BF16)[:, 0]
+    g = z["deq_bf16"]
+    gnan = (g & 0x7fff) > 0x7f80
+    assert np.array_equal(deq[~gnan], g[~gnan])
+    assert (((deq & 0x7fff) > 0x7f80) == gnan).all()
+
+
+@pytest.mark.parametrize("T", [1, 7, 16, 128, 236, 250, 256, 768])
+def test_cdf_golden(oracle, golden_dir, T):
+    z = np.load(os.path.join(golden_dir, "cdf.npz"))
+    got = oracle.cdf(z[f"T{T}_sym"], 32)
+    assert np.array_equal(got, z[f"T{T}_cdf"])
+    # strictly increasing as uint16 except the final wrap to 65536 == 0
+    g = got.astype(np.int64)
+    g[..., -1] += 65536
+    assert (np.diff(g, axis=-1) >= 1).all() and (g[..., 0] == 0).all() and (g[..., -1] == 65536).all()
+
+
+def test_group_coder_roundtrip_and_bound(oracle):
+    rng = np.random.default_rng(3)
+    for T, C in ((1, 64), (5, 70), (256, 128), (300, 64)):
+        for spread in (0.3, 2.0, 9.0):
+            sym = np.clip(np.rint(rng.normal(15, spread, (1, T, C))), 0, 30).astype(np.int8)
+            cdf = oracle.cdf(sym, 32)
+            G = (C + 63) // 64
+            for g in range(G):
+                stream = oracle.encode_group(sym[0], g, cdf[0])
+                assert len(stream) % 2 == 0 and len(stream) <= oracle.group_cap_bytes(T)
+                out = np.full((T, C), -1, np.int8)
+                assert oracle.decode_group(stream, T, C, g, cdf[0], out) == 0
+                lo, hi = g * 64, min(C, g * 64 + 64)
+                assert np.array_equal(out[:, lo:hi], sym[0][:, lo:hi])
+                # corruption is detected by the final-state check
+                bad = bytearray(stream)
+                bad[len(bad) // 3] ^= 0x10
+                if len(stream) > 256 + 8:
+                    rc = oracle.decode_group(bytes(bad), T, C, g, cdf[0], out.copy())
+                    # rANS is a bijection: same symbols + different words => the final state is not L
+                    assert rc != 0
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_blob_roundtrip_equals_quant_dequant(oracle, dtype):
+    """decode(encode(x)) == do_dequantize(torch_quant_vectorized(x)) -- SURVEY.md 8(c) oracle."""
+    import torch
+    torch.manual_seed(0)
+    L, T, H, D = 3, 37, 2, 40
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    kv = torch.randn(L, 2, T, H * D).to(tdt)
+    bits, code = oracle.torch_to_bits(kv)
+    bins = np.array([32, 16, 16, 32, 16, 16], np.int32)
+    blob = oracle.encode_blob(bits, code, H, D, bins)
+    hdr = oracle.parse_header(blob)
+    assert hdr["total_bytes"] == len(blob) and hdr["num_heads"] == H and hdr["head_size"] == D
+    sym, scale = oracle.quantize(bits, code, bins)
+    assert np.array_equal(oracle.decode_blob_symbols(blob), sym)
+    for oc in (oracle.BF16, oracle.FP16):
+        assert np.array_equal(oracle.decode_blob(blob, oc), oracle.dequantize(sym, scale, code, bins, oc))
+    # error bound vs the original: |x^ - x| <= max1/(2M) + 1ulp16(max1)   
+    dec = oracle.bits_to_torch(oracle.decode_blob(blob, code), code).float()
+    mx = kv.float().abs().amax(-1, keepdim=True)
+    M = torch.tensor(bins.reshape(2, L).T // 2 - 1).float()[:, :, None, None]
+    tol = mx / (2 * M) + mx * (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10)
+    assert ((dec - kv.float()).abs() <= tol).all()
