@@ -1,0 +1,227 @@
+/*
+ * lmc_hip.h -- C ABI of liblmc_hip.so, the MI355X (gfx950) KV hot path.
+ *
+ * Drop-in boundary for LMCache's CacheGen serde + host-DRAM offload path.
+ * Every entry point cites the reference interface it replaces (paths relative
+ * to the reference tree).  Conventions:
+ *   - plain C types only; pointers are DEVICE pointers unless suffixed _h
+ *     (host) -- no torch types cross this boundary;
+ *   - every call that touches the GPU takes the hipStream_t to run on
+ *     (`lmc_stream_t`, NULL = default stream), is ASYNCHRONOUS and never calls
+ *     hipDeviceSynchronize (the reference flags torch.cuda.synchronize() as
+ *     harmful on this path, lmcache/storage_backend/local_backend.py:83-85);
+ *   - return value: 0 = ok, negative = error (lmc_strerror); nothing throws;
+ *   - re-entrant per context: calls on different streams may interleave; the
+ *     context orders its internal workspace with events, not host syncs.
+ *
+ * Plane order everywhere: p = kv * L + layer (all K planes, then all V
+ * planes) -- the order of the reference's encode_input / cdf tensors
+ * (cachegen_encoder.py:284,290).
+ */
+#ifndef LMC_HIP_H
+#define LMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "lmc_format.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lmc_ctx lmc_ctx;
+typedef void* lmc_stream_t; /* hipStream_t */
+typedef void* lmc_event_t;  /* hipEvent_t  */
+
+#define LMC_OK 0
+#define LMC_ERR_INVALID (-1)     /* bad argument / unsupported geometry            */
+#define LMC_ERR_HIP (-2)         /* a HIP runtime call failed (see lmc_last_hip_error) */
+#define LMC_ERR_NOMEM (-3)
+#define LMC_ERR_DEVICE_FLAG (-4) /* a kernel reported an error (lmc_device_status)  */
+
+const char* lmc_strerror(int code);
+/* hipError_t of the last failing HIP call made by this library on this thread. */
+int lmc_last_hip_error(void);
+/* ABI version of this header. */
+int lmc_abi_version(void);
+#define LMC_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ */
+/* KV addressing                                                       */
+/* ------------------------------------------------------------------ */
+/*
+ * Where the 16-bit element (layer l, kv, token t, head h, dim d) of a KV cache
+ * lives.  One descriptor covers every layout the reference's engine and the
+ * (external) vLLM connector hand over:
+ *   - chunk blob  [L,2,T,H,D]  "vllm" fmt          (cache_engine.py:137-138)
+ *   - chunk blob  [L,2,H,T,D]  "huggingface" fmt   (cache_engine.py:139-140)
+ *   - the KVCache tuple of per-layer (K,V) tensors passed to
+ *     LMCacheEngine.store (cache_engine.py:230-236) -> plane_ptrs
+ *   - vLLM paged blocks addressed through slot_mapping
+ *     (docs/source/developer_tutorial/LLM_Engine.rst:91-122)
+ *
+ *   addr = plane_base(l,kv) + tok_off(t) + h*stride_head + d        [elements]
+ *   plane_base = plane_ptrs ? plane_ptrs[2*l+kv] : base + l*stride_layer + kv*stride_kv
+ *   tok_off(t) = slot_mapping ? (s / block_size)*stride_block + (s % block_size)*stride_token,
+ *                               s = slot_mapping[t]
+ *                             : t*stride_token
+ * d is contiguous; head_size must be a multiple of 8 (16-byte vectors).
+ */
+typedef struct lmc_kv_layout {
+  int32_t dtype;      /* LMC_DTYPE_BF16 / LMC_DTYPE_FP16 */
+  int32_t num_layers; /* L */
+  int32_t num_heads;  /* H (KV heads held by this rank) */
+  int32_t head_size;  /* D */
+  const void* base;
+  const void* const* plane_ptrs; /* device array [2L] of device pointers, or NULL */
+  int64_t stride_layer;
+  int64_t stride_kv;
+  int64_t stride_token;
+  int64_t stride_head;
+  const int64_t* slot_mapping; /* device [ntokens] or NULL */
+  int32_t block_size;
+  int32_t _pad;
+  int64_t stride_block;
+} lmc_kv_layout;
+
+/* ------------------------------------------------------------------ */
+/* context                                                             */
+/* ------------------------------------------------------------------ */
+/* Replaces the per-serializer device state of CacheGenSerializer /
+ * CacheGenDeserializer.__init__ (cachegen_encoder.py:330-350,
+ * cachegen_decoder.py:110-140: bins tensors, reusable output buffer). */
+int lmc_ctx_create(int device, lmc_ctx** out);
+int lmc_ctx_destroy(lmc_ctx* ctx);
+/* Pre-size the encode workspace (symbols + padded stream scratch) for up to
+ * max_chunks chunks of chunk_tokens tokens.  Optional: lmc_encode_chunks grows
+ * it on demand (growth allocates, i.e. may stall that one call). */
+int lmc_ctx_reserve(lmc_ctx* ctx, int L, int H, int D, int chunk_tokens, int max_chunks);
+/* Sticky status word written by kernels (0 = ok): stream overflow, bad blob
+ * header, inconsistent stream.  Valid once the work has completed (after an
+ * event / stream sync by the caller).  `clear` resets it. */
+int lmc_device_status(lmc_ctx* ctx, int clear);
+
+/* Per-kernel timing of the NEXT lmc_encode_chunks / lmc_decode_chunks calls:
+ * when enabled the call brackets each of its kernels with hipEvents on the
+ * caller's stream.  lmc_ctx_profile_read (after the caller has synchronised
+ * that stream) returns the durations in ms of the last profiled call, in
+ * launch order (encode: quantize, cdf_encode, scan_finalize, pack_streams;
+ * decode: decode) and the number of entries written (<= cap). */
+int lmc_ctx_profile(lmc_ctx* ctx, int enable);
+int lmc_ctx_profile_read(lmc_ctx* ctx, float* ms_out, int cap);
+
+/* ------------------------------------------------------------------ */
+/* encode side                                                         */
+/* ------------------------------------------------------------------ */
+/*
+ * Quantise tokens [tok_begin, tok_begin+ntok) of `src`.
+ * Replaces torch_quant_vectorized applied to K and V + the torch.cat that
+ * builds encode_input (cachegen_encoder.py:40-61, 278-285).
+ *   bins_h   host int32 [2L], plane order (key_bins ++ value_bins,
+ *            cachegen_encoder.py:339-350)
+ *   sym_out  int8  [2L][ntok][C]   (= encode_input)
+ *   scale_out u16  [2L][ntok]      raw bits of src dtype (= max_tensors_key ++ max_tensors_value)
+ */
+int lmc_quantize(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin, int32_t ntok,
+                 const int32_t* bins_h, int8_t* sym_out, uint16_t* scale_out, lmc_stream_t stream);
+
+/*
+ * Replaces torchac_cuda.calculate_cdf(sym, max_bins) (call sites
+ * cachegen_encoder.py:287-289): per-(plane,channel) histogram over tokens ->
+ * 16-bit strictly increasing CDF.
+ *   sym int8 [P][T][C], cdf_out u16 [P][C][max_bins+1]; max_bins must be 32.
+ */
+int lmc_calculate_cdf(lmc_ctx* ctx, const int8_t* sym, int32_t P, int32_t T, int32_t C, int32_t max_bins,
+                      uint16_t* cdf_out, lmc_stream_t stream);
+
+/*
+ * Fused encode of consecutive token chunks: quantise + CDF + entropy-encode +
+ * compaction + container, one blob per chunk.  Replaces, per chunk,
+ * LMCacheEngine._slice_kv_at (cache_engine.py:131-161) +
+ * CacheGenSerializer.to_bytes -> encode_function -> encode_ntokens/
+ * torchac_cuda.encode_fast_new -> collect_bytes -> CacheGenGPUEncoderOutput
+ * (cachegen_encoder.py:225-325, 352-389), minus the pickle/D2H which is
+ * lmc_memcpy_async's job.
+ *   chunk i covers tokens [tok_begin + i*chunk_tokens, min(+chunk_tokens, tok_end))
+ *   blobs    device arena; blob i is written at blobs + i*blob_stride;
+ *            blob_stride >= lmc_blob_bound(L, chunk_tokens, H, D), multiple of 16
+ *   sizes    device-accessible uint32 [nchunks] (device or pinned host memory):
+ *            receives total_bytes of each blob
+ */
+int lmc_encode_chunks(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end,
+                      int32_t chunk_tokens, const int32_t* bins_h, void* blobs, uint64_t blob_stride,
+                      uint32_t* sizes, lmc_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* decode side                                                         */
+/* ------------------------------------------------------------------ */
+/*
+ * Fused decode of nchunks blobs straight into the destination layout:
+ * entropy-decode + dequantise + cast + scatter.  Replaces, per chunk,
+ * CacheGenDeserializer.from_bytes -> decode_function_gpu -> decode_chunk /
+ * torchac_cuda.decode_fast_prefsum -> do_dequantize -> stack/reshape/permute/
+ * .to(16-bit) (cachegen_decoder.py:24-35, 51-106, 142-202) and the engine's
+ * torch.cat over chunks (cache_engine.py:362-368).
+ *   blob i is read from blobs + i*blob_stride (device memory)
+ *   token t of chunk i is written to dst token  dst_tok0 + i*chunk_tokens + t;
+ *   tokens that land below 0 are dropped (the "drop extra tokens in the first
+ *   chunk" rule of retrieve(), cache_engine.py:360-365: pass dst_tok0 = -skip)
+ *   dst->dtype selects the output type (bf16 for "vllm", fp16 for
+ *   "huggingface": cachegen_decoder.py:190-200)
+ */
+int lmc_decode_chunks(lmc_ctx* ctx, const void* blobs, uint64_t blob_stride, int32_t nchunks,
+                      const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, lmc_stream_t stream);
+
+/* Entropy-decode only (debug / parity): blob -> sym_out int8 [P][T][C].
+ * Stands where torchac_cuda.decode_fast_prefsum stands (cachegen_decoder.py:65-66). */
+int lmc_decode_symbols(lmc_ctx* ctx, const void* blob, int32_t L, int32_t H, int32_t D, int8_t* sym_out,
+                       lmc_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* lossless gather / scatter (raw chunks)                              */
+/* ------------------------------------------------------------------ */
+/*
+ * Copy tokens [tok_begin, +ntok) between an arbitrary KV layout and a
+ * contiguous chunk.  Replaces _tuple_kv_to_blob + _slice_kv_at
+ * (cache_engine.py:98-161) on the store side, torch.cat + _blob_to_tuple_kv
+ * (cache_engine.py:120-129, 362-368) on the retrieve side, and the external
+ * connector's slot_mapping gather / reshape_and_cache_flash scatter
+ * (LLM_Engine.rst:91-122).  Both layouts share L, H, D and dtype.
+ * dst token index = dst_tok0 + (t - tok_begin).
+ */
+int lmc_copy_kv(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin, int32_t ntok,
+                const lmc_kv_layout* dst, int32_t dst_tok0, lmc_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* host DRAM offload plumbing                                          */
+/* ------------------------------------------------------------------ */
+/* Pinned, device-accessible host memory (hipHostMalloc).  Replaces the
+ * pageable kv_chunk.to("cpu") of LMCLocalBackend.put_blocking and its stubbed
+ * pin-memory path (local_backend.py:50,82-100). */
+int lmc_pinned_alloc(size_t bytes, void** out_h);
+int lmc_pinned_free(void* ptr_h);
+/* hipMemcpyAsync on `stream`; kind: 0 = D2H, 1 = H2D, 2 = D2D. */
+int lmc_memcpy_async(void* dst, const void* src, size_t bytes, int kind, lmc_stream_t stream);
+
+int lmc_stream_create(lmc_stream_t* out);
+int lmc_stream_destroy(lmc_stream_t s);
+int lmc_stream_synchronize(lmc_stream_t s);
+int lmc_stream_wait_event(lmc_stream_t s, lmc_event_t e);
+int lmc_event_create(lmc_event_t* out, int timing);
+int lmc_event_destroy(lmc_event_t e);
+int lmc_event_record(lmc_event_t e, lmc_stream_t s);
+int lmc_event_synchronize(lmc_event_t e);
+/* 1 = complete, 0 = pending, negative = error */
+int lmc_event_query(lmc_event_t e);
+int lmc_event_elapsed_ms(lmc_event_t start, lmc_event_t stop, float* ms);
+
+/* Host-side blob header check/parse (no GPU).  Stands where
+ * CacheGenEncoderOutput.from_bytes is used to inspect a blob
+ * (tests/test_serde.py:60-62). */
+int lmc_blob_info(const void* blob_h, size_t nbytes, lmc_blob_header* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMC_HIP_H */

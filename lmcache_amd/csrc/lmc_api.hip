@@ -1,0 +1,480 @@
+// lmc_api.hip -- C ABI (include/lmc_hip.h) over the gfx950 kernels.
+//
+// Host side only does argument checking, workspace management and kernel
+// launches.  Nothing here synchronises the device; the workspace shared by
+// successive encode calls is ordered with an event recorded after the last
+// kernel of a job and waited on by the first kernel of the next one.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <new>
+#include <string.h>
+
+#include "../../include/lmc_hip.h"
+#include "k_copy.h"
+#include "k_decode.h"
+#include "k_encode.h"
+#include "k_quantize.h"
+
+static thread_local int g_last_hip = 0;
+
+#define HIP_TRY(expr)                      \
+  do {                                     \
+    hipError_t e__ = (expr);               \
+    if (e__ != hipSuccess) {               \
+      g_last_hip = (int)e__;               \
+      return LMC_ERR_HIP;                  \
+    }                                      \
+  } while (0)
+
+struct lmc_ctx {
+  int device;
+  std::mutex mu;
+  // encode workspace
+  u32* sym4 = nullptr;  size_t sym4_bytes = 0;
+  u8* scratch = nullptr; size_t scratch_bytes = 0;
+  u32* glen = nullptr;  u32* goff = nullptr; size_t glen_bytes = 0;
+  hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
+  bool ws_used = false;
+  u32* status_h = nullptr;  // pinned, device-accessible
+  // optional per-kernel timing (lmc_ctx_profile)
+  bool profile = false;
+  hipEvent_t pev[8] = {};
+  int pn = 0;  // events recorded by the last profiled call
+};
+
+// Record the next timing event of a profiled call (no-op when profiling is off).
+static int prof_mark(lmc_ctx* c, hipStream_t s) {
+  if (!c->profile) return LMC_OK;
+  if (c->pn >= 8) return LMC_OK;
+  if (!c->pev[c->pn]) HIP_TRY(hipEventCreate(&c->pev[c->pn]));
+  HIP_TRY(hipEventRecord(c->pev[c->pn], s));
+  c->pn++;
+  return LMC_OK;
+}
+
+extern "C" {
+
+const char* lmc_strerror(int code) {
+  switch (code) {
+    case LMC_OK: return "ok";
+    case LMC_ERR_INVALID: return "invalid argument or unsupported geometry";
+    case LMC_ERR_HIP: return "HIP runtime error (see lmc_last_hip_error)";
+    case LMC_ERR_NOMEM: return "out of memory";
+    case LMC_ERR_DEVICE_FLAG: return "a kernel flagged an error (see lmc_device_status)";
+    default: return "unknown error";
+  }
+}
+int lmc_last_hip_error(void) { return g_last_hip; }
+int lmc_abi_version(void) { return LMC_ABI_VERSION; }
+
+int lmc_ctx_create(int device, lmc_ctx** out) {
+  if (!out) return LMC_ERR_INVALID;
+  HIP_TRY(hipSetDevice(device));
+  lmc_ctx* c = new (std::nothrow) lmc_ctx();
+  if (!c) return LMC_ERR_NOMEM;
+  c->device = device;
+  hipError_t e = hipHostMalloc((void**)&c->status_h, 64, hipHostMallocMapped | hipHostMallocPortable);
+  if (e != hipSuccess) { g_last_hip = (int)e; delete c; return LMC_ERR_HIP; }
+  memset(c->status_h, 0, 64);
+  e = hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming);
+  if (e != hipSuccess) { g_last_hip = (int)e; (void)hipHostFree(c->status_h); delete c; return LMC_ERR_HIP; }
+  *out = c;
+  return LMC_OK;
+}
+
+int lmc_ctx_destroy(lmc_ctx* c) {
+  if (!c) return LMC_OK;
+  (void)hipSetDevice(c->device);
+  if (c->ws_used) (void)hipEventSynchronize(c->ws_free);
+  if (c->sym4) (void)hipFree(c->sym4);
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->glen) (void)hipFree(c->glen);
+  if (c->goff) (void)hipFree(c->goff);
+  if (c->ws_free) (void)hipEventDestroy(c->ws_free);
+  for (int i = 0; i < 8; i++) if (c->pev[i]) (void)hipEventDestroy(c->pev[i]);
+  if (c->status_h) (void)hipHostFree(c->status_h);
+  delete c;
+  return LMC_OK;
+}
+
+int lmc_ctx_profile(lmc_ctx* c, int enable) {
+  if (!c) return LMC_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->profile = enable != 0;
+  c->pn = 0;
+  return LMC_OK;
+}
+
+int lmc_ctx_profile_read(lmc_ctx* c, float* ms_out, int cap) {
+  if (!c || !ms_out || cap < 1) return LMC_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  int n = 0;
+  for (int i = 0; i + 1 < c->pn && n < cap; i++, n++)
+    HIP_TRY(hipEventElapsedTime(&ms_out[n], c->pev[i], c->pev[i + 1]));
+  return n;
+}
+
+int lmc_device_status(lmc_ctx* c, int clear) {
+  if (!c) return LMC_ERR_INVALID;
+  int v = (int)__atomic_load_n(c->status_h, __ATOMIC_ACQUIRE);
+  if (clear) __atomic_store_n(c->status_h, 0u, __ATOMIC_RELEASE);
+  return v;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+static bool layout_ok(const lmc_kv_layout* l) {
+  if (!l) return false;
+  if (l->dtype != LMC_DTYPE_BF16 && l->dtype != LMC_DTYPE_FP16) return false;
+  if (l->num_layers < 1 || 2 * l->num_layers > LMC_MAX_PLANES) return false;
+  if (l->num_heads < 1 || l->head_size < 8 || (l->head_size & 7)) return false;
+  if (!l->base && !l->plane_ptrs) return false;
+  // 16-byte vectors: every stride a multiple of 8 elements, base 16-byte aligned
+  if ((l->stride_token & 7) || (l->stride_head & 7)) return false;
+  if (!l->plane_ptrs && ((l->stride_layer & 7) || (l->stride_kv & 7) || ((uintptr_t)l->base & 15))) return false;
+  if (l->slot_mapping && (l->block_size < 1 || (l->stride_block & 7))) return false;
+  return true;
+}
+
+static KvAddr to_addr(const lmc_kv_layout* l) {
+  KvAddr a;
+  a.base = (const u16*)l->base;
+  a.plane_ptrs = (const u16* const*)l->plane_ptrs;
+  a.slot_mapping = (const long long*)l->slot_mapping;
+  a.stride_layer = l->stride_layer; a.stride_kv = l->stride_kv; a.stride_token = l->stride_token;
+  a.stride_head = l->stride_head; a.stride_block = l->stride_block;
+  a.block_size = l->block_size > 0 ? l->block_size : 1;
+  a.L = l->num_layers; a.H = l->num_heads; a.D = l->head_size; a.dtype = l->dtype;
+  return a;
+}
+
+static bool bins_ok(const int32_t* bins_h, int P, BinsArg* out) {
+  if (!bins_h) return false;
+  memset(out, 0, sizeof *out);
+  for (int p = 0; p < P; p++) {
+    // MAX = bins//2 - 1 >= 1 and symbols 0..2*MAX must fit the 32-entry CDF
+    if (bins_h[p] < 4 || bins_h[p] > LMC_MAX_BINS) return false;
+    out->b[p] = (u8)bins_h[p];
+  }
+  return true;
+}
+
+template <int DT, bool QUAD>
+static int launch_quant_dt(const QuantArgs& a, hipStream_t s) {
+  const int C = a.C;
+  long long nq = a.nquads;
+#define LQ(G, N)                                                                                   \
+  do {                                                                                             \
+    long long per_wg = 4LL * (64 / (G));                                                           \
+    unsigned grid = (unsigned)((nq + per_wg - 1) / per_wg);                                        \
+    hipLaunchKernelGGL((k_quantize<G, N, DT, QUAD>), dim3(grid), dim3(256), 0, s, a);              \
+  } while (0)
+  if (C <= 128) LQ(16, 1);
+  else if (C <= 256) LQ(32, 1);
+  else if (C <= 512) LQ(64, 1);
+  else if (C <= 1024) LQ(64, 2);
+  else if (C <= 2048) LQ(64, 4);
+  else if (C <= 4096) LQ(64, 8);
+  else return LMC_ERR_INVALID;
+#undef LQ
+  HIP_TRY(hipGetLastError());
+  return LMC_OK;
+}
+
+template <bool QUAD>
+static int launch_quant(const QuantArgs& a, hipStream_t s) {
+  return a.src.dtype == LMC_DTYPE_BF16 ? launch_quant_dt<LMC_DTYPE_BF16, QUAD>(a, s)
+                                       : launch_quant_dt<LMC_DTYPE_FP16, QUAD>(a, s);
+}
+
+static int ws_grow(void** p, size_t* have, size_t need) {
+  if (*have >= need) return LMC_OK;
+  if (*p) { hipError_t e = hipFree(*p); if (e != hipSuccess) { g_last_hip = (int)e; return LMC_ERR_HIP; } *p = nullptr; *have = 0; }
+  need = (need + (size_t)(1 << 20)) & ~(size_t)((1 << 20) - 1);
+  hipError_t e = hipMalloc(p, need);
+  if (e != hipSuccess) { g_last_hip = (int)e; return e == hipErrorOutOfMemory ? LMC_ERR_NOMEM : LMC_ERR_HIP; }
+  *have = need;
+  return LMC_OK;
+}
+
+// caller holds ctx->mu
+static int reserve_locked(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_chunks) {
+  const size_t P = 2 * (size_t)L, C = (size_t)H * D, G = (C + 63) / 64, TQ = ((size_t)chunk_tokens + 3) / 4;
+  const size_t need_sym = (size_t)max_chunks * P * TQ * C * 4;
+  const size_t need_scr = (size_t)max_chunks * P * G * lmc_group_cap_bytes((uint32_t)chunk_tokens);
+  const size_t need_len = (size_t)max_chunks * P * G * 4;
+  if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && need_len <= c->glen_bytes) return LMC_OK;
+  // growing frees memory that queued kernels may still use: wait for them (this call only)
+  if (c->ws_used) HIP_TRY(hipEventSynchronize(c->ws_free));
+  int rc;
+  if ((rc = ws_grow((void**)&c->sym4, &c->sym4_bytes, need_sym))) return rc;
+  if ((rc = ws_grow((void**)&c->scratch, &c->scratch_bytes, need_scr))) return rc;
+  if (need_len > c->glen_bytes) {
+    size_t h1 = c->glen_bytes, h2 = c->glen_bytes;
+    if ((rc = ws_grow((void**)&c->glen, &h1, need_len))) return rc;
+    if ((rc = ws_grow((void**)&c->goff, &h2, need_len))) return rc;
+    c->glen_bytes = h1 < h2 ? h1 : h2;
+  }
+  return LMC_OK;
+}
+
+extern "C" {
+
+int lmc_ctx_reserve(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_chunks) {
+  if (!c || L < 1 || H < 1 || D < 8 || chunk_tokens < 1 || max_chunks < 1) return LMC_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  return reserve_locked(c, L, H, D, chunk_tokens, max_chunks);
+}
+
+int lmc_quantize(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t ntok, const int32_t* bins_h,
+                 int8_t* sym_out, uint16_t* scale_out, lmc_stream_t stream) {
+  if (!c || !layout_ok(src) || ntok < 1 || ntok > 65535 || tok_begin < 0 || !sym_out || !scale_out) return LMC_ERR_INVALID;
+  QuantArgs a;
+  memset(&a, 0, sizeof a);
+  a.src = to_addr(src);
+  a.P = 2 * src->num_layers;
+  if (!bins_ok(bins_h, a.P, &a.bins)) return LMC_ERR_INVALID;
+  a.C = src->num_heads * src->head_size;
+  a.tok_begin = tok_begin; a.tok_end = tok_begin + ntok; a.chunk_tokens = ntok; a.nchunks = 1;
+  a.TQ = (ntok + 3) / 4;
+  a.nquads = (long long)a.P * a.TQ;
+  a.sym8 = sym_out;
+  a.scale_base = (u8*)scale_out; a.scale_stride = 0;
+  HIP_TRY(hipSetDevice(c->device));
+  return launch_quant<false>(a, (hipStream_t)stream);
+}
+
+int lmc_calculate_cdf(lmc_ctx* c, const int8_t* sym, int32_t P, int32_t T, int32_t C, int32_t max_bins,
+                      uint16_t* cdf_out, lmc_stream_t stream) {
+  if (!c || !sym || !cdf_out || P < 1 || T < 1 || T > 65535 || C < 8 || (C & 7) || max_bins != LMC_MAX_BINS)
+    return LMC_ERR_INVALID;
+  EncodeArgs a;
+  memset(&a, 0, sizeof a);
+  a.sym8 = sym;
+  a.tok_begin = 0; a.tok_end = T; a.chunk_tokens = T; a.nchunks = 1;
+  a.P = P; a.C = C; a.G = (C + 63) / 64; a.TQ = (T + 3) / 4;
+  a.cdf_out = cdf_out;
+  a.status = c->status_h;
+  HIP_TRY(hipSetDevice(c->device));
+  long long n = (long long)P * a.G;
+  hipLaunchKernelGGL((k_cdf_encode<false, false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return LMC_OK;
+}
+
+int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
+                      const int32_t* bins_h, void* blobs, uint64_t blob_stride, uint32_t* sizes, lmc_stream_t stream) {
+  if (!c || !layout_ok(src) || tok_begin < 0 || tok_end <= tok_begin || chunk_tokens < 1 || chunk_tokens > 65535 ||
+      !blobs || !sizes || ((uintptr_t)blobs & 15) || (blob_stride & 15))
+    return LMC_ERR_INVALID;
+  const int L = src->num_layers, H = src->num_heads, D = src->head_size;
+  const int P = 2 * L, C = H * D, G = (C + 63) / 64;
+  if (C > 4096) return LMC_ERR_INVALID;
+  const int nchunks = (tok_end - tok_begin + chunk_tokens - 1) / chunk_tokens;
+  if (blob_stride < lmc_blob_bound((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D)) return LMC_ERR_INVALID;
+  BinsArg bins;
+  if (!bins_ok(bins_h, P, &bins)) return LMC_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+
+  std::lock_guard<std::mutex> lk(c->mu);
+  int rc = reserve_locked(c, L, H, D, chunk_tokens, nchunks);
+  if (rc) return rc;
+  if (c->ws_used) HIP_TRY(hipStreamWaitEvent(s, c->ws_free, 0));
+
+  const int TQ = (chunk_tokens + 3) / 4;
+  const u32 cap = lmc_group_cap_bytes((uint32_t)chunk_tokens);
+  lmc_blob_header hl;
+  lmc_blob_layout((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D, &hl);
+
+  QuantArgs qa;
+  memset(&qa, 0, sizeof qa);
+  qa.src = to_addr(src); qa.bins = bins;
+  qa.tok_begin = tok_begin; qa.tok_end = tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = nchunks;
+  qa.P = P; qa.C = C; qa.TQ = TQ; qa.nquads = (long long)nchunks * P * TQ;
+  qa.sym4 = c->sym4;
+  qa.scale_base = (u8*)blobs + hl.off_scales;  // off_scales does not depend on T
+  qa.scale_stride = (long long)blob_stride;
+  c->pn = 0;
+  if ((rc = prof_mark(c, s))) return rc;
+  rc = launch_quant<true>(qa, s);
+  if (rc) return rc;
+  if ((rc = prof_mark(c, s))) return rc;
+
+  EncodeArgs ea;
+  memset(&ea, 0, sizeof ea);
+  ea.sym4 = c->sym4;
+  ea.tok_begin = tok_begin; ea.tok_end = tok_end; ea.chunk_tokens = chunk_tokens; ea.nchunks = nchunks;
+  ea.P = P; ea.C = C; ea.G = G; ea.TQ = TQ;
+  ea.blobs = (u8*)blobs; ea.blob_stride = (long long)blob_stride;
+  ea.scratch = c->scratch; ea.cap = cap; ea.glen = c->glen; ea.status = c->status_h;
+  const long long ngroups = (long long)nchunks * P * G;
+  hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, ea);
+  HIP_TRY(hipGetLastError());
+  if ((rc = prof_mark(c, s))) return rc;
+
+  ScanArgs sa;
+  memset(&sa, 0, sizeof sa);
+  sa.blobs = (u8*)blobs; sa.blob_stride = (long long)blob_stride;
+  sa.glen = c->glen; sa.goff = c->goff; sa.sizes = sizes; sa.bins = bins;
+  sa.tok_begin = tok_begin; sa.tok_end = tok_end; sa.chunk_tokens = chunk_tokens;
+  sa.L = L; sa.H = H; sa.D = D; sa.P = P; sa.C = C; sa.G = G; sa.dtype = src->dtype;
+  hipLaunchKernelGGL(k_scan_finalize, dim3((unsigned)nchunks), dim3(1024), 0, s, sa);
+  HIP_TRY(hipGetLastError());
+  if ((rc = prof_mark(c, s))) return rc;
+
+  PackArgs pa;
+  memset(&pa, 0, sizeof pa);
+  pa.blobs = (u8*)blobs; pa.blob_stride = (long long)blob_stride;
+  pa.scratch = c->scratch; pa.cap = cap; pa.glen = c->glen; pa.goff = c->goff;
+  pa.tok_begin = tok_begin; pa.tok_end = tok_end; pa.chunk_tokens = chunk_tokens;
+  pa.P = P; pa.C = C; pa.G = G; pa.ngroups_total = ngroups;
+  hipLaunchKernelGGL(k_pack_streams, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, pa);
+  HIP_TRY(hipGetLastError());
+  if ((rc = prof_mark(c, s))) return rc;
+
+  HIP_TRY(hipEventRecord(c->ws_free, s));
+  c->ws_used = true;
+  return LMC_OK;
+}
+
+static int decode_common(lmc_ctx* c, const void* blobs, uint64_t blob_stride, int nchunks, int L, int H, int D,
+                         DecodeArgs& a) {
+  if (!c || !blobs || nchunks < 1 || ((uintptr_t)blobs & 15) || (blob_stride & 15)) return LMC_ERR_INVALID;
+  a.blobs = (const u8*)blobs; a.blob_stride = (long long)blob_stride; a.nchunks = nchunks;
+  a.P = 2 * L; a.C = H * D; a.G = (a.C + 63) / 64;
+  a.status = c->status_h;
+  return LMC_OK;
+}
+
+int lmc_decode_chunks(lmc_ctx* c, const void* blobs, uint64_t blob_stride, int32_t nchunks, const lmc_kv_layout* dst,
+                      int32_t dst_tok0, int32_t chunk_tokens, lmc_stream_t stream) {
+  if (!layout_ok(dst) || chunk_tokens < 1) return LMC_ERR_INVALID;
+  DecodeArgs a;
+  memset(&a, 0, sizeof a);
+  int rc = decode_common(c, blobs, blob_stride, nchunks, dst->num_layers, dst->num_heads, dst->head_size, a);
+  if (rc) return rc;
+  a.dst = to_addr(dst); a.dst_tok0 = dst_tok0; a.chunk_tokens = chunk_tokens;
+  HIP_TRY(hipSetDevice(c->device));
+  const long long n = (long long)nchunks * a.P * a.G;
+  dim3 grid((unsigned)((n + 3) / 4));
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->pn = 0;
+  if ((rc = prof_mark(c, (hipStream_t)stream))) return rc;
+  if (dst->dtype == LMC_DTYPE_BF16)
+    hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  if ((rc = prof_mark(c, (hipStream_t)stream))) return rc;
+  return LMC_OK;
+}
+
+int lmc_decode_symbols(lmc_ctx* c, const void* blob, int32_t L, int32_t H, int32_t D, int8_t* sym_out,
+                       lmc_stream_t stream) {
+  if (!sym_out || L < 1 || H < 1 || D < 8) return LMC_ERR_INVALID;
+  DecodeArgs a;
+  memset(&a, 0, sizeof a);
+  int rc = decode_common(c, blob, 0, 1, L, H, D, a);
+  if (rc) return rc;
+  a.sym_out = sym_out;
+  HIP_TRY(hipSetDevice(c->device));
+  const long long n = (long long)a.P * a.G;
+  hipLaunchKernelGGL((k_decode<true, LMC_DTYPE_BF16>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return LMC_OK;
+}
+
+int lmc_copy_kv(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t ntok, const lmc_kv_layout* dst,
+                int32_t dst_tok0, lmc_stream_t stream) {
+  if (!c || !layout_ok(src) || !layout_ok(dst) || ntok < 1 || tok_begin < 0 || dst_tok0 < 0) return LMC_ERR_INVALID;
+  if (src->num_layers != dst->num_layers || src->num_heads != dst->num_heads || src->head_size != dst->head_size ||
+      src->dtype != dst->dtype)
+    return LMC_ERR_INVALID;
+  CopyArgs a;
+  memset(&a, 0, sizeof a);
+  a.src = to_addr(src); a.dst = to_addr(dst);
+  a.tok_begin = tok_begin; a.ntok = ntok; a.dst_tok0 = dst_tok0;
+  a.P = 2 * src->num_layers; a.C = src->num_heads * src->head_size;
+  a.nvec = (long long)a.P * ntok * (a.C / 8);
+  HIP_TRY(hipSetDevice(c->device));
+  long long blocks = (a.nvec + 255) / 256;
+  if (blocks > 256LL * 64) blocks = 256LL * 64;  // grid-stride beyond 64 blocks per CU
+  hipLaunchKernelGGL(k_copy_kv, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return LMC_OK;
+}
+
+// ---- host DRAM offload plumbing ---------------------------------------------
+int lmc_pinned_alloc(size_t bytes, void** out_h) {
+  if (!out_h || bytes == 0) return LMC_ERR_INVALID;
+  hipError_t e = hipHostMalloc(out_h, bytes, hipHostMallocMapped | hipHostMallocPortable);
+  if (e != hipSuccess) { g_last_hip = (int)e; return e == hipErrorOutOfMemory ? LMC_ERR_NOMEM : LMC_ERR_HIP; }
+  return LMC_OK;
+}
+int lmc_pinned_free(void* p) { if (p) HIP_TRY(hipHostFree(p)); return LMC_OK; }
+
+int lmc_memcpy_async(void* dst, const void* src, size_t bytes, int kind, lmc_stream_t stream) {
+  if (!dst || !src) return LMC_ERR_INVALID;
+  if (bytes == 0) return LMC_OK;
+  hipMemcpyKind k = kind == 0 ? hipMemcpyDeviceToHost : kind == 1 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  if (kind < 0 || kind > 2) return LMC_ERR_INVALID;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, k, (hipStream_t)stream));
+  return LMC_OK;
+}
+
+int lmc_stream_create(lmc_stream_t* out) {
+  if (!out) return LMC_ERR_INVALID;
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *out = (lmc_stream_t)s;
+  return LMC_OK;
+}
+int lmc_stream_destroy(lmc_stream_t s) { HIP_TRY(hipStreamDestroy((hipStream_t)s)); return LMC_OK; }
+int lmc_stream_synchronize(lmc_stream_t s) { HIP_TRY(hipStreamSynchronize((hipStream_t)s)); return LMC_OK; }
+int lmc_stream_wait_event(lmc_stream_t s, lmc_event_t e) { HIP_TRY(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0)); return LMC_OK; }
+int lmc_event_create(lmc_event_t* out, int timing) {
+  if (!out) return LMC_ERR_INVALID;
+  hipEvent_t e;
+  HIP_TRY(hipEventCreateWithFlags(&e, timing ? hipEventDefault : hipEventDisableTiming));
+  *out = (lmc_event_t)e;
+  return LMC_OK;
+}
+int lmc_event_destroy(lmc_event_t e) { HIP_TRY(hipEventDestroy((hipEvent_t)e)); return LMC_OK; }
+int lmc_event_record(lmc_event_t e, lmc_stream_t s) { HIP_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); return LMC_OK; }
+int lmc_event_synchronize(lmc_event_t e) { HIP_TRY(hipEventSynchronize((hipEvent_t)e)); return LMC_OK; }
+int lmc_event_query(lmc_event_t e) {
+  hipError_t r = hipEventQuery((hipEvent_t)e);
+  if (r == hipSuccess) return 1;
+  if (r == hipErrorNotReady) return 0;
+  g_last_hip = (int)r;
+  return LMC_ERR_HIP;
+}
+int lmc_event_elapsed_ms(lmc_event_t a, lmc_event_t b, float* ms) {
+  if (!ms) return LMC_ERR_INVALID;
+  HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return LMC_OK;
+}
+
+int lmc_blob_info(const void* blob_h, size_t nbytes, lmc_blob_header* out) {
+  if (!blob_h || !out || nbytes < sizeof(lmc_blob_header)) return LMC_ERR_INVALID;
+  lmc_blob_header h;
+  memcpy(&h, blob_h, sizeof h);
+  if (h.magic != LMC_BLOB_MAGIC || h.version != LMC_BLOB_VERSION || h.header_bytes != LMC_HEADER_BYTES) return LMC_ERR_INVALID;
+  lmc_blob_header ref;
+  memset(&ref, 0, sizeof ref);
+  if (h.num_layers == 0 || h.ntokens == 0 || h.num_heads == 0 || h.head_size == 0) return LMC_ERR_INVALID;
+  lmc_blob_layout(h.num_layers, h.ntokens, h.num_heads, h.head_size, &ref);
+  if (h.nchannels != ref.nchannels || h.nplanes != ref.nplanes || h.ngroups != ref.ngroups || h.lp != ref.lp ||
+      h.off_bins != ref.off_bins || h.off_scales != ref.off_scales || h.off_cdf != ref.off_cdf ||
+      h.off_gend != ref.off_gend || h.off_streams != ref.off_streams)
+    return LMC_ERR_INVALID;
+  if (h.total_bytes != h.off_streams + h.stream_bytes || h.total_bytes > nbytes) return LMC_ERR_INVALID;
+  *out = h;
+  return LMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// lmc_device.h -- device-side helpers shared by the gfx950 kernels.
+// CDNA4 only: wave64, no portability shims.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lmc_format.h"
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define LMC_WAVE 64
+#define LMC_MAX_PLANES 256
+
+// Device status bits (lmc_device_status).
+#define LMC_ST_STREAM_OVERFLOW 1u
+#define LMC_ST_BAD_HEADER 2u
+#define LMC_ST_BAD_STREAM 4u
+
+// Device copy of lmc_kv_layout (include/lmc_hip.h), strides in elements.
+struct KvAddr {
+  const u16* base;
+  const u16* const* plane_ptrs;
+  const long long* slot_mapping;
+  long long stride_layer, stride_kv, stride_token, stride_head, stride_block;
+  int block_size;
+  int L, H, D, dtype;
+};
+
+struct BinsArg {
+  u8 b[LMC_MAX_PLANES];
+};
+
+__device__ __forceinline__ const u16* lmc_plane_base(const KvAddr& a, int p) {
+  int kv = p / a.L, l = p - kv * a.L;
+  if (a.plane_ptrs) return a.plane_ptrs[2 * l + kv];
+  return a.base + (long long)l * a.stride_layer + (long long)kv * a.stride_kv;
+}
+
+__device__ __forceinline__ long long lmc_tok_off(const KvAddr& a, int t) {
+  if (a.slot_mapping) {
+    u32 s = (u32)a.slot_mapping[t];
+    u32 b = s / (u32)a.block_size;
+    u32 w = s - b * (u32)a.block_size;
+    return (long long)b * a.stride_block + (long long)w * a.stride_token;
+  }
+  return (long long)t * a.stride_token;
+}
+
+// Section offsets of a chunk blob with T tokens (mirror of lmc_blob_layout).
+struct BlobOff {
+  u32 bins, scales, cdf, gend, streams;
+};
+__device__ __forceinline__ BlobOff lmc_blob_off(u32 P, u32 T, u32 C, u32 G) {
+  BlobOff o;
+  o.bins = LMC_HEADER_BYTES;
+  o.scales = o.bins + ((P + 15u) & ~15u);
+  o.cdf = o.scales + ((2u * P * T + 15u) & ~15u);
+  o.gend = o.cdf + ((2u * P * C * LMC_LP + 15u) & ~15u);
+  o.streams = o.gend + ((4u * P * G + 15u) & ~15u);
+  return o;
+}
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// max of two packed u16 pairs (v_pk_max_u16)
+__device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
+  us2 x = __builtin_bit_cast(us2, a), y = __builtin_bit_cast(us2, b);
+  us2 z = __builtin_elementwise_max(x, y);
+  return __builtin_bit_cast(u32, z);
+}
+
+template <int DT>
+__device__ __forceinline__ float h_lo(u32 w) {  // low 16-bit element of a packed pair -> fp32
+  if (DT == LMC_DTYPE_BF16) return __uint_as_float(w << 16);
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
+}
+template <int DT>
+__device__ __forceinline__ float h_hi(u32 w) {
+  if (DT == LMC_DTYPE_BF16) return __uint_as_float(w & 0xffff0000u);
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+}
+__device__ __forceinline__ float h2f_rt(u32 bits, int dtype) {
+  if (dtype == LMC_DTYPE_BF16) return __uint_as_float(bits << 16);
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)bits);
+}
+
+// fp32 -> bf16 bits, round-to-nearest-even; NaN -> 0x7FC0 (c10::BFloat16).
+__device__ __forceinline__ u32 f2bf16(float f) {
+  u32 u = __float_as_uint(f);
+  u32 r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  return (f != f) ? 0x7fc0u : r;
+}
+__device__ __forceinline__ u32 f2fp16(float f) {  // v_cvt_f16_f32, RNE
+  return (u32)__builtin_bit_cast(unsigned short, (_Float16)f);
+}
+
+// Order this wave's LDS traffic (cross-lane hand-off inside one wave): a
+// compiler + hardware fence at wavefront scope; no workgroup barrier needed.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ u32 lane_rank(u64 mask) {  // # set bits of mask below this lane
+  return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+
+// RNE(v / T) for wave-uniform T; magic = floor(2^32 / T) (0xffffffff for T == 1).
+// v = n * 65504 with n <= T < 65536, so v < 2^32.
+__device__ __forceinline__ u32 rne_div_u32(u32 v, u32 T, u32 magic) {
+  u32 q = __umulhi(v, magic);
+  u32 r = v - q * T;
+  if (r >= T) { q++; r -= T; }
+  if (r >= T) { q++; r -= T; }
+  u32 r2 = 2u * r;
+  q += (r2 > T || (r2 == T && (q & 1u))) ? 1u : 0u;
+  return q;
+}
+
+// Exact (x / f, x % f) for x < f * 2^16, 1 <= f < 2^16, through a float
+// reciprocal estimate corrected by at most one step either way.
+__device__ __forceinline__ void divmod_est(u32 x, u32 f, u32& q, u32& r) {
+  float rf = __builtin_amdgcn_rcpf((float)f);
+  u32 qe = (u32)((float)x * rf);
+  u32 re = x - __umul24(qe, f);
+  if ((int)re < 0) { qe--; re += f; }
+  else if (re >= f) { qe++; re -= f; }
+  q = qe; r = re;
+}

@@ -1,0 +1,445 @@
+"""ctypes binding of liblmc_hip.so (include/lmc_hip.h) -- the only door from the
+Python host side into the HIP hot path.
+
+There is NO CPU fallback: if the library is missing or was not built for this
+box the import-time loader raises, and every product entry point fails loudly.
+torch is used only as plumbing (device memory, streams); torch types never
+cross the C ABI -- tensors are passed as raw device pointers.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+from typing import Optional, Sequence, Tuple
+
+import torch  # must be imported before the .so so that a single libamdhip64 (torch's) is loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "liblmc_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+BF16, FP16 = 0, 1
+LANES, MAX_BINS, LP = 64, 32, 33
+HEADER_BYTES = 128
+BLOB_MAGIC = 0x31434D4C
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing",
+               "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wl,-rpath,/opt/rocm/lib"]
+
+
+def build(force: bool = False) -> str:
+    """Compile lmcache_amd/csrc/lmc_api.hip for gfx950 with hipcc, in-tree."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if force or not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < newest:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "lmc_api.hip"), "-o", SO_PATH]
+        subprocess.check_call(cmd)
+    return SO_PATH
+
+
+class KvLayoutStruct(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int32), ("num_layers", ctypes.c_int32), ("num_heads", ctypes.c_int32),
+                ("head_size", ctypes.c_int32), ("base", ctypes.c_void_p), ("plane_ptrs", ctypes.c_void_p),
+                ("stride_layer", ctypes.c_int64), ("stride_kv", ctypes.c_int64), ("stride_token", ctypes.c_int64),
+                ("stride_head", ctypes.c_int64), ("slot_mapping", ctypes.c_void_p), ("block_size", ctypes.c_int32),
+                ("_pad", ctypes.c_int32), ("stride_block", ctypes.c_int64)]
+
+
+class BlobHeader(ctypes.Structure):
+    _fields_ = [("magic", ctypes.c_uint32), ("version", ctypes.c_uint16), ("header_bytes", ctypes.c_uint16),
+                ("dtype", ctypes.c_uint32), ("num_layers", ctypes.c_uint32), ("ntokens", ctypes.c_uint32),
+                ("num_heads", ctypes.c_uint32), ("head_size", ctypes.c_uint32), ("nchannels", ctypes.c_uint32),
+                ("nplanes", ctypes.c_uint32), ("ngroups", ctypes.c_uint32), ("lp", ctypes.c_uint32),
+                ("off_bins", ctypes.c_uint32), ("off_scales", ctypes.c_uint32), ("off_cdf", ctypes.c_uint32),
+                ("off_gend", ctypes.c_uint32), ("off_streams", ctypes.c_uint32), ("stream_bytes", ctypes.c_uint32),
+                ("total_bytes", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 14)]
+
+
+# name -> (restype, argtypes); every symbol include/lmc_hip.h declares
+_vp, _i32, _u64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64, ctypes.c_size_t
+_PL = ctypes.POINTER(KvLayoutStruct)
+SYMBOLS = {
+    "lmc_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "lmc_last_hip_error": (ctypes.c_int, []),
+    "lmc_abi_version": (ctypes.c_int, []),
+    "lmc_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "lmc_ctx_destroy": (ctypes.c_int, [_vp]),
+    "lmc_ctx_reserve": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "lmc_device_status": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lmc_ctx_profile": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lmc_ctx_profile_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
+    "lmc_quantize": (ctypes.c_int, [_vp, _PL, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "lmc_calculate_cdf": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "lmc_encode_chunks": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp]),
+    "lmc_decode_chunks": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _vp]),
+    "lmc_decode_symbols": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "lmc_copy_kv": (ctypes.c_int, [_vp, _PL, _i32, _i32, _PL, _i32, _vp]),
+    "lmc_pinned_alloc": (ctypes.c_int, [_sz, ctypes.POINTER(_vp)]),
+    "lmc_pinned_free": (ctypes.c_int, [_vp]),
+    "lmc_memcpy_async": (ctypes.c_int, [_vp, _vp, _sz, ctypes.c_int, _vp]),
+    "lmc_stream_create": (ctypes.c_int, [ctypes.POINTER(_vp)]),
+    "lmc_stream_destroy": (ctypes.c_int, [_vp]),
+    "lmc_stream_synchronize": (ctypes.c_int, [_vp]),
+    "lmc_stream_wait_event": (ctypes.c_int, [_vp, _vp]),
+    "lmc_event_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int]),
+    "lmc_event_destroy": (ctypes.c_int, [_vp]),
+    "lmc_event_record": (ctypes.c_int, [_vp, _vp]),
+    "lmc_event_synchronize": (ctypes.c_int, [_vp]),
+    "lmc_event_query": (ctypes.c_int, [_vp]),
+    "lmc_event_elapsed_ms": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    "lmc_blob_info": (ctypes.c_int, [_vp, _sz, ctypes.POINTER(BlobHeader)]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load liblmc_hip.so (built in-tree by build()).  Raises if absent: there is no fallback path."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(SO_PATH):
+                raise NativeError(
+                    f"{SO_PATH} is missing: the MI355X HIP extension has not been built "
+                    f"(run `python -c 'import __graft_entry__ as g; g.build()'`). lmcache_amd has no CPU fallback.")
+            L = ctypes.CDLL(SO_PATH)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(L, name)  # AttributeError if the ABI and this binding drift apart
+                fn.restype, fn.argtypes = res, args
+            if L.lmc_abi_version() != 1:
+                raise NativeError("liblmc_hip.so ABI version mismatch; rebuild")
+            _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        L = lib()
+        msg = L.lmc_strerror(rc).decode()
+        raise NativeError(f"{what or 'lmc call'} failed: {msg} (rc={rc}, hip={L.lmc_last_hip_error()})")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.float16:
+        return FP16
+    raise ValueError(f"KV dtype must be bfloat16 or float16, got {dt}")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return torch.bfloat16 if code == BF16 else torch.float16
+
+
+def r16(x: int) -> int:
+    return (x + 15) & ~15
+
+
+def group_cap_bytes(T: int) -> int:
+    return r16(LANES * (T + 8))
+
+
+def blob_static_bytes(L: int, T: int, H: int, D: int) -> int:
+    C, P = H * D, 2 * L
+    G = (C + LANES - 1) // LANES
+    off = HEADER_BYTES + r16(P)
+    off += r16(2 * P * T)
+    off += r16(2 * P * C * LP)
+    off += r16(4 * P * G)
+    return off
+
+
+def blob_bound(L: int, T: int, H: int, D: int) -> int:
+    """Worst-case blob size (lmc_blob_bound in include/lmc_format.h)."""
+    C, P = H * D, 2 * L
+    G = (C + LANES - 1) // LANES
+    return blob_static_bytes(L, T, H, D) + P * G * group_cap_bytes(T)
+
+
+def current_stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class KVLayout:
+    """Python owner of a lmc_kv_layout; keeps the tensors it points into alive."""
+
+    def __init__(self, struct: KvLayoutStruct, keep: Sequence, ntokens: int, device: torch.device):
+        self.struct = struct
+        self._keep = list(keep)
+        self.ntokens = ntokens
+        self.device = device
+
+    @property
+    def L(self):
+        return self.struct.num_layers
+
+    @property
+    def H(self):
+        return self.struct.num_heads
+
+    @property
+    def D(self):
+        return self.struct.head_size
+
+    @property
+    def dtype(self):
+        return self.struct.dtype
+
+    @staticmethod
+    def from_chunk(t: torch.Tensor, fmt: str) -> "KVLayout":
+        """A chunk blob: [L,2,T,H,D] for "vllm", [L,2,H,T,D] for "huggingface"
+        (cache_engine.py:137-140).  Any strides are fine (permuted views included) as long as
+        the head dimension is contiguous and strides are multiples of 8 elements."""
+        assert t.is_cuda and t.dim() == 5 and t.shape[1] == 2, f"bad chunk shape {tuple(t.shape)}"
+        s = KvLayoutStruct()
+        st = t.stride()
+        if fmt == "vllm":
+            L, _, T, H, D = t.shape
+            s.stride_token, s.stride_head = st[2], st[3]
+        elif fmt == "huggingface":
+            L, _, H, T, D = t.shape
+            s.stride_token, s.stride_head = st[3], st[2]
+        else:
+            raise ValueError(f"Invalid format: {fmt}")
+        if st[4] != 1:
+            raise ValueError("head dimension must be contiguous")
+        s.dtype = dtype_code(t.dtype)
+        s.num_layers, s.num_heads, s.head_size = L, H, D
+        s.base = t.data_ptr()
+        s.plane_ptrs = None
+        s.stride_layer, s.stride_kv = st[0], st[1]
+        s.slot_mapping = None
+        s.block_size, s.stride_block = 0, 0
+        return KVLayout(s, [t], T, t.device)
+
+    @staticmethod
+    def from_kv_tuple(kv, fmt: str) -> "KVLayout":
+        """The KVCache nested tuple handed to LMCacheEngine.store (cache_engine.py:230-236):
+        per layer (K, V), each [T,H,D] ("vllm") or [H,T,D] ("huggingface").  No stacking copy:
+        the kernels read every plane through a pointer table."""
+        k0 = kv[0][0]
+        assert k0.is_cuda and k0.dim() == 3
+        st = k0.stride()
+        if st[2] != 1:
+            raise ValueError("head dimension must be contiguous")
+        ptrs = []
+        keep = []
+        for k, v in kv:
+            for x in (k, v):
+                if x.shape != k0.shape or x.stride() != st or x.dtype != k0.dtype or x.device != k0.device:
+                    raise ValueError("all K/V tensors must share shape, strides, dtype and device")
+                ptrs.append(x.data_ptr())
+                keep.append(x)
+        table = torch.tensor(ptrs, dtype=torch.int64).to(k0.device, non_blocking=False)
+        s = KvLayoutStruct()
+        if fmt == "vllm":
+            T, H, D = k0.shape
+            s.stride_token, s.stride_head = st[0], st[1]
+        elif fmt == "huggingface":
+            H, T, D = k0.shape
+            s.stride_token, s.stride_head = st[1], st[0]
+        else:
+            raise ValueError(f"Invalid format: {fmt}")
+        s.dtype = dtype_code(k0.dtype)
+        s.num_layers, s.num_heads, s.head_size = len(kv), H, D
+        s.base = None
+        s.plane_ptrs = table.data_ptr()
+        s.stride_layer = s.stride_kv = 0
+        s.slot_mapping = None
+        s.block_size, s.stride_block = 0, 0
+        return KVLayout(s, keep + [table], T, k0.device)
+
+    @staticmethod
+    def paged(kv_caches, slot_mapping: torch.Tensor, block_size: int, layout: str = "NBHD") -> "KVLayout":
+        """vLLM paged KV: per layer a tensor [2, num_blocks, ...] addressed through slot_mapping
+        (LLM_Engine.rst:91-122).  layout "NBHD" = [num_blocks, block_size, H, D] (flash layout),
+        "NHBD" = [num_blocks, H, block_size, D] (BASELINE.json north star)."""
+        c0 = kv_caches[0]
+        assert c0.is_cuda and c0.dim() == 5 and c0.shape[0] == 2
+        st = c0.stride()
+        ptrs, keep = [], []
+        for c in kv_caches:
+            if c.shape != c0.shape or c.stride() != st or c.dtype != c0.dtype:
+                raise ValueError("all layer caches must share shape, strides and dtype")
+            ptrs += [c[0].data_ptr(), c[1].data_ptr()]
+            keep.append(c)
+        table = torch.tensor(ptrs, dtype=torch.int64).to(c0.device)
+        sm = slot_mapping.to(device=c0.device, dtype=torch.int64).contiguous()
+        s = KvLayoutStruct()
+        if layout == "NBHD":
+            _, _, bs, H, D = c0.shape
+            s.stride_token, s.stride_head = st[2], st[3]
+        elif layout == "NHBD":
+            _, _, H, bs, D = c0.shape
+            s.stride_token, s.stride_head = st[3], st[2]
+        else:
+            raise ValueError(layout)
+        assert bs == block_size and st[4] == 1
+        s.dtype = dtype_code(c0.dtype)
+        s.num_layers, s.num_heads, s.head_size = len(kv_caches), H, D
+        s.base = None
+        s.plane_ptrs = table.data_ptr()
+        s.stride_layer = s.stride_kv = 0
+        s.slot_mapping = sm.data_ptr()
+        s.block_size, s.stride_block = block_size, st[1]
+        return KVLayout(s, keep + [table, sm], sm.numel(), c0.device)
+
+
+class PinnedBuffer:
+    """hipHostMalloc'ed host memory (lmc_pinned_alloc) exposed as a uint8 torch tensor view."""
+
+    def __init__(self, nbytes: int):
+        p = ctypes.c_void_p()
+        check(lib().lmc_pinned_alloc(nbytes, ctypes.byref(p)), "lmc_pinned_alloc")
+        self.ptr = p.value
+        self.nbytes = nbytes
+        self._arr = (ctypes.c_uint8 * nbytes).from_address(self.ptr)
+        self.tensor = torch.frombuffer(self._arr, dtype=torch.uint8)
+
+    def free(self):
+        if self.ptr:
+            self.tensor = None
+            self._arr = None
+            lib().lmc_pinned_free(ctypes.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """Owner of one lmc_ctx (per device).  Thread-safe: the C side serialises workspace use."""
+
+    def __init__(self, device: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise NativeError("lmcache_amd needs an MI355X (torch.cuda.is_available() is False); no CPU fallback")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        h = ctypes.c_void_p()
+        check(lib().lmc_ctx_create(self.device, ctypes.byref(h)), "lmc_ctx_create")
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib().lmc_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def status(self, clear: bool = False) -> int:
+        return lib().lmc_device_status(self.handle, 1 if clear else 0)
+
+    def raise_on_status(self, what: str):
+        st = self.status(clear=True)
+        if st:
+            raise NativeError(f"{what}: device status 0x{st:x} (1=stream overflow, 2=bad header, 4=bad stream)")
+
+    def profile(self, enable: bool) -> None:
+        check(lib().lmc_ctx_profile(self.handle, 1 if enable else 0), "lmc_ctx_profile")
+
+    def profile_read(self):
+        """Per-kernel ms of the last profiled call (caller must have synchronised the stream)."""
+        buf = (ctypes.c_float * 8)()
+        n = lib().lmc_ctx_profile_read(self.handle, buf, 8)
+        if n < 0:
+            check(n, "lmc_ctx_profile_read")
+        return [float(buf[i]) for i in range(n)]
+
+    def reserve(self, L, H, D, chunk_tokens, max_chunks):
+        check(lib().lmc_ctx_reserve(self.handle, L, H, D, chunk_tokens, max_chunks), "lmc_ctx_reserve")
+
+    @staticmethod
+    def _bins(bins: Sequence[int]):
+        arr = (ctypes.c_int32 * len(bins))(*[int(b) for b in bins])
+        return arr
+
+    def quantize(self, src: KVLayout, tok_begin: int, ntok: int, bins, stream: Optional[int] = None
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+        P, C = 2 * src.L, src.H * src.D
+        sym = torch.empty((P, ntok, C), dtype=torch.int8, device=src.device)
+        scale = torch.empty((P, ntok), dtype=torch.int16, device=src.device)
+        b = self._bins(bins)
+        st = current_stream_ptr(src.device) if stream is None else stream
+        check(lib().lmc_quantize(self.handle, ctypes.byref(src.struct), tok_begin, ntok, b, sym.data_ptr(),
+                                 scale.data_ptr(), st), "lmc_quantize")
+        return sym, scale
+
+    def calculate_cdf(self, sym: torch.Tensor, max_bins: int = MAX_BINS, stream: Optional[int] = None) -> torch.Tensor:
+        assert sym.is_cuda and sym.dtype == torch.int8 and sym.is_contiguous() and sym.dim() == 3
+        P, T, C = sym.shape
+        out = torch.empty((P, C, max_bins + 1), dtype=torch.int16, device=sym.device)
+        st = current_stream_ptr(sym.device) if stream is None else stream
+        check(lib().lmc_calculate_cdf(self.handle, sym.data_ptr(), P, T, C, max_bins, out.data_ptr(), st),
+              "lmc_calculate_cdf")
+        return out
+
+    def encode_chunks(self, src: KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int, bins,
+                      blobs_ptr: int, blob_stride: int, sizes_ptr: int, stream: Optional[int] = None) -> int:
+        b = self._bins(bins)
+        st = current_stream_ptr(src.device) if stream is None else stream
+        check(lib().lmc_encode_chunks(self.handle, ctypes.byref(src.struct), tok_begin, tok_end, chunk_tokens, b,
+                                      blobs_ptr, blob_stride, sizes_ptr, st), "lmc_encode_chunks")
+        return (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
+
+    def decode_chunks(self, blobs_ptr: int, blob_stride: int, nchunks: int, dst: KVLayout, dst_tok0: int,
+                      chunk_tokens: int, stream: Optional[int] = None) -> None:
+        st = current_stream_ptr(dst.device) if stream is None else stream
+        check(lib().lmc_decode_chunks(self.handle, blobs_ptr, blob_stride, nchunks, ctypes.byref(dst.struct),
+                                      dst_tok0, chunk_tokens, st), "lmc_decode_chunks")
+
+    def decode_symbols(self, blob: torch.Tensor, L: int, H: int, D: int, T: int, stream: Optional[int] = None
+                       ) -> torch.Tensor:
+        sym = torch.empty((2 * L, T, H * D), dtype=torch.int8, device=blob.device)
+        st = current_stream_ptr(blob.device) if stream is None else stream
+        check(lib().lmc_decode_symbols(self.handle, blob.data_ptr(), L, H, D, sym.data_ptr(), st),
+              "lmc_decode_symbols")
+        return sym
+
+    def copy_kv(self, src: KVLayout, tok_begin: int, ntok: int, dst: KVLayout, dst_tok0: int,
+                stream: Optional[int] = None) -> None:
+        st = current_stream_ptr(src.device) if stream is None else stream
+        check(lib().lmc_copy_kv(self.handle, ctypes.byref(src.struct), tok_begin, ntok, ctypes.byref(dst.struct),
+                                dst_tok0, st), "lmc_copy_kv")
+
+
+def memcpy_async(dst_ptr: int, src_ptr: int, nbytes: int, kind: str, stream: int) -> None:
+    k = {"d2h": 0, "h2d": 1, "d2d": 2}[kind]
+    check(lib().lmc_memcpy_async(dst_ptr, src_ptr, nbytes, k, stream), "lmc_memcpy_async")
+
+
+def blob_info(blob: bytes) -> BlobHeader:
+    """Parse + validate a blob header on the host (lmc_blob_info)."""
+    h = BlobHeader()
+    if len(blob) < HEADER_BYTES:
+        raise NativeError("blob shorter than its header")
+    buf = (ctypes.c_uint8 * HEADER_BYTES).from_buffer_copy(bytes(blob[:HEADER_BYTES]))
+    rc = lib().lmc_blob_info(buf, len(blob), ctypes.byref(h))
+    check(rc, "lmc_blob_info")
+    return h
+
+
+_ctx_lock = threading.Lock()
+_ctxs = {}
+
+
+def get_context(device: Optional[int] = None) -> Context:
+    """Per-device singleton context."""
+    dev = torch.cuda.current_device() if device is None else int(device)
+    with _ctx_lock:
+        if dev not in _ctxs:
+            _ctxs[dev] = Context(dev)
+        return _ctxs[dev]

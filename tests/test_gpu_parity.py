@@ -1,0 +1,288 @@
+"""HIP hot path vs the CPU oracle and the reference-generated golden vectors.
+Every call goes through the C ABI (lmcache_amd.native -> liblmc_hip.so).
+Bit-exact: symbols, scales, CDF, blob bytes, decoded 16-bit tensors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from lmcache_amd import native
+    native.lib()
+    return native
+
+
+@pytest.fixture(scope="module")
+def ctx(nat):
+    return nat.get_context(0)
+
+
+def bits_np(t: torch.Tensor) -> np.ndarray:
+    return t.contiguous().cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def make_kv(L, T, H, D, dtype, kind="randn", seed=0):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "rand":
+        x = torch.rand(L, 2, T, H, D, generator=g)
+    elif kind == "randn":
+        x = torch.randn(L, 2, T, H, D, generator=g)
+    else:
+        x = torch.randn(L, 2, T, H, D, generator=g) * torch.exp(1.5 * torch.randn(H * D, generator=g)).reshape(H, D)
+    return x.to(dtype)
+
+
+def default_bins(L):
+    kb = [32 if l < max(1, L // 3) else 16 for l in range(L)]
+    vb = [32 if l < 1 else 16 for l in range(L)]
+    return kb + vb
+
+
+def encode(nat, ctx, layout, tok_begin, tok_end, chunk_tokens, bins):
+    L, H, D = layout.L, layout.H, layout.D
+    stride = nat.r16(nat.blob_bound(L, chunk_tokens, H, D))
+    n = (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
+    blobs = torch.zeros(n * stride, dtype=torch.uint8, device=DEV)
+    sizes = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ctx.encode_chunks(layout, tok_begin, tok_end, chunk_tokens, bins, blobs.data_ptr(), stride, sizes.data_ptr())
+    torch.cuda.synchronize()
+    ctx.raise_on_status("encode")
+    sz = sizes.cpu().tolist()
+    host = blobs.cpu().numpy()
+    return [host[i * stride:i * stride + sz[i]].tobytes() for i in range(n)], blobs, stride
+
+
+# --------------------------------------------------------------------------
+def test_quantize_golden(nat, ctx, oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "quant.npz"))
+    bins = z["bins"].tolist()
+    for dname, tdt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        for kind in ("rand", "randn", "outlier"):
+            tag = f"{dname}_{kind}"
+            kvb = z[f"{tag}_kv"]  # [L,2,T,C] bits; C = 256 -> H=2, D=128
+            L, _, T, C = kvb.shape
+            kv = torch.from_numpy(kvb.view(np.int16)).view(tdt).reshape(L, 2, T, 2, C // 2).to(DEV)
+            sym, scale = ctx.quantize(nat.KVLayout.from_chunk(kv, "vllm"), 0, T, bins)
+            torch.cuda.synchronize()
+            assert np.array_equal(sym.cpu().numpy(), z[f"{tag}_sym"]), tag
+            assert np.array_equal(scale.cpu().numpy().view(np.uint16), z[f"{tag}_scale"]), tag
+
+
+def test_quantize_edge_rows_golden(nat, ctx, golden_dir):
+    z = np.load(os.path.join(golden_dir, "quant_edge.npz"))
+    x = torch.from_numpy(z["x"].view(np.int16)).view(torch.bfloat16)  # [2, T, 64]
+    Lk, T, C = x.shape
+    kv = torch.stack([x, x], dim=1).reshape(Lk, 2, T, 1, C).to(DEV)
+    bins = z["bins"].tolist() * 2
+    sym, scale = ctx.quantize(nat.KVLayout.from_chunk(kv, "vllm"), 0, T, bins)
+    torch.cuda.synchronize()
+    assert np.array_equal(sym.cpu().numpy()[:Lk], z["sym"])
+    gs, s = z["scale"], scale.cpu().numpy().view(np.uint16)[:Lk]
+    nan = (gs & 0x7fff) > 0x7f80
+    assert np.array_equal(s[~nan], gs[~nan]) and (((s & 0x7fff) > 0x7f80) == nan).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 1, 128), (2, 24, 2, 128), (1, 9, 4, 128), (2, 13, 8, 128), (1, 6, 5, 128),
+                                   (1, 5, 16, 128), (1, 5, 32, 128), (2, 7, 3, 40)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_quantize_vs_oracle_shapes(nat, ctx, oracle, shape, dtype):
+    L, T, H, D = shape
+    kv = make_kv(L, T, H, D, dtype, "outlier", seed=T)
+    bins = default_bins(L)
+    sym, scale = ctx.quantize(nat.KVLayout.from_chunk(kv.to(DEV), "vllm"), 0, T, bins)
+    torch.cuda.synchronize()
+    b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
+    rs, rsc = oracle.quantize(b, code, np.array(bins, np.int32))
+    assert np.array_equal(sym.cpu().numpy(), rs)
+    assert np.array_equal(scale.cpu().numpy().view(np.uint16), rsc)
+
+
+@pytest.mark.parametrize("T", [1, 7, 16, 128, 236, 250, 256, 768])
+def test_cdf_golden(nat, ctx, golden_dir, T):
+    z = np.load(os.path.join(golden_dir, "cdf.npz"))
+    sym = torch.from_numpy(z[f"T{T}_sym"]).to(DEV)
+    cdf = ctx.calculate_cdf(sym)
+    torch.cuda.synchronize()
+    assert np.array_equal(cdf.cpu().numpy().view(np.uint16), z[f"T{T}_cdf"])
+
+
+# --------------------------------------------------------------------------
+CHUNK_SHAPES = [
+    # L, T, H, D, dtype, kind
+    (4, 64, 8, 128, torch.bfloat16, "randn"),
+    (2, 236, 8, 128, torch.bfloat16, "rand"),   # tests/test_serde.py:87-107 ragged chunk
+    (2, 1, 8, 128, torch.bfloat16, "randn"),
+    (2, 3, 1, 128, torch.bfloat16, "outlier"),  # C=128: one KV head per rank (70B TP=8)
+    (2, 50, 2, 128, torch.float16, "randn"),
+    (1, 33, 5, 128, torch.bfloat16, "outlier"),  # C=640: partial last group
+    (1, 40, 32, 128, torch.float16, "rand"),     # C=4096: BASELINE config 1 head count
+    (3, 16, 3, 40, torch.float16, "randn"),      # C=120 (not a multiple of 64)
+    (1, 300, 2, 64, torch.bfloat16, "randn"),    # T > 256: no 256-token sub-chunking needed
+]
+
+
+@pytest.mark.parametrize("shape", CHUNK_SHAPES, ids=lambda s: f"L{s[0]}T{s[1]}H{s[2]}D{s[3]}{'bf' if s[4] == torch.bfloat16 else 'fp'}")
+def test_blob_and_decode_bit_exact(nat, ctx, oracle, shape):
+    L, T, H, D, dtype, kind = shape
+    kv = make_kv(L, T, H, D, dtype, kind, seed=L * 1000 + T)
+    bins = default_bins(L)
+    blobs, blob_dev, stride = encode(nat, ctx, nat.KVLayout.from_chunk(kv.to(DEV), "vllm"), 0, T, T, bins)
+    b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
+    ref = oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+    assert len(blobs[0]) == len(ref)
+    assert blobs[0] == ref
+    hdr = nat.blob_info(blobs[0])
+    assert (hdr.num_heads, hdr.head_size, hdr.ntokens, hdr.total_bytes) == (H, D, T, len(ref))
+    # entropy decode only
+    sym = ctx.decode_symbols(blob_dev, L, H, D, T)
+    torch.cuda.synchronize()
+    assert np.array_equal(sym.cpu().numpy(), oracle.decode_blob_symbols(ref))
+    # fused decode, both output dtypes (vllm -> bf16, huggingface -> fp16: cachegen_decoder.py:190-200)
+    for odt, ocode in ((torch.bfloat16, oracle.BF16), (torch.float16, oracle.FP16)):
+        out = torch.zeros(L, 2, T, H, D, dtype=odt, device=DEV)
+        ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+        torch.cuda.synchronize()
+        ctx.raise_on_status("decode")
+        want = oracle.decode_blob(ref, ocode)
+        assert np.array_equal(bits_np(out).reshape(L, 2, T, H * D), want)
+
+
+def test_multi_chunk_tail_and_kv_tuple(nat, ctx, oracle):
+    """engine.store shape: per-layer (K,V) tensors, chunked with a short tail."""
+    L, Ttot, H, D, cs = 3, 150, 4, 128, 64
+    g = torch.Generator().manual_seed(4)
+    kvt = tuple((torch.randn(Ttot, H, D, generator=g).to(torch.bfloat16).to(DEV),
+                 torch.randn(Ttot, H, D, generator=g).to(torch.bfloat16).to(DEV)) for _ in range(L))
+    bins = default_bins(L)
+    blobs, blob_dev, stride = encode(nat, ctx, nat.KVLayout.from_kv_tuple(kvt, "vllm"), 0, Ttot, cs, bins)
+    assert len(blobs) == 3
+    full = torch.stack([torch.stack(p, 0) for p in kvt], 0).cpu()  # [L,2,T,H,D]
+    for i, blob in enumerate(blobs):
+        t0, t1 = i * cs, min(Ttot, (i + 1) * cs)
+        b, code = oracle.torch_to_bits(full[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
+        assert blob == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)), f"chunk {i}"
+    # decode all chunks straight into per-layer destination tensors (no torch.cat)
+    outt = tuple((torch.zeros(Ttot, H, D, dtype=torch.bfloat16, device=DEV),
+                  torch.zeros(Ttot, H, D, dtype=torch.bfloat16, device=DEV)) for _ in range(L))
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, 3, nat.KVLayout.from_kv_tuple(outt, "vllm"), 0, cs)
+    torch.cuda.synchronize()
+    ctx.raise_on_status("decode")
+    for i, blob in enumerate(blobs):
+        t0, t1 = i * cs, min(Ttot, (i + 1) * cs)
+        want = oracle.decode_blob(blob, oracle.BF16)  # [L,2,Tc,C]
+        for l in range(L):
+            for kvi in range(2):
+                got = bits_np(outt[l][kvi][t0:t1]).reshape(t1 - t0, H * D)
+                assert np.array_equal(got, want[l, kvi])
+
+
+def test_huggingface_layout_and_skip(nat, ctx, oracle):
+    """[L,2,H,T,D] fp16 chunk (cache_engine.py:139-140) + retrieve()'s drop-first-tokens rule (:360-365)."""
+    L, T, H, D = 2, 40, 4, 64
+    kv = make_kv(L, T, H, D, torch.float16, "randn", seed=9)  # vllm order
+    hf = kv.permute(0, 1, 3, 2, 4).contiguous().to(DEV)       # [L,2,H,T,D]
+    bins = default_bins(L)
+    blobs, blob_dev, stride = encode(nat, ctx, nat.KVLayout.from_chunk(hf, "huggingface"), 0, T, T, bins)
+    b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
+    ref = oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+    assert blobs[0] == ref
+    # a permuted (non-contiguous) vllm view of the same memory encodes identically, with no copy
+    view = hf.permute(0, 1, 3, 2, 4)
+    blobs2, _, _ = encode(nat, ctx, nat.KVLayout.from_chunk(view, "vllm"), 0, T, T, bins)
+    assert blobs2[0] == ref
+    skip = 7
+    out = torch.zeros(L, 2, H, T - skip, D, dtype=torch.float16, device=DEV)
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "huggingface"), -skip, T)
+    torch.cuda.synchronize()
+    want = oracle.decode_blob(ref, oracle.FP16).reshape(L, 2, T, H, D)[:, :, skip:]
+    got = bits_np(out).reshape(L, 2, H, T - skip, D).transpose(0, 1, 3, 2, 4)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("layout", ["NBHD", "NHBD"])
+def test_paged_gather_encode_and_scatter_decode(nat, ctx, oracle, layout):
+    """vLLM paged blocks through slot_mapping (LLM_Engine.rst:91-122), incl. BASELINE's
+    [num_blocks, num_heads, block_size, head_dim] layout; non-contiguous random slots (config 5)."""
+    L, T, H, D, bs, nb = 2, 48, 4, 128, 16, 9
+    g = torch.Generator().manual_seed(21)
+    shape = (2, nb, bs, H, D) if layout == "NBHD" else (2, nb, H, bs, D)
+    caches = [torch.randn(shape, generator=g).to(torch.bfloat16).to(DEV) for _ in range(L)]
+    slots = torch.randperm(nb * bs, generator=g)[:T]
+    lay = nat.KVLayout.paged(caches, slots, bs, layout)
+    bins = default_bins(L)
+    blobs, blob_dev, stride = encode(nat, ctx, lay, 0, T, T, bins)
+    # dense gather on the host as the oracle's input
+    dense = torch.zeros(L, 2, T, H, D, dtype=torch.bfloat16)
+    for l in range(L):
+        c = caches[l].cpu()
+        for t, s in enumerate(slots.tolist()):
+            blk, w = divmod(s, bs)
+            dense[l, :, t] = c[:, blk, w] if layout == "NBHD" else c[:, blk, :, w]
+    b, code = oracle.torch_to_bits(dense.reshape(L, 2, T, H * D))
+    ref = oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+    assert blobs[0] == ref
+    # lossless gather into a contiguous chunk == dense
+    chunk = torch.zeros(L, 2, T, H, D, dtype=torch.bfloat16, device=DEV)
+    ctx.copy_kv(lay, 0, T, nat.KVLayout.from_chunk(chunk, "vllm"), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(chunk.cpu(), dense)
+    # scatter-decode into fresh paged caches at other random slots
+    caches2 = [torch.zeros(shape, dtype=torch.bfloat16, device=DEV) for _ in range(L)]
+    slots2 = torch.randperm(nb * bs, generator=g)[:T]
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.paged(caches2, slots2, bs, layout), 0, T)
+    torch.cuda.synchronize()
+    ctx.raise_on_status("decode")
+    want = oracle.decode_blob(ref, oracle.BF16).reshape(L, 2, T, H, D)
+    touched = torch.zeros(nb * bs, dtype=torch.bool)
+    touched[slots2] = True
+    for l in range(L):
+        c = caches2[l].cpu()
+        for t, s in enumerate(slots2.tolist()):
+            blk, w = divmod(s, bs)
+            got = c[:, blk, w] if layout == "NBHD" else c[:, blk, :, w]
+            assert np.array_equal(bits_np(got), want[l, :, t])
+        flat = c.reshape(2, nb * bs, H, D) if layout == "NBHD" else c.permute(0, 1, 3, 2, 4).reshape(2, nb * bs, H, D)
+        assert (flat[:, ~touched] == 0).all()  # nothing written outside slot_mapping
+
+
+def test_corrupt_blob_is_flagged(nat, ctx):
+    L, T, H, D = 1, 32, 1, 128
+    kv = make_kv(L, T, H, D, torch.bfloat16, "randn", 1).to(DEV)
+    blobs, blob_dev, stride = encode(nat, ctx, nat.KVLayout.from_chunk(kv, "vllm"), 0, T, T, [32, 16])
+    out = torch.zeros_like(kv)
+    bad = blob_dev.clone()
+    bad[0] ^= 0xff  # magic
+    ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+    torch.cuda.synchronize()
+    assert ctx.status(clear=True) & 2
+    hdr = nat.blob_info(blobs[0])
+    bad = blob_dev.clone()
+    bad[hdr.off_streams + 40] ^= 0x5a  # a stream word
+    ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+    torch.cuda.synchronize()
+    assert ctx.status(clear=True) & 4
+
+
+def test_full_size_llama8b_chunk_vs_oracle(nat, ctx, oracle):
+    """BASELINE config 2, one full chunk: L=32, 8 KV heads x 128, T=256 bf16 (32 MiB)."""
+    L, T, H, D = 32, 256, 8, 128
+    bins, nl = oracle.cachegen_bins("meta-llama/Llama-3.1-8B-Instruct")
+    assert nl == L
+    kv = make_kv(L, T, H, D, torch.bfloat16, "rand", seed=0)  # the reference's test distribution
+    blobs, blob_dev, stride = encode(nat, ctx, nat.KVLayout.from_chunk(kv.to(DEV), "vllm"), 0, T, T, bins.tolist())
+    b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
+    ref = oracle.encode_blob(b, code, H, D, bins)
+    assert blobs[0] == ref
+    ratio = kv.numel() * 2 / len(ref)
+    assert 2.5 < ratio < 3.3, ratio  # ~3.0x on uniform data
+    out = torch.zeros(L, 2, T, H, D, dtype=torch.bfloat16, device=DEV)
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits_np(out).reshape(L, 2, T, H * D), oracle.decode_blob(ref, oracle.BF16))
