@@ -1,0 +1,254 @@
+"""LMCacheEngine -- the drop-in boundary.
+
+Same public surface as the reference's lmcache/cache_engine.py:
+  LMCacheEngine(config, metadata)                                        :18-35
+  .store(tokens, kv_tensors_raw, skip_existing=True, blocking=True)      :230-287
+  .retrieve(tokens, mask=None) -> (KVCache | (), ret_mask)               :293-381
+  .close()                                                               :383
+  LMCacheEngineBuilder.get_or_create / get / destroy                     :387-436
+
+What stays Python, bit-exact with the reference: token chunking (:68-84), the
+SHA-256 prefix-hash chain (:58-66, :86-96), key construction (:37-44), the
+skip-existing scan (:183-208), the prefix-only / suffix-mask retrieve rules
+(:323-357, :379).
+
+What moved into HIP: the three full-size copies of store()
+(_tuple_kv_to_blob :98-118, _slice_kv_at :131-161) and the concat of
+retrieve() (:362-368) are gone -- chunks are gathered from / scattered to the
+caller's per-layer tensors by the kernels (put_kv_range / get_kv_range), or by
+one lmc_copy_kv pass per chunk for backends that only speak chunk tensors.
+"""
+import hashlib
+import time
+from typing import Dict, Iterable, List, Optional, Tuple, Union
+
+import torch
+
+from lmcache_amd import native
+from lmcache_amd.config import LMCacheEngineConfig, LMCacheEngineMetadata
+from lmcache_amd.logging import init_logger
+from lmcache_amd.storage_backend import CreateStorageBackend
+from lmcache_amd.utils import CacheEngineKey, KVCache, _lmcache_nvtx_annotate
+
+logger = init_logger(__name__)
+
+
+def _token_dim(fmt: str) -> int:
+    if fmt == "vllm":
+        return 0
+    if fmt == "huggingface":
+        return 1
+    raise ValueError(f"Invalid format: {fmt}")
+
+
+class LMCacheEngine:
+    def __init__(self, config: LMCacheEngineConfig, metadata: LMCacheEngineMetadata):
+        self.config = config
+        self.metadata = metadata
+        self.chunk_size = config.chunk_size
+        self.save_decode_cache = config.save_decode_cache
+        self.engine_ = CreateStorageBackend(config, metadata)
+        logger.debug("Current storage backend type %s", type(self.engine_))
+
+    # ------------------------------------------------------------------ index (pure Python)
+    def _make_key(self, chunk_hash: str, fmt: str) -> CacheEngineKey:
+        m = self.metadata
+        return CacheEngineKey(fmt, m.model_name, m.world_size, m.worker_id, chunk_hash)
+
+    def _num_tokens_in_kv(self, kv_tensors: Union[KVCache, torch.Tensor], fmt: str) -> int:
+        return kv_tensors[0][0].shape[_token_dim(fmt)]
+
+    def _get_init_hash(self) -> str:
+        return ""
+
+    def _hash(self, tokens: torch.Tensor, prefix_hash: str) -> str:
+        # the token bytes are dtype dependent (int64 little-endian for the usual LongTensor)
+        return hashlib.sha256(prefix_hash.encode("ascii") + tokens.cpu().numpy().tobytes()).hexdigest()
+
+    def _chunk_tokens(self, tokens: torch.Tensor) -> Iterable[torch.Tensor]:
+        for start in range(0, len(tokens), self.chunk_size):
+            yield tokens[start:start + self.chunk_size]
+
+    def _prefix_hash(self, token_chunks: Iterable[torch.Tensor], num_skip_chunk: Optional[int] = 0) -> List[str]:
+        running = self._get_init_hash()
+        out = []
+        for chunk in token_chunks:
+            running = self._hash(chunk, running)
+            out.append(running)
+        return out[num_skip_chunk:]
+
+    def _first_missing_chunk(self, chunk_hashes: List[str], fmt: str) -> Optional[int]:
+        """Index of the first chunk the backend does not hold (None: all present) -- the
+        skip-existing scan of _make_chunks_skip_existing (:192-202)."""
+        for idx, h in enumerate(chunk_hashes):
+            if not self.engine_.contains(self._make_key(h, fmt)):
+                return idx
+        return None
+
+    @staticmethod
+    def plan_retrieve(num_tokens: int, chunk_size: int, mask_false_prefix: int, hit_chunks: int):
+        """Pure arithmetic of retrieve() (:323-329, :360-365, :379): given how many leading tokens the
+        mask skips and how many consecutive chunks (after the skipped whole chunks) hit, return
+        (num_skip_chunk, extra_token_len, retrieved_token_count)."""
+        num_skip_chunk = mask_false_prefix // chunk_size
+        extra = mask_false_prefix - num_skip_chunk * chunk_size
+        if hit_chunks == 0:
+            return num_skip_chunk, extra, 0
+        covered_end = min((num_skip_chunk + hit_chunks) * chunk_size, num_tokens)
+        return num_skip_chunk, extra, covered_end - mask_false_prefix
+
+    # ------------------------------------------------------------------ data movement helpers
+    def _as_cuda_kv(self, kv: KVCache) -> KVCache:
+        if all(k.is_cuda and v.is_cuda for k, v in kv):
+            return kv
+        return tuple((k.cuda(), v.cuda()) for k, v in kv)
+
+    def _blob_to_tuple_kv(self, blob: torch.Tensor) -> KVCache:
+        return tuple((layer[0], layer[1]) for layer in torch.unbind(blob, dim=0))
+
+    # ------------------------------------------------------------------ store
+    @_lmcache_nvtx_annotate
+    @torch.no_grad()
+    def store(self, tokens: torch.Tensor, kv_tensors_raw: KVCache, skip_existing=True, blocking=True) -> None:
+        """tokens [seq_len]; kv_tensors_raw: per layer (K, V), [T,H,D] ("vllm") or [H,T,D] ("huggingface")."""
+        t_start = time.perf_counter()
+        fmt = self.metadata.fmt
+        assert len(tokens.shape) == 1, f"Invalid shape of tokens: {tokens.shape}"
+        assert len(kv_tensors_raw) > 0, "Empty kv_tensors"
+        assert len(tokens) == self._num_tokens_in_kv(kv_tensors_raw, fmt), \
+            "Number of tokens in the kv cache does not match the input tokens"
+        ntok = len(tokens)
+        cs = self.chunk_size
+        chunk_hashes = self._prefix_hash(self._chunk_tokens(tokens))
+        first = 0
+        if skip_existing:
+            first = self._first_missing_chunk(chunk_hashes, fmt)
+            if first is None:
+                logger.info("Stored/updated 0 chunks (all present)")
+                return
+        keys = [self._make_key(h, fmt) for h in chunk_hashes[first:]]
+        kv = self._as_cuda_kv(kv_tensors_raw)
+        src = native.KVLayout.from_kv_tuple(kv, fmt)
+        t_plan = time.perf_counter()
+        if getattr(self.engine_, "supports_kv_layout", False):
+            n = self.engine_.put_kv_range(keys, src, fmt, first * cs, ntok, cs, blocking=blocking)
+        else:
+            n = self.engine_.batched_put(self._gather_chunks(keys, src, fmt, first * cs, ntok), blocking=blocking)
+        logger.info("Stored/updated %d chunks, total time %.4fs, planning %.4fs", n,
+                    time.perf_counter() - t_start, t_plan - t_start)
+
+    def _gather_chunks(self, keys, src: native.KVLayout, fmt: str, tok_begin: int, tok_end: int):
+        """(key, contiguous chunk tensor) pairs for chunk-tensor backends: one lmc_copy_kv pass per chunk
+        instead of stack + permute + split + contiguous (:98-118, :141-150)."""
+        ctx = native.get_context(src.device.index)
+        dt = native.torch_dtype(src.dtype)
+        for i, key in enumerate(keys):
+            t0 = tok_begin + i * self.chunk_size
+            T = min(self.chunk_size, tok_end - t0)
+            shape = (src.L, 2, T, src.H, src.D) if fmt == "vllm" else (src.L, 2, src.H, T, src.D)
+            chunk = torch.empty(shape, dtype=dt, device=src.device)
+            ctx.copy_kv(src, t0, T, native.KVLayout.from_chunk(chunk, fmt), 0)
+            yield key, chunk
+
+    # ------------------------------------------------------------------ retrieve
+    @_lmcache_nvtx_annotate
+    @torch.no_grad()
+    def retrieve(self, tokens: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Tuple[KVCache, torch.Tensor]:
+        """Prefix hits only; `mask` (suffix mask) marks the tokens whose KV is wanted.
+        Returns (per-layer (K, V) tuple or (), ret_mask)."""
+        t_start = time.perf_counter()
+        fmt = self.metadata.fmt
+        tdim = _token_dim(fmt)
+        cs = self.chunk_size
+        ret_mask = torch.ones_like(tokens, dtype=torch.bool)
+        num_skip_tok = 0
+        if mask is not None:
+            num_skip_tok = int(len(mask) - int(torch.sum(mask)))
+        num_skip_chunk = num_skip_tok // cs
+        ret_mask[:num_skip_tok] = False
+        chunk_hashes = self._prefix_hash(self._chunk_tokens(tokens), num_skip_chunk)
+        keys = [self._make_key(h, fmt) for h in chunk_hashes]
+
+        if getattr(self.engine_, "supports_kv_layout", False):
+            hits = 0
+            for k in keys:
+                if not self.engine_.contains(k):
+                    break
+                hits += 1
+            _, extra, nret = self.plan_retrieve(len(tokens), cs, num_skip_tok, hits)
+            if hits == 0 or nret <= 0:
+                ret_mask[:] = False
+                return (), ret_mask
+            shape0, dtype = self.engine_.chunk_meta(keys[0])
+            L = shape0[0]
+            H, D = (shape0[3], shape0[4]) if fmt == "vllm" else (shape0[2], shape0[4])
+            dev = torch.device("cuda", torch.cuda.current_device())
+            shape = (L, 2, nret, H, D) if fmt == "vllm" else (L, 2, H, nret, D)
+            blob = torch.empty(shape, dtype=dtype, device=dev)
+            self.engine_.get_kv_range(keys[:hits], native.KVLayout.from_chunk(blob, fmt), fmt, -extra, cs)
+        else:
+            chunks = []
+            for chunk in self.engine_.batched_get(iter(keys)):
+                if chunk is None:
+                    break
+                chunks.append(chunk)
+            hits = len(chunks)
+            _, extra, nret = self.plan_retrieve(len(tokens), cs, num_skip_tok, hits)
+            if hits == 0 or nret <= 0:
+                ret_mask[:] = False
+                return (), ret_mask
+            c0 = chunks[0]
+            L = c0.shape[0]
+            H, D = (c0.shape[3], c0.shape[4]) if fmt == "vllm" else (c0.shape[2], c0.shape[4])
+            shape = (L, 2, nret, H, D) if fmt == "vllm" else (L, 2, H, nret, D)
+            blob = torch.empty(shape, dtype=c0.dtype, device=c0.device)
+            ctx = native.get_context(c0.device.index)
+            dst = native.KVLayout.from_chunk(blob, fmt)
+            pos = -extra
+            for c in chunks:  # scatter every chunk into its slice (replaces slice + torch.cat, :360-368)
+                T = c.shape[2] if fmt == "vllm" else c.shape[3]
+                skip = max(0, -pos)
+                if skip < T:
+                    ctx.copy_kv(native.KVLayout.from_chunk(c, fmt), skip, T - skip, dst, pos + skip)
+                pos += T
+        ret = self._blob_to_tuple_kv(blob)
+        retrieved = ret[0][0].shape[tdim]
+        ret_mask[num_skip_tok + retrieved:] = False
+        logger.info("Retrieved %d chunks (%d tokens in total) -- elapsed time %.4f", hits, retrieved,
+                    time.perf_counter() - t_start)
+        return ret, ret_mask
+
+    def close(self):
+        self.engine_.close()
+
+
+class LMCacheEngineBuilder:
+    """Per-process registry of engines by instance id (cache_engine.py:387-436)."""
+    _instances: Dict[str, LMCacheEngine] = {}
+    _cfgs: Dict[str, LMCacheEngineConfig] = {}
+    _metadatas: Dict[str, LMCacheEngineMetadata] = {}
+
+    @classmethod
+    def get_or_create(cls, instance_id: str, config: LMCacheEngineConfig,
+                      metadata: LMCacheEngineMetadata) -> LMCacheEngine:
+        if instance_id in cls._instances:
+            if cls._cfgs[instance_id] != config or cls._metadatas[instance_id] != metadata:
+                raise ValueError(f"Instance {instance_id} already exists with a different configuration or metadata.")
+            return cls._instances[instance_id]
+        engine = LMCacheEngine(config, metadata)
+        cls._instances[instance_id] = engine
+        cls._cfgs[instance_id] = config
+        cls._metadatas[instance_id] = metadata
+        return engine
+
+    @classmethod
+    def get(cls, instance_id: str) -> Optional[LMCacheEngine]:
+        return cls._instances.get(instance_id)
+
+    @classmethod
+    def destroy(cls, instance_id: str) -> None:
+        engine = cls._instances.pop(instance_id, None)
+        if engine is not None:
+            engine.close()
+        cls._cfgs.pop(instance_id, None)
+        cls._metadatas.pop(instance_id, None)

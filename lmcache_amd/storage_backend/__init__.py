@@ -1,0 +1,29 @@
+"""Backend factory (mirror of lmcache/storage_backend/__init__.py:13-44): the same
+(local_device, remote_url) -> backend decision table and the same ValueError.
+
+  remote only                -> LMCRemoteBackend (serde + connector)
+  local "cpu" / "cuda"       -> LMCLocalBackend  (HBM, pinned raw, or pinned CacheGen via local_serde)
+  local path (disk) / hybrid -> outside the hot path (file I/O, orchestration: SURVEY.md section 2 #3, #5)
+"""
+from lmcache_amd.config import LMCacheEngineConfig, LMCacheEngineMetadata
+from lmcache_amd.logging import init_logger
+from lmcache_amd.storage_backend.abstract_backend import LMCBackendInterface
+
+logger = init_logger(__name__)
+
+
+def CreateStorageBackend(config: LMCacheEngineConfig, metadata: LMCacheEngineMetadata) -> LMCBackendInterface:
+    local, remote = config.local_device, config.remote_url
+    if local is None and remote is not None:
+        from lmcache_amd.storage_backend.remote_backend import LMCRemoteBackend
+        return LMCRemoteBackend(config, metadata)
+    if local is not None and remote is None:
+        if local in ("cpu", "cuda"):
+            from lmcache_amd.storage_backend.local_backend import LMCLocalBackend
+            return LMCLocalBackend(config, metadata)
+        raise ValueError(f"local disk backend ({local!r}) is file I/O outside lmcache_amd's scope; "
+                         f"use the reference's LMCLocalDiskBackend")
+    if local is not None and remote is not None:
+        raise ValueError("hybrid (local + remote) orchestration is outside lmcache_amd's scope; "
+                         "use the reference's LMCHybridBackend over these backends")
+    raise ValueError(f"Invalid configuration: {config}")

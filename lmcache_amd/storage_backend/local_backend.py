@@ -1,0 +1,320 @@
+"""LMCLocalBackend -- the local (HBM / host-DRAM) leg of the hot path.
+
+Mirror of the reference's LMCLocalBackend (lmcache/storage_backend/
+local_backend.py:22-153): a dict keyed by CacheEngineKey, `put` (blocking or
+queued to a worker thread, :72-80, :102-125), `get` returning a tensor on the
+GPU (:128-144), `contains`, `close`.
+
+Three storage modes, chosen by the config:
+  local_device="cuda"                      chunks stay in HBM (reference :95-100 with device "cuda")
+  local_device="cpu"                       raw chunks in PINNED host DRAM: hipMemcpyAsync on a side
+                                           stream + events (the reference's pin-memory path is stubbed
+                                           off and device-synchronises, :50, :82-90)
+  local_device="cpu", local_serde="cachegen"
+                                           CacheGen-ENCODED chunks in pinned host DRAM -- the
+                                           BASELINE.json north-star path: fused HIP encode, blobs DMA'd
+                                           to host on the side stream, ~3x less PCIe and DRAM
+
+All three implement the optional put_kv_range / get_kv_range protocol
+(abstract_backend.py) so the engine never materialises the [L,2,T,H,D] blob
+(cache_engine.py:98-161) nor the final torch.cat (:362-368): KV is gathered
+from / scattered to the caller's tensors by the HIP kernels.
+"""
+import queue
+import threading
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from lmcache_amd import native
+from lmcache_amd.config import LMCacheEngineConfig, LMCacheEngineMetadata
+from lmcache_amd.logging import init_logger
+from lmcache_amd.storage_backend.abstract_backend import LMCBackendInterface
+from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
+from lmcache_amd.storage_backend.serde.cachegen_decoder import output_spec
+from lmcache_amd.storage_backend.serde.cachegen_device import HostBlob, PinnedArena, get_codec
+from lmcache_amd.utils import CacheEngineKey, _lmcache_nvtx_annotate
+
+logger = init_logger(__name__)
+
+
+class LocalBackendEndSignal:
+    pass
+
+
+@dataclass
+class _HostChunk:
+    blob: HostBlob
+    ready: Optional[torch.cuda.Event]  # D2H finished
+    shape: Tuple[int, ...]             # chunk tensor shape in the engine's fmt
+    dtype: torch.dtype
+    encoded: bool
+
+
+def _chunk_shape(fmt: str, L: int, T: int, H: int, D: int) -> Tuple[int, ...]:
+    if fmt == "vllm":
+        return (L, 2, T, H, D)
+    if fmt == "huggingface":
+        return (L, 2, H, T, D)
+    raise ValueError(f"Invalid format: {fmt}")
+
+
+def _fmt_of_chunk(t: torch.Tensor, fmt_hint: Optional[str]) -> str:
+    return fmt_hint or "vllm"
+
+
+class LMCLocalBackend(LMCBackendInterface):
+    supports_kv_layout = True
+
+    def __init__(self, config: LMCacheEngineConfig, metadata: Optional[LMCacheEngineMetadata] = None):
+        super().__init__()
+        native.lib()  # no CPU fallback: fail at construction if the HIP library is missing
+        self.chunk_size = config.chunk_size
+        self.config = config
+        self.metadata = metadata
+        self.fmt = metadata.fmt if metadata is not None else None
+        self.device = config.local_device
+        self.dst_device = "cuda"
+        if self.device == "cuda":
+            self.mode = "hbm"
+        elif self.device == "cpu":
+            self.mode = "cachegen" if config.local_serde == "cachegen" else "raw"
+        else:
+            raise ValueError(f"LMCLocalBackend: unsupported local_device {self.device!r}")
+        if config.local_serde not in (None, "cachegen"):
+            raise ValueError(f"Invalid local_serde: {config.local_serde}")
+        self.cachegen_config = None
+        if self.mode == "cachegen":
+            if metadata is None:
+                raise ValueError("local_serde='cachegen' needs the engine metadata (model name, fmt)")
+            self.cachegen_config = CacheGenConfig.from_model_name(metadata.model_name)
+        self.dict: Dict[CacheEngineKey, Union[torch.Tensor, _HostChunk]] = {}
+        self.update_lock = threading.Lock()
+        self.host_arena = PinnedArena() if self.mode != "hbm" else None
+        self._stage: Optional[torch.Tensor] = None   # device staging for raw gathers / scatters
+        self._stage_free: Optional[torch.cuda.Event] = None
+        self._cuda_device = torch.cuda.current_device()
+        self.put_queue: "queue.Queue" = queue.Queue()
+        self.put_thread = threading.Thread(target=self.put_worker, daemon=True)
+        self.put_thread.start()
+
+    # ------------------------------------------------------------------ basics
+    def contains(self, key: CacheEngineKey) -> bool:
+        return key in self.dict
+
+    def _publish(self, key: CacheEngineKey, entry) -> None:
+        with self.update_lock:
+            self.dict[key] = entry
+
+    @_lmcache_nvtx_annotate
+    def put_worker(self):
+        torch.cuda.set_device(self._cuda_device)
+        while True:
+            item = self.put_queue.get()
+            if isinstance(item, LocalBackendEndSignal):
+                break
+            try:
+                item()
+            except Exception:  # keep the worker alive; the chunk simply is not cached
+                logger.exception("asynchronous put failed")
+
+    def close(self):
+        if self.put_thread is not None and self.put_thread.is_alive():
+            self.put_queue.put(LocalBackendEndSignal())
+            self.put_thread.join()
+        if self.host_arena is not None:
+            # entries may still be read by a caller holding tensors made from them: drop our refs first
+            self.dict.clear()
+            self.host_arena.close()
+            self.host_arena = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ single chunk
+    def _codec(self):
+        return get_codec(self._cuda_device)
+
+    def _finish_encoded(self, keys: Sequence[CacheEngineKey], job, shapes, dtype) -> None:
+        codec = self._codec()
+        sizes = codec.sizes_of(job)
+        blobs, done = codec.offload(job, sizes, self.host_arena)
+        done.synchronize()
+        for key, hb, shp in zip(keys, blobs, shapes):
+            self._publish(key, _HostChunk(hb, None, shp, dtype, True))
+
+    def _put_chunk_now(self, key: CacheEngineKey, kv_chunk: torch.Tensor, fmt: str) -> None:
+        if not kv_chunk.is_cuda:
+            kv_chunk = kv_chunk.to(self.dst_device)
+        if self.mode == "hbm":
+            self._publish(key, kv_chunk if kv_chunk.is_contiguous() else kv_chunk.contiguous())
+            return
+        lay = native.KVLayout.from_chunk(kv_chunk, fmt)
+        shape = _chunk_shape(fmt, lay.L, lay.ntokens, lay.H, lay.D)
+        if self.mode == "cachegen":
+            _, out_dt = output_spec(fmt, 1, 1, 1, 8)
+            with torch.cuda.device(kv_chunk.device):
+                job = self._codec().encode(lay, 0, lay.ntokens, lay.ntokens, self.cachegen_config.plane_bins(lay.L))
+            self._finish_encoded([key], job, [shape], out_dt)
+            return
+        # raw: contiguous chunk -> pinned host
+        src = kv_chunk if kv_chunk.is_contiguous() else kv_chunk.contiguous()
+        nbytes = src.numel() * src.element_size()
+        hb = self.host_arena.alloc(nbytes)
+        codec = self._codec()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(src.device))
+        codec.copy_stream.wait_event(ev)
+        native.memcpy_async(hb.ptr, src.data_ptr(), nbytes, "d2h", codec.copy_stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(codec.copy_stream)
+        done.synchronize()  # `src` may be freed by the caller after we return
+        self._publish(key, _HostChunk(hb, None, tuple(src.shape), src.dtype, False))
+
+    def put(self, key: CacheEngineKey, kv_chunk: torch.Tensor, blocking: bool = True) -> None:
+        fmt = _fmt_of_chunk(kv_chunk, self.fmt)
+        if blocking:
+            self._put_chunk_now(key, kv_chunk, fmt)
+        else:
+            self.put_queue.put(lambda: self._put_chunk_now(key, kv_chunk, fmt))
+
+    @_lmcache_nvtx_annotate
+    def get(self, key: CacheEngineKey) -> Optional[torch.Tensor]:
+        entry = self.dict.get(key, None)
+        if entry is None:
+            return None
+        if isinstance(entry, torch.Tensor):
+            return entry.to(self.dst_device)
+        dev = torch.device("cuda", self._cuda_device)
+        out = torch.empty(entry.shape, dtype=entry.dtype, device=dev)
+        fmt = self.fmt or "vllm"
+        if entry.encoded:
+            T = entry.shape[2] if fmt == "vllm" else entry.shape[3]
+            self._codec().decode([entry.blob], native.KVLayout.from_chunk(out, fmt), 0, T)
+        else:
+            cur = torch.cuda.current_stream(dev)
+            native.memcpy_async(out.data_ptr(), entry.blob.ptr, entry.blob.nbytes, "h2d", cur.cuda_stream)
+        return out
+
+    def chunk_meta(self, key: CacheEngineKey) -> Tuple[Tuple[int, ...], torch.dtype]:
+        """(shape, dtype) of the chunk tensor get(key) would return."""
+        e = self.dict[key]
+        return (tuple(e.shape), e.dtype)
+
+    # ------------------------------------------------------------- range protocol
+    def _stage_tensor(self, nbytes: int, dev) -> torch.Tensor:
+        if self._stage is None or self._stage.numel() < nbytes:
+            self._stage = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return self._stage
+
+    def put_kv_range(self, keys: Sequence[CacheEngineKey], src: native.KVLayout, fmt: str, tok_begin: int,
+                     tok_end: int, chunk_tokens: int, blocking: bool = True) -> int:
+        """Store chunks [tok_begin + i*chunk_tokens, ...) of `src` under keys[i], reading KV where it lies."""
+        n = (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
+        assert n == len(keys), "one key per chunk"
+        if n == 0:
+            return 0
+        L, H, D = src.L, src.H, src.D
+        dt = native.torch_dtype(src.dtype)
+        shapes = [_chunk_shape(fmt, L, min(chunk_tokens, tok_end - (tok_begin + i * chunk_tokens)), H, D)
+                  for i in range(n)]
+        ctx = native.get_context(self._cuda_device)
+        dev = src.device
+        if self.mode == "cachegen":
+            _, out_dt = output_spec(fmt, 1, 1, 1, 8)
+            with torch.cuda.device(dev):
+                job = self._codec().encode(src, tok_begin, tok_end, chunk_tokens, self.cachegen_config.plane_bins(L))
+            if blocking:
+                self._finish_encoded(keys, job, shapes, out_dt)
+            else:
+                self.put_queue.put(lambda: self._finish_encoded(list(keys), job, shapes, out_dt))
+            return n
+        if self.mode == "hbm":
+            for key, shp, i in zip(keys, shapes, range(n)):
+                chunk = torch.empty(shp, dtype=dt, device=dev)
+                T = shp[2] if fmt == "vllm" else shp[3]
+                ctx.copy_kv(src, tok_begin + i * chunk_tokens, T, native.KVLayout.from_chunk(chunk, fmt), 0)
+                self._publish(key, chunk)
+            return n
+        # raw: gather every chunk into a device staging arena with the copy kernel, then D2H on the side stream
+        codec = self._codec()
+        cur = torch.cuda.current_stream(dev)
+        chunk_bytes = L * 2 * chunk_tokens * H * D * 2
+        stage = self._stage_tensor(n * chunk_bytes, dev)
+        if self._stage_free is not None:
+            cur.wait_event(self._stage_free)
+        views = []
+        for i, shp in enumerate(shapes):
+            numel = 1
+            for s in shp:
+                numel *= s
+            v = stage[i * chunk_bytes:i * chunk_bytes + numel * 2].view(dt).view(shp)
+            T = shp[2] if fmt == "vllm" else shp[3]
+            ctx.copy_kv(src, tok_begin + i * chunk_tokens, T, native.KVLayout.from_chunk(v, fmt), 0)
+            views.append(v)
+        gathered = torch.cuda.Event()
+        gathered.record(cur)
+        codec.copy_stream.wait_event(gathered)
+        entries = []
+        for v in views:
+            nb = v.numel() * 2
+            hb = self.host_arena.alloc(nb)
+            native.memcpy_async(hb.ptr, v.data_ptr(), nb, "d2h", codec.copy_stream.cuda_stream)
+            entries.append(_HostChunk(hb, None, tuple(v.shape), dt, False))
+        done = torch.cuda.Event()
+        done.record(codec.copy_stream)
+        self._stage_free = done
+
+        def finish():
+            done.synchronize()
+            for key, e in zip(keys, entries):
+                self._publish(key, e)
+
+        if blocking:
+            finish()
+        else:
+            self.put_queue.put(finish)
+        return n
+
+    def get_kv_range(self, keys: Sequence[CacheEngineKey], dst: native.KVLayout, fmt: str, dst_tok0: int,
+                     chunk_tokens: int) -> None:
+        """Write chunk i (stored under keys[i]) to dst tokens dst_tok0 + i*chunk_tokens ...; tokens that land
+        below 0 are dropped (retrieve()'s first-chunk trim, cache_engine.py:360-365).  All keys must be present."""
+        entries = [self.dict[k] for k in keys]
+        if not entries:
+            return
+        ctx = native.get_context(self._cuda_device)
+        dev = dst.device
+        if self.mode == "cachegen":
+            with torch.cuda.device(dev):
+                self._codec().decode([e.blob for e in entries], dst, dst_tok0, chunk_tokens)
+            return
+        cur = torch.cuda.current_stream(dev)
+        stage = None
+        if self.mode == "raw":
+            tot = sum(native.r16(e.blob.nbytes) for e in entries)
+            stage = self._stage_tensor(tot, dev)
+            if self._stage_free is not None:
+                cur.wait_event(self._stage_free)
+        off = 0
+        for i, e in enumerate(entries):
+            if isinstance(e, torch.Tensor):
+                chunk = e
+            else:
+                numel = e.blob.nbytes // 2
+                chunk = stage[off:off + e.blob.nbytes].view(e.dtype)[:numel].view(e.shape)
+                native.memcpy_async(chunk.data_ptr(), e.blob.ptr, e.blob.nbytes, "h2d", cur.cuda_stream)
+                off += native.r16(e.blob.nbytes)
+            T = chunk.shape[2] if fmt == "vllm" else chunk.shape[3]
+            t0 = dst_tok0 + i * chunk_tokens
+            skip = max(0, -t0)
+            if skip < T:
+                ctx.copy_kv(native.KVLayout.from_chunk(chunk, fmt), skip, T - skip, dst, t0 + skip)
+        if stage is not None:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._stage_free = ev

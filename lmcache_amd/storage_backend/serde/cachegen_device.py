@@ -1,0 +1,227 @@
+"""Device-side plumbing shared by the CacheGen serializer, deserializer and the
+pinned-host backend: HBM blob arena, pinned host arena, side copy stream,
+stream/event ordering.  All compute goes through the C ABI (lmcache_amd.native);
+this file only sequences it.
+
+What it replaces in the reference: the implicit, synchronous data movement of
+`pickle.dump` of CUDA tensors (cachegen_basics.py:131-136), `.cuda()` after
+`pickle.load` (cachegen_decoder.py:144-147) and the pageable `.to("cpu")` /
+`.to("cuda")` copies of LMCLocalBackend (local_backend.py:82-100, 128-144) --
+with pinned `hipMemcpyAsync` on a side stream ordered by events (no device-wide
+synchronisation: the reference itself flags torch.cuda.synchronize() as harmful
+here, local_backend.py:83-85).
+"""
+import ctypes
+import threading
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from lmcache_amd import native
+from lmcache_amd.logging import init_logger
+
+logger = init_logger(__name__)
+
+
+class PinnedArena:
+    """Bump allocator over hipHostMalloc'ed slabs.  The reference never evicts
+    (hybrid_backend.py:24), so neither do we: memory is returned at close()."""
+
+    def __init__(self, slab_bytes: int = 256 << 20):
+        self.slab_bytes = slab_bytes
+        self._slabs: List[native.PinnedBuffer] = []
+        self._used = 0
+        self._lock = threading.Lock()
+        self.total_allocated = 0
+
+    def alloc(self, nbytes: int) -> "HostBlob":
+        need = native.r16(max(nbytes, 16))
+        with self._lock:
+            if not self._slabs or self._used + need > self._slabs[-1].nbytes:
+                self._slabs.append(native.PinnedBuffer(max(self.slab_bytes, need)))
+                self._used = 0
+            slab = self._slabs[-1]
+            off = self._used
+            self._used += need
+            self.total_allocated += need
+        return HostBlob(slab, off, nbytes)
+
+    def reset(self):
+        """Recycle the newest slab (callers that own every blob handed out so far)."""
+        with self._lock:
+            for s in self._slabs[:-1]:
+                s.free()
+            self._slabs = self._slabs[-1:]
+            self._used = 0
+            self.total_allocated = 0
+
+    def close(self):
+        with self._lock:
+            for s in self._slabs:
+                s.free()
+            self._slabs = []
+
+
+@dataclass
+class HostBlob:
+    """One encoded chunk resident in pinned host DRAM."""
+    slab: native.PinnedBuffer
+    offset: int
+    nbytes: int
+
+    @property
+    def ptr(self) -> int:
+        return self.slab.ptr + self.offset
+
+    def tobytes(self) -> bytes:
+        return ctypes.string_at(self.ptr, self.nbytes)
+
+
+@dataclass
+class EncodeJob:
+    nchunks: int
+    stride: int
+    arena: torch.Tensor        # device uint8, blob i at i*stride
+    sizes: native.PinnedBuffer  # uint32 [nchunks], written by the GPU
+    done: torch.cuda.Event     # recorded after the last encode kernel
+    geometry: tuple            # (L, H, D, chunk_tokens)
+    size_list: Optional[List[int]] = None  # filled by sizes_of (the pinned words are reused by the next job)
+
+
+class CacheGenDeviceCodec:
+    """Per-device encode/decode sequencer."""
+
+    def __init__(self, device: Optional[int] = None):
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.ctx = native.get_context(self.device_index)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._lock = threading.RLock()
+        self._enc_arena: Optional[torch.Tensor] = None
+        self._dec_arena: Optional[torch.Tensor] = None
+        self._sizes: Optional[native.PinnedBuffer] = None
+        self._arena_free: Optional[torch.cuda.Event] = None  # D2H of the previous job done
+        self._dec_free: Optional[torch.cuda.Event] = None    # previous decode kernel done
+        self._stage: Optional[native.PinnedBuffer] = None    # staging for pageable `bytes` inputs
+        self._pending: Optional[EncodeJob] = None            # last job whose sizes were not read yet
+
+    # ---- encode ------------------------------------------------------------------
+    def encode(self, src: native.KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int,
+               bins: Sequence[int]) -> EncodeJob:
+        """Launch the fused encode of every chunk of [tok_begin, tok_end) on the CURRENT stream
+        (so it is ordered after whatever produced the KV).  Asynchronous."""
+        L, H, D = src.L, src.H, src.D
+        n = (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
+        stride = native.r16(native.blob_bound(L, chunk_tokens, H, D))
+        with self._lock:
+            if self._pending is not None:
+                self.sizes_of(self._pending)  # the pinned size words are about to be overwritten
+            with torch.cuda.device(self.device):
+                if self._enc_arena is None or self._enc_arena.numel() < n * stride:
+                    self._enc_arena = torch.empty(n * stride, dtype=torch.uint8, device=self.device)
+                if self._sizes is None or self._sizes.nbytes < 4 * n:
+                    self._sizes = native.PinnedBuffer(4 * max(n, 256))
+                cur = torch.cuda.current_stream(self.device)
+                if self._arena_free is not None:
+                    cur.wait_event(self._arena_free)  # previous job's D2H has read the arena
+                self.ctx.encode_chunks(src, tok_begin, tok_end, chunk_tokens, bins, self._enc_arena.data_ptr(),
+                                       stride, self._sizes.ptr, stream=cur.cuda_stream)
+                done = torch.cuda.Event()
+                done.record(cur)
+            job = EncodeJob(n, stride, self._enc_arena, self._sizes, done, (L, H, D, chunk_tokens))
+            self._pending = job
+            return job
+
+    def sizes_of(self, job: EncodeJob) -> List[int]:
+        """Wait for THIS job only (event, not device) and read the blob sizes the GPU wrote to pinned memory."""
+        with self._lock:
+            if job.size_list is None:
+                job.done.synchronize()
+                self.ctx.raise_on_status("CacheGen encode")
+                job.size_list = job.sizes.tensor[:4 * job.nchunks].view(torch.int32).tolist()
+                if self._pending is job:
+                    self._pending = None
+            return job.size_list
+
+    def offload(self, job: EncodeJob, sizes: Sequence[int], arena: PinnedArena) -> (List[HostBlob], torch.cuda.Event):
+        """hipMemcpyAsync every blob to pinned host DRAM on the side stream."""
+        blobs = []
+        with self._lock:
+            self.copy_stream.wait_event(job.done)
+            cs = self.copy_stream.cuda_stream
+            for i, nb in enumerate(sizes):
+                hb = arena.alloc(nb)
+                native.memcpy_async(hb.ptr, job.arena.data_ptr() + i * job.stride, nb, "d2h", cs)
+                blobs.append(hb)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+            self._arena_free = ev
+        return blobs, ev
+
+    # ---- decode ------------------------------------------------------------------
+    def _dec_slots(self, n: int, stride: int) -> torch.Tensor:
+        if self._dec_arena is None or self._dec_arena.numel() < n * stride:
+            self._dec_arena = torch.empty(n * stride, dtype=torch.uint8, device=self.device)
+        return self._dec_arena
+
+    def decode(self, host_blobs: Sequence, dst: native.KVLayout, dst_tok0: int, chunk_tokens: int) -> None:
+        """H2D every blob on the side stream, then ONE fused decode launch on the current stream that writes
+        straight into `dst`.  host_blobs: HostBlob (pinned) or bytes-like (staged through pinned memory)."""
+        n = len(host_blobs)
+        if n == 0:
+            return
+        sizes = [hb.nbytes if isinstance(hb, HostBlob) else len(hb) for hb in host_blobs]
+        stride = native.r16(max(sizes))
+        with self._lock:
+            with torch.cuda.device(self.device):
+                cur = torch.cuda.current_stream(self.device)
+                arena = self._dec_slots(n, stride)
+                if self._dec_free is not None:
+                    self.copy_stream.wait_event(self._dec_free)  # previous decode has read the slots
+                cs = self.copy_stream.cuda_stream
+                staged_off = 0
+                pageable = [hb for hb in host_blobs if not isinstance(hb, HostBlob)]
+                if pageable:
+                    need = sum(native.r16(len(b)) for b in pageable)
+                    if self._stage is None or self._stage.nbytes < need:
+                        self.copy_stream.synchronize()
+                        self._stage = native.PinnedBuffer(need)
+                    else:
+                        self.copy_stream.synchronize()  # staging buffer is reused: earlier H2D must be done
+                for i, hb in enumerate(host_blobs):
+                    if isinstance(hb, HostBlob):
+                        src_ptr = hb.ptr
+                    else:
+                        data = hb if isinstance(hb, bytes) else bytes(hb)  # never mutates the caller's buffer
+                        ctypes.memmove(self._stage.ptr + staged_off, data, len(data))
+                        src_ptr = self._stage.ptr + staged_off
+                        staged_off += native.r16(len(data))
+                    native.memcpy_async(arena.data_ptr() + i * stride, src_ptr, sizes[i], "h2d", cs)
+                ready = torch.cuda.Event()
+                ready.record(self.copy_stream)
+                cur.wait_event(ready)
+                self.ctx.decode_chunks(arena.data_ptr(), stride, n, dst, dst_tok0, chunk_tokens, stream=cur.cuda_stream)
+                free = torch.cuda.Event()
+                free.record(cur)
+                self._dec_free = free
+
+    def close(self):
+        with self._lock:
+            for b in (self._sizes, self._stage):
+                if b is not None:
+                    b.free()
+            self._sizes = self._stage = None
+            self._enc_arena = self._dec_arena = None
+
+
+_codecs = {}
+_codecs_lock = threading.Lock()
+
+
+def get_codec(device: Optional[int] = None) -> CacheGenDeviceCodec:
+    dev = torch.cuda.current_device() if device is None else int(device)
+    with _codecs_lock:
+        if dev not in _codecs:
+            _codecs[dev] = CacheGenDeviceCodec(dev)
+        return _codecs[dev]

@@ -1,0 +1,195 @@
+"""CPU-only tests of the host side: config, keys, hash index, retrieve planning,
+factories, blob header parsing and the C-ABI export list.  No GPU compute."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from lmcache_amd.config import LMCacheEngineConfig, LMCacheEngineMetadata
+from lmcache_amd.utils import CacheEngineKey
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bare_engine(chunk_size, fmt="vllm"):
+    """An engine without a backend: the index logic is pure Python."""
+    from lmcache_amd.cache_engine import LMCacheEngine
+    e = LMCacheEngine.__new__(LMCacheEngine)
+    e.chunk_size = chunk_size
+    e.metadata = LMCacheEngineMetadata("test_model", 3, 123, fmt, "half")
+    return e
+
+
+def test_key_string_roundtrip_and_golden(golden_dir):
+    with open(os.path.join(golden_dir, "hash_chain.json")) as f:
+        gold = json.load(f)
+    key = CacheEngineKey(*gold["key_fields"])
+    assert key.to_string() == gold["key_string"]
+    assert CacheEngineKey.from_string(gold["key_string"]) == key
+    assert hash(key) == hash(CacheEngineKey.from_string(key.to_string()))
+    with pytest.raises(ValueError):
+        CacheEngineKey.from_string("a@b@c")
+    assert len(key.to_string()) <= 150  # lm:// header limit (protocol.py:4,28-30)
+
+
+def test_prefix_hash_matches_reference_and_oracle(golden_dir, oracle):
+    with open(os.path.join(golden_dir, "hash_chain.json")) as f:
+        gold = json.load(f)
+    for case in gold["cases"]:
+        e = _bare_engine(case["chunk_size"])
+        toks = torch.tensor(case["tokens"], dtype=torch.int64)
+        got = e._prefix_hash(e._chunk_tokens(toks))
+        assert got == case["hashes"], case["name"]                       # reference-generated
+        assert got == oracle.prefix_hash(toks.numpy(), case["chunk_size"])  # independent C SHA-256
+        assert e._prefix_hash(e._chunk_tokens(toks), 1) == case["hashes"][1:]
+    # dtype dependence noted in SURVEY.md 8(c): int32 tokens hash differently
+    e = _bare_engine(256)
+    t64 = torch.arange(300, dtype=torch.int64)
+    assert e._prefix_hash(e._chunk_tokens(t64)) != e._prefix_hash(e._chunk_tokens(t64.to(torch.int32)))
+
+
+def test_retrieve_planning_matches_reference_semantics(golden_dir):
+    """ret_mask / hit length for prefix, diverging, extended and suffix-masked queries, as produced by the
+    reference engine (tests/golden/engine_semantics.json)."""
+    from lmcache_amd.cache_engine import LMCacheEngine
+    with open(os.path.join(golden_dir, "engine_semantics.json")) as f:
+        gold = json.load(f)
+    for rec in gold:
+        cs = rec["chunk_size"]
+        e = _bare_engine(cs, rec["fmt"])
+        stored = set(e._prefix_hash(e._chunk_tokens(torch.tensor(rec["tokens"]))))
+        for q in rec["queries"]:
+            toks = torch.tensor(q["tokens"])
+            skip = q["skip"] or 0
+            hashes = e._prefix_hash(e._chunk_tokens(toks), skip // cs)
+            hits = 0
+            for h in hashes:
+                if h not in stored:
+                    break
+                hits += 1
+            _, extra, nret = LMCacheEngine.plan_retrieve(len(toks), cs, skip, hits)
+            assert nret == q["ret_tokens"], q["name"]
+            mask = torch.ones(len(toks), dtype=torch.bool)
+            mask[:skip] = False
+            if nret == 0:
+                mask[:] = False
+            else:
+                mask[skip + nret:] = False
+            assert mask.to(torch.int8).tolist() == q["ret_mask"], q["name"]
+
+
+def test_config_loaders(tmp_path):
+    c = LMCacheEngineConfig.from_defaults()
+    assert (c.chunk_size, c.local_device, c.remote_url, c.remote_serde) == (256, "cuda", "redis://localhost:6379", "torch")
+    assert LMCacheEngineConfig.from_legacy(backend="cpu").local_device == "cpu"
+    assert LMCacheEngineConfig.from_legacy(backend="file://local_disk/").local_device == "local_disk/"
+    c = LMCacheEngineConfig.from_legacy(backend="lm://localhost:65000")
+    assert c.local_device is None and c.remote_url == "lm://localhost:65000"
+    # positional construction stays the reference's six fields
+    c = LMCacheEngineConfig(128, "cpu", None, "cachegen", False, True)
+    assert c.local_serde is None and c.save_decode_cache
+    p = tmp_path / "a.yaml"
+    p.write_text("chunk_size: 64\nlocal_device: cpu\nremote_url: null\nlocal_serde: cachegen\n")
+    c = LMCacheEngineConfig.from_file(str(p))
+    assert (c.chunk_size, c.local_device, c.remote_url, c.remote_serde, c.local_serde) == (64, "cpu", None, "torch", "cachegen")
+    p.write_text("local_device: file://somewhere/\nremote_url: lm://h:1\n")
+    c = LMCacheEngineConfig.from_file(str(p))
+    assert c.local_device == "somewhere/" and c.remote_url == "lm://h:1" and c.chunk_size == 256
+    p.write_text("local_device: tape\n")
+    with pytest.raises(ValueError):
+        LMCacheEngineConfig.from_file(str(p))
+    p.write_text("remote_url: nonsense\n")
+    with pytest.raises(ValueError):
+        LMCacheEngineConfig.from_file(str(p))
+
+
+def test_cachegen_tables(oracle):
+    from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
+    for name in ("mistralai/Mistral-7B-Instruct-v0.2", "meta-llama/Llama-3.1-8B-Instruct", "THUDM/glm-4-9b-chat"):
+        cfg = CacheGenConfig.from_model_name(name)
+        bins, nl = oracle.cachegen_bins(name)
+        assert cfg.plane_bins(nl) == bins.tolist()
+        assert cfg["key_first_bins"] == 32 and cfg.key_third_layers == nl
+    assert len(CacheGenConfig.from_model_name("Llama-3-70B").key_bins()) == 80
+    with pytest.raises(ValueError):
+        CacheGenConfig.from_model_name("not/a-model")
+
+
+def test_factories_reject_bad_configs():
+    from lmcache_amd.storage_backend import CreateStorageBackend
+    from lmcache_amd.storage_backend.connector import CreateConnector
+    from lmcache_amd.storage_backend.serde import CreateSerde
+    meta = LMCacheEngineMetadata("test_model", 1, 0, "vllm", "half")
+    with pytest.raises(ValueError):
+        CreateStorageBackend(LMCacheEngineConfig(256, None, None, "torch", False, False), meta)
+    with pytest.raises(ValueError):
+        CreateSerde("bogus", LMCacheEngineConfig.from_defaults(), meta)
+    with pytest.raises(ValueError):  # unknown model for cachegen (cachegen_basics.py:77-78)
+        CreateSerde("cachegen", LMCacheEngineConfig.from_defaults(), meta)
+    with pytest.raises(ValueError):
+        CreateConnector("notaurl")
+    s, d = CreateSerde("torch", LMCacheEngineConfig.from_defaults(), meta)
+    t = torch.rand(2, 2, 5, 3, 8).to(torch.bfloat16)
+    assert torch.equal(d.from_bytes(s.to_bytes(t)), t)
+    c = CreateConnector("mem://unit:1")
+    c.set("k", b"v")
+    assert c.exists("k") and c.get("k") == b"v" and c.list() == ["k"] and not c.exists("x")
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads and exports exactly what include/lmc_hip.h declares."""
+    from lmcache_amd import native
+    hdr = open(os.path.join(ROOT, "include", "lmc_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(lmc_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"lmc_r16", "lmc_blob_layout", "lmc_group_cap_bytes", "lmc_blob_bound"}  # static inline (lmc_format.h)
+    assert declared == set(native.SYMBOLS), declared ^ set(native.SYMBOLS)
+    L = native.lib()  # raises if any symbol is missing
+    out = subprocess.check_output(["nm", "-D", "--defined-only", native.SO_PATH], text=True)
+    exported = set(re.findall(r" T (lmc_[a-z0-9_]+)", out))
+    assert declared <= exported
+    assert L.lmc_abi_version() == 1
+    assert L.lmc_strerror(-1).decode().startswith("invalid")
+
+
+def test_blob_header_parse_on_host(oracle):
+    """lmc_blob_info / CacheGenEncoderOutput.from_bytes on an oracle-made blob (tests/test_serde.py:59-62 analogue)."""
+    from lmcache_amd import native
+    from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenEncoderOutput
+    torch.manual_seed(1)
+    L, T, H, D = 2, 20, 8, 128
+    kv = torch.rand(L, 2, T, H * D).to(torch.bfloat16)
+    bits, code = oracle.torch_to_bits(kv)
+    bins = np.array([32, 16, 32, 16], np.int32)
+    blob = oracle.encode_blob(bits, code, H, D, bins)
+    h = native.blob_info(blob)
+    assert (h.num_layers, h.ntokens, h.num_heads, h.head_size, h.total_bytes) == (L, T, H, D, len(blob))
+    assert native.blob_bound(L, T, H, D) == oracle.blob_bound(L, T, H, D)
+    out = CacheGenEncoderOutput.from_bytes(blob)
+    assert out.num_heads == 8 and out.head_size == 128
+    assert out.bins == bins.tolist()
+    sym, scale = oracle.quantize(bits, code, bins)
+    assert np.array_equal(out.cdf.numpy().view(np.uint16), oracle.cdf(sym))
+    assert np.array_equal(out.max_tensors_key.view(torch.int16).numpy().view(np.uint16)[..., 0], scale[:L])
+    assert out.data_chunks[0].ntokens == T
+    assert int(out.data_chunks[0].bytestream_lengths.sum()) <= h.stream_bytes
+    with pytest.raises(native.NativeError):
+        native.blob_info(b"\0" * 200)
+    with pytest.raises(native.NativeError):
+        native.blob_info(blob[:1000])  # truncated: total_bytes > len
+
+
+def test_product_never_imports_the_oracle():
+    """The product path must not route through oracle/ (checked statically)."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lmcache_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, fn)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "lmc_oracle" in src or "liblmc_oracle" in src:
+                    bad.append(fn)
+    assert not bad, bad
