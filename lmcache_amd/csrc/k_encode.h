@@ -11,9 +11,10 @@
 //
 //   pass 1  per-lane histogram in LDS [bin pair][lane] (2 x u16 counters per
 //           dword, ds_add, bank = lane: conflict free)
-//   CDF     cdf[i] = RNE(n_i * 65504 / T) + i, exact integer arithmetic
-//           -> staged in LDS and written to the blob's cdf section as whole
-//              16-byte vectors;  coder table tab[s][lane] = freq<<16 | start
+//   CDF     cdf[i] = RNE(n_i * 65504 / T) + i, exact integer arithmetic, kept in
+//           LDS as tab[entry][lane] u16 (aliases the dead histogram: 4.2 KiB per
+//           wave -> 8 waves per SIMD) and written to the blob's cdf section with
+//           coalesced 2-byte stores read transposed from LDS
 //   pass 2  tokens T-1..0: renormalise (ballot + mbcnt append of 16-bit words,
 //           ascending lane order), then x = (x/f << 16) + x%f + start
 //   tail    64 states, zero pad to 16 B, exact length -> glen
@@ -36,18 +37,19 @@ struct EncodeArgs {
   u32* status;
 };
 
-#define ENC_WAVE_DWORDS 3104  // tab 32*64 dwords (8 KiB, aliases hist 16*64) + cdf stage 1056 dwords (4224 B)
+#define ENC_WAVE_DWORDS 1056  // 4224 B per wave: histogram [16][64] u32, then (aliased) CDF table [33][64] u16
 
 template <bool QUADSYM, bool ENCODE>
 __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   __shared__ __attribute__((aligned(16))) u32 lds_all[4 * ENC_WAVE_DWORDS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  // everything derived from the wave id is wave-uniform: keep it in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long gid = (long long)blockIdx.x * 4 + wave;
   const long long ngroups_total = (long long)a.nchunks * a.P * a.G;
   if (gid >= ngroups_total) return;
-  u32* tab = lds_all + wave * ENC_WAVE_DWORDS;  // [32][64]
-  u32* hist = tab;                              // [16][64] (dead before tab is written)
-  u16* stage = reinterpret_cast<u16*>(tab + 32 * 64);  // [64][33] u16
+  u32* hist = lds_all + wave * ENC_WAVE_DWORDS;    // [16][64] u32: two u16 counters per dword
+  u16* tab = reinterpret_cast<u16*>(hist);          // [33][64] u16 CDF, written after hist is in registers
 
   const int g = (int)(gid % a.G);
   const long long pc = gid / a.G;
@@ -76,17 +78,15 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           if (4 * (qb + j) + k >= Tc) break;
-          u32 s = (w[j] >> (8 * k)) & 0xffu;
-          if (active) atomicAdd(&hist[(s >> 1) * 64 + lane], 1u << ((s & 1u) * 16));
+          const u32 s = (w[j] >> (8 * k)) & 0xffu;
+          atomicAdd(&hist[(s >> 1) * 64 + lane], 1u << ((s & 1u) * 16));  // ds_add_u32, bank = lane
         }
       }
     }
   } else {
     for (int t = 0; t < Tc; t++) {
-      if (active) {
-        u32 s = min((u32)(u8)symb[(long long)t * a.C], 31u);
-        atomicAdd(&hist[(s >> 1) * 64 + lane], 1u << ((s & 1u) * 16));
-      }
+      const u32 s = active ? min((u32)(u8)symb[(long long)t * a.C], 31u) : 0u;
+      atomicAdd(&hist[(s >> 1) * 64 + lane], 1u << ((s & 1u) * 16));
     }
   }
   u32 hreg[16];
@@ -98,69 +98,81 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   const u32 T = (u32)Tc;
   const u32 magic = (T == 1u) ? 0xffffffffu : (u32)(0x100000000ull / T);
   {
-    u32 n = 0, prev = 0;
+    u32 n = 0;
 #pragma unroll
     for (int i = 0; i <= 32; i++) {
-      u32 ci = (rne_div_u32(n * LMC_CDF_SCALE, T, magic) + (u32)i) & 0xffffu;
-      stage[lane * LMC_LP + i] = (u16)ci;
-      if (i >= 1) tab[(i - 1) * 64 + lane] = (((ci - prev) & 0xffffu) << 16) | prev;
-      prev = ci;
+      const u32 ci = rne_div_u32(n * LMC_CDF_SCALE, T, magic) + (u32)i;
+      tab[i * 64 + lane] = (u16)ci;  // entry 32 is 65536 stored as 0
       if (i < 32) n += (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
     }
   }
-  wave_lds_fence();  // stage rows are read by other lanes below
+  wave_lds_fence();  // columns are read by other lanes below
   {
-    const int nvalid = min(64, a.C - g * 64);
-    const int n16 = nvalid * (LMC_LP * 2) / 16;  // C % 8 == 0 -> whole vectors
+    // channel-major [c][33] rows of this group are contiguous in the blob: write them with
+    // consecutive lanes on consecutive u16 (128 B per store), reading LDS transposed
+    const u32 total = (u32)min(64, a.C - g * 64) * LMC_LP;
     u16* dst;
     if (ENCODE) {
-      BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G);
+      const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G);
       dst = reinterpret_cast<u16*>(a.blobs + (long long)chunk * a.blob_stride + bo.cdf);
     } else {
       dst = a.cdf_out;
     }
     dst += ((long long)p * a.C + g * 64) * LMC_LP;
-    const uint4* s4 = reinterpret_cast<const uint4*>(stage);
-    uint4* d4 = reinterpret_cast<uint4*>(dst);
-    for (int i = lane; i < n16; i += 64) d4[i] = s4[i];
+    for (u32 e = lane; e < total; e += 64) {
+      const u32 cl = div33(e), s = e - cl * LMC_LP;
+      dst[e] = tab[s * 64 + cl];
+    }
   }
   if (!ENCODE) return;
 
   // ---- pass 2: interleaved rANS ---------------------------------------------
   u16* out = reinterpret_cast<u16*>(a.scratch + gid * (long long)a.cap);
-  u32 x = LMC_RANS_L;
+  // Idle lanes (channel >= C) see symbol 0 only (w = 0, start 0): starting them at x = 0 keeps them at 0,
+  // so they never satisfy the renormalisation test and the hot loop needs no lane predicate.
+  u32 x = active ? LMC_RANS_L : 0u;
   u32 wcur = 0;  // wave-uniform word cursor
   for (int qb = (TQc - 1) & ~7; qb >= 0; qb -= 8) {
     u32 w[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) w[j] = (active && qb + j < TQc) ? symq[(long long)(qb + j) * a.C] : 0u;
+    // software pipeline: the table entries of the next token are fetched before this token is coded
+    const int tfirst = min(4 * (qb + 8), Tc) - 1;  // first token of this block (descending order)
+    u32 lo_n, hi_n;
+    {
+      const int jf = (tfirst >> 2) - qb, sh = 8 * (tfirst & 3);  // uniform; w[] must be indexed statically
+      u32 wf = w[0];
+#pragma unroll
+      for (int j = 1; j < 8; j++) wf = (j == jf) ? w[j] : wf;
+      const u32 s0 = (wf >> sh) & 0xffu;
+      lo_n = tab[s0 * 64 + lane];
+      hi_n = tab[s0 * 64 + 64 + lane];
+    }
 #pragma unroll
     for (int j = 7; j >= 0; j--) {
       if (qb + j >= TQc) continue;
 #pragma unroll
       for (int k = 3; k >= 0; k--) {
-        if (4 * (qb + j) + k >= Tc) continue;
-        const u32 s = (w[j] >> (8 * k)) & 0xffu;
-        const u32 e = tab[s * 64 + lane];
-        const u32 f = e >> 16, st = e & 0xffffu;
-        const bool emit = active && (x >= (f << 16));
+        const int t = 4 * (qb + j) + k;
+        if (t >= Tc) continue;
+        const u32 st = lo_n, f = (hi_n - lo_n) & 0xffffu;
+        if (!(j == 0 && k == 0)) {  // prefetch for token t-1 (same block)
+          const u32 sn = k > 0 ? (w[j] >> (8 * (k - 1))) & 0xffu : (w[j > 0 ? j - 1 : 0] >> 24) & 0xffu;
+          lo_n = tab[sn * 64 + lane];
+          hi_n = tab[sn * 64 + 64 + lane];
+        }
+        const bool emit = x >= (f << 16);
         const u64 mask = __ballot(emit);
-        if (mask) {
-          const u32 rank = lane_rank(mask);
-          if (emit) {
-            out[wcur + rank] = (u16)x;
-            x >>= 16;
-          }
-          wcur += (u32)__popcll(mask);
-        }
-        if (active) {
-          u32 q, r;
-          divmod_est(x, f, q, r);
-          x = (q << 16) + r + st;
-        }
+        if (emit) out[wcur + lane_rank(mask)] = (u16)x;
+        x = emit ? x >> 16 : x;
+        wcur += (u32)__popcll(mask);
+        u32 q, r;
+        divmod_est(x, f, q, r);
+        x = (q << 16) + r + st;
       }
     }
   }
+  x = active ? x : LMC_RANS_L;  // idle lanes (channel >= C) carry the initial state
   // tail: states, pad, length
   out[wcur + 2 * lane] = (u16)x;
   out[wcur + 2 * lane + 1] = (u16)(x >> 16);

@@ -121,13 +121,20 @@ __device__ __forceinline__ u32 rne_div_u32(u32 v, u32 T, u32 magic) {
   return q;
 }
 
-// Exact (x / f, x % f) for x < f * 2^16, 1 <= f < 2^16, through a float
-// reciprocal estimate corrected by at most one step either way.
+// Exact (x / f, x % f) for x < f * 2^16, 1 <= f < 2^16.
+// qe = trunc(float(x) * rcp(f) * (1 - 2^-21)): the four roundings involved
+// (cvt 2^-24, v_rcp_f32 1 ulp = 2^-23, two multiplies 2^-24 each) add up to
+// < 2^-21.6 relative, so the biased estimate never exceeds the true quotient
+// and is short of it by < 2^16 * 2^-20.3 < 1: qe is q or q-1, one branch-free
+// correction (re >= f) finishes it.
 __device__ __forceinline__ void divmod_est(u32 x, u32 f, u32& q, u32& r) {
-  float rf = __builtin_amdgcn_rcpf((float)f);
-  u32 qe = (u32)((float)x * rf);
-  u32 re = x - __umul24(qe, f);
-  if ((int)re < 0) { qe--; re += f; }
-  else if (re >= f) { qe++; re -= f; }
-  q = qe; r = re;
+  const float rf = __builtin_amdgcn_rcpf((float)f) * 0.99999952316284f;  // 1 - 2^-21
+  const u32 qe = (u32)((float)x * rf);
+  const u32 re = x - __umul24(qe, f);
+  const bool fix = re >= f;
+  q = qe + (fix ? 1u : 0u);
+  r = fix ? re - f : re;
 }
+
+// e / 33 for e < 8192 (CDF rows are 33 entries)
+__device__ __forceinline__ u32 div33(u32 e) { return (e * 1986u) >> 16; }
