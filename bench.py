@@ -37,6 +37,9 @@ MODEL = "meta-llama/Llama-3.1-8B-Instruct"
 L, H, D = 32, 8, 128
 CTX, CHUNK = 16384, 256
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# HBM bytes per step from the PMC passes committed under profiles/ (see profiles/r01_*_pmc.md): updated by hand
+# whenever the kernels' data flow changes; None until measured.
+TRAFFIC_BYTES_PER_STEP = None
 
 
 def cachegen_bins_llama8b():
@@ -87,6 +90,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the cpu_baseline sample (0 = auto)")
+    ap.add_argument("--subbatch", type=int, default=0, help="chunks per encode sub-batch (0 = whole context at once)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,6 +114,7 @@ def main():
     blobs = torch.empty(nchunks * stride, dtype=torch.uint8, device=dev)
     sizes = torch.zeros(nchunks, dtype=torch.int32, device=dev)
     ctx.reserve(L, H, D, CHUNK, nchunks)
+    ctx.set_subbatch(args.subbatch)
     raw_bytes = L * 2 * CTX * H * D * 2
 
     stream = torch.cuda.Stream(device=dev)
@@ -139,6 +144,7 @@ def main():
     ev1.record(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
     barrier()
     ctx.raise_on_status("bench")
     if world > 1:
@@ -178,15 +184,20 @@ def main():
     ctx.profile(False)
     kms = ksum / reps
     knames = ["k_quantize", "k_cdf_encode", "k_scan_finalize", "k_pack_streams"]
-    t_kernels = float(kms.sum()) / 1e3
-    achieved = algo_bytes / t_kernels / 1e9
+    achieved = algo_bytes / (gpu_ms_per_step / 1e3) / 1e9
+    serial = algo_bytes / (float(kms.sum()) / 1e3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": TRAFFIC_BYTES_PER_STEP,
                 "kernel": knames[int(np.argmax(kms))],
-                "kernels_ms": {n: round(float(v), 4) for n, v in zip(knames, kms)},
+                "gpu_ms_per_step": round(gpu_ms_per_step, 4),
+                "kernels_ms_serial": {n: round(float(v), 4) for n, v in zip(knames, kms)},
+                "achieved_serial": round(serial, 1),
                 "algorithmic_bytes_per_step": int(algo_bytes),
-                "note": "achieved = (raw KV read once + blob written once) / sum of the four encode kernels' "
-                        "HIP-event durations on the launch stream"}
+                "note": "achieved = (raw KV read once + blob written once) per step / HIP-event time of one step "
+                        "(the whole encode job = its four kernels) on the launch stream over the timed region; "
+                        "kernels_ms_serial = per-kernel HIP events of one job (lmc_ctx_profile); traffic = HBM bytes per "
+                        "step from rocprofv3 FETCH_SIZE/WRITE_SIZE (profiles/), FETCH_SIZE doubled for the 16-B/lane "
+                        "streams per MI355X_MICROARCH.md"}
 
     # offload leg: blobs -> pinned host on a side stream, pipelined with the next step's kernels
     offload = None

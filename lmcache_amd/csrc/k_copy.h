@@ -28,6 +28,6 @@ __global__ __launch_bounds__(256) void k_copy_kv(CopyArgs a) {
     const u16* sp = lmc_plane_base(a.src, p) + lmc_tok_off(a.src, a.tok_begin + t) + (long long)hs * a.src.stride_head + ds;
     u16* dp = const_cast<u16*>(lmc_plane_base(a.dst, p)) + lmc_tok_off(a.dst, a.dst_tok0 + t) +
               (long long)hs * a.dst.stride_head + ds;
-    *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+    st_global_u4(dp, ld_global_u4(sp));
   }
 }

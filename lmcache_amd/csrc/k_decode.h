@@ -35,12 +35,23 @@ struct DecodeArgs {
   u32* status;
 };
 
-// per-wave LDS: cdfT [32][64] u16 (4096) | word ring 512 x u16 (1024) | scales 512 x u16 (1024) | lut 32 x f32 (128)
-#define DEC_WAVE_BYTES 6272
+// per-wave LDS: cdfT [33][64] u16 (4224) | word ring 512 x u16 (1024) | scales 512 x u16 (1024) | lut 32 x f32 (128)
+#define DEC_CDF_BYTES 4224
+#define DEC_WAVE_BYTES (DEC_CDF_BYTES + 1024 + 1024 + 128)
 #define DEC_RING_WORDS 512
 #define DEC_SCALE_TOKENS 512
 
-template <bool SYMOUT, int DT_OUT>
+template <bool B>
+struct BoolTag { static constexpr bool value = B; };
+
+__device__ __forceinline__ u64 uniform_ptr(const void* p) {  // a pointer every lane holds -> SGPR pair
+  const u64 v = (u64)p;
+  const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
+  const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+  return ((u64)hi << 32) | (u64)lo;
+}
+
+template <bool SYMOUT, int DT_OUT, bool PAGED>
 __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   __shared__ __attribute__((aligned(16))) u8 lds_all[4 * DEC_WAVE_BYTES];
   const int lane = threadIdx.x & 63;
@@ -49,10 +60,10 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   const int n = a.P * a.G;
   if (gid >= (long long)a.nchunks * n) return;
   u8* wl = lds_all + wave * DEC_WAVE_BYTES;
-  u16* cdfT = reinterpret_cast<u16*>(wl);                 // [32][64]: entry-major, bank = lane/2
-  u16* ring = reinterpret_cast<u16*>(wl + 4096);          // stream words, indexed by consumption order
-  u16* scs = reinterpret_cast<u16*>(wl + 4096 + 1024);    // raw per-token scales of this plane
-  float* lut = reinterpret_cast<float*>(wl + 4096 + 2048);  // (q - C) / C
+  u16* cdfT = reinterpret_cast<u16*>(wl);                           // [33][64]: entry-major, bank = lane/2
+  u16* ring = reinterpret_cast<u16*>(wl + DEC_CDF_BYTES);           // stream words, by consumption order
+  u16* scs = reinterpret_cast<u16*>(wl + DEC_CDF_BYTES + 1024);     // raw per-token scales (one window)
+  float* lut = reinterpret_cast<float*>(wl + DEC_CDF_BYTES + 2048);  // (q - C) / C
 
   const int chunk = (int)(gid / n);
   const int pg = (int)(gid - (long long)chunk * n);
@@ -85,19 +96,16 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
       for (int i = 0; i < 11; i++) {
         const u32 e = e0 + i * 64 + lane;
         const u32 cl = div33(e), s = e - cl * LMC_LP;
-        if (e < total && s < 32u) cdfT[s * 64 + cl] = v[i];
+        if (e < total) cdfT[s * 64 + cl] = v[i];
       }
     }
     if (!active) {  // idle lanes: any strictly increasing column keeps the search in range
 #pragma unroll
-      for (int i = 0; i < 32; i++) cdfT[i * 64 + lane] = (u16)i;
+      for (int i = 0; i < 33; i++) cdfT[i * 64 + lane] = (u16)i;
     }
   }
-  // ---- per-token scales and the dequantisation LUT -------------------------
+  // ---- dequantisation LUT; scales are staged one 512-token window at a time inside the loop ----
   const u16* scl = reinterpret_cast<const u16*>(blob + bo.scales) + (long long)p * T;
-  const bool sc_in_lds = !SYMOUT && T <= (u32)DEC_SCALE_TOKENS;
-  if (sc_in_lds)
-    for (u32 t = lane; t < T; t += 64) scs[t] = scl[t];
   if (!SYMOUT && lane < 32) {
     const float Cf = (float)((int)blob[bo.bins + p] / 2 - 1);
     const float v = (float)lane - Cf;
@@ -117,9 +125,10 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   u32 x = (u32)words[nwords + 2 * lane] | ((u32)words[nwords + 2 * lane + 1] << 16);
   // Word k (k = 0, 1, ... in the order the decoder consumes them) is words[nwords - 1 - k]; it is staged
   // in ring[k % 512].  The ring is refilled half a ring (256 words) at a time: the loads of the next half
-  // are ISSUED into registers when fewer than 384 words are ahead of the consumer and WRITTEN to the ring
-  // when fewer than 256 are (by then the older half is fully consumed) -- ~10 tokens later, so their
-  // latency is off the per-token dependency chain.
+  // are ISSUED into registers when at most 384 words are ahead of the consumer and WRITTEN to the ring
+  // when at most 256 are (by then the older half is fully consumed) -- ~10 tokens later, so their
+  // latency is off the per-token dependency chain.  Reads past the end of a corrupt stream stay inside
+  // the ring (index masked, loads guarded); the final state / count check reports them.
   u16 pend[4];
   auto ring_issue = [&](u32 k0) {
 #pragma unroll
@@ -136,76 +145,93 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   ring_commit(0);
   ring_issue(256);
   ring_commit(256);
-  u32 filled = 512;        // words [0, filled) are in the ring
-  bool pending = false;    // loads for [filled, filled + 256) are in flight (wave-uniform)
-  u32 consumed = 0;        // wave-uniform
+  u32 filled = 512;     // words [0, filled) are in the ring
+  u32 consumed = 0;     // wave-uniform
+  u32 trigger = 128;    // next ring event when consumed reaches this (= filled - 384, then filled - 256)
+  bool pending = false;
   wave_lds_fence();
 
   // pivots of the first search level live in registers
   const u32 p8 = cdfT[8 * 64 + lane], p16 = cdfT[16 * 64 + lane], p24 = cdfT[24 * 64 + lane];
 
-  // destination addressing (row independent part)
-  u16* dbase = nullptr;
-  int8_t* sbase = nullptr;
+  // destination: uniform base (SGPRs) + per-lane 32-bit byte offset
+  u32 lane_off = 0;
+  u64 ubase = 0;
   if (SYMOUT) {
-    sbase = a.sym_out + (long long)p * T * a.C + c;
+    ubase = (u64)(a.sym_out + (long long)p * T * a.C);
+    lane_off = (u32)c;
   } else {
     const int h = c / a.dst.D, d = c - h * a.dst.D;
-    dbase = const_cast<u16*>(lmc_plane_base(a.dst, p)) + (long long)h * a.dst.stride_head + d;
+    lane_off = (u32)(((long long)h * a.dst.stride_head + d) * 2);
+    ubase = uniform_ptr(lmc_plane_base(a.dst, p));
   }
   const int tdst0 = a.dst_tok0 + chunk * a.chunk_tokens;
-  bool bad = false;
 
-  for (u32 t = 0; t < T; t++) {
-    const u32 slot = x & 0xffffu;
-    // level 1: quadrant from register pivots; levels 2-4: three dependent LDS probes
-    const bool g8 = p8 <= slot, g16 = p16 <= slot, g24 = p24 <= slot;
-    u32 s = g24 ? 24u : g16 ? 16u : g8 ? 8u : 0u;
-    u32 lo = g24 ? p24 : g16 ? p16 : g8 ? p8 : 0u;
-    u32 hi = g24 ? 65536u : g16 ? p24 : g8 ? p16 : p8;
+  auto run = [&](auto src_tag) {
+    constexpr bool SRC_BF16 = decltype(src_tag)::value;
+    for (u32 t0 = 0; t0 < T; t0 += DEC_SCALE_TOKENS) {
+      const u32 t1 = min(T, t0 + (u32)DEC_SCALE_TOKENS);
+      if (!SYMOUT) {
+        wave_lds_fence();
+        for (u32 t = t0 + lane; t < t1; t += 64) scs[t - t0] = scl[t];
+        wave_lds_fence();
+      }
+      for (u32 t = t0; t < t1; t++) {
+        const u32 slot = x & 0xffffu;
+        // level 1 on register pivots, levels 2-4 on LDS probes; then the symbol's own two CDF entries
+        u32 s = (p8 <= slot ? 8u : 0u) + (p16 <= slot ? 8u : 0u) + (p24 <= slot ? 8u : 0u);
 #pragma unroll
-    for (int step = 4; step >= 1; step >>= 1) {
-      const u32 v = cdfT[(s + step) * 64 + lane];
-      const bool ge = v <= slot;
-      s = ge ? s + step : s;
-      lo = ge ? v : lo;
-      hi = ge ? hi : v;
-    }
-    const u32 f = hi - lo;
-    x = __umul24(f, x >> 16) + slot - lo;
-    const bool need = active && (x < LMC_RANS_L);
-    const u64 mask = __ballot(need);
-    const u32 cnt = (u32)__popcll(mask);
-    if (consumed + cnt > nwords) { bad = true; break; }
-    // the encoder appended this token's words in ascending lane order; counted from the tail that is
-    // descending, so rank r of cnt takes consumption index consumed + cnt - 1 - r
-    if (need) x = (x << 16) | (u32)ring[(consumed + cnt - 1u - lane_rank(mask)) & (DEC_RING_WORDS - 1)];
-    consumed += cnt;
-    if (!pending && consumed + 384u >= filled && filled < nwords) {
-      ring_issue(filled);
-      pending = true;
-    }
-    if (pending && consumed + 256u >= filled) {
-      wave_lds_fence();  // every lane's reads of the older half are done
-      ring_commit(filled);
-      filled += 256;
-      pending = false;
-      wave_lds_fence();
-    }
-    if (SYMOUT) {
-      if (active) sbase[(long long)t * a.C] = (int8_t)s;
-    } else {
-      const int td = tdst0 + (int)t;
-      if (td >= 0 && active) {
-        const float scale = h2f_rt(sc_in_lds ? scs[t] : scl[t], (int)src_dtype);
-        const float val = lut[s] * scale;
-        const u32 bits = DT_OUT == LMC_DTYPE_BF16 ? f2bf16(val) : f2fp16(val);
-        dbase[lmc_tok_off(a.dst, td)] = (u16)bits;
+        for (int step = 4; step >= 1; step >>= 1) {
+          const u32 v = cdfT[(s + step) * 64 + lane];
+          s = v <= slot ? s + step : s;
+        }
+        const u32 lo = cdfT[s * 64 + lane], hi = cdfT[s * 64 + 64 + lane];  // entry 32 is 65536 stored as 0
+        const u32 f = (hi - lo) & 0xffffu;
+        x = __umul24(f, x >> 16) + slot - lo;
+        const bool need = active && (x < LMC_RANS_L);
+        const u64 mask = __ballot(need);
+        const u32 cnt = (u32)__popcll(mask);
+        // the encoder appended this token's words in ascending lane order; counted from the tail that is
+        // descending, so rank r of cnt takes consumption index consumed + cnt - 1 - r
+        if (need) x = (x << 16) | (u32)ring[(consumed + cnt - 1u - lane_rank(mask)) & (DEC_RING_WORDS - 1)];
+        consumed += cnt;
+        if (consumed >= trigger) {
+          if (!pending) {
+            ring_issue(filled);
+            pending = true;
+            trigger = filled - 256u;
+          } else {
+            wave_lds_fence();  // every lane's reads of the older half are done
+            ring_commit(filled);
+            filled += 256;
+            pending = false;
+            trigger = filled - 384u;
+            wave_lds_fence();
+          }
+        }
+        if (SYMOUT) {
+          if (active) *((LMC_GLOBAL int8_t*)(ubase + (u64)t * a.C) + lane_off) = (int8_t)s;
+        } else {
+          const int td = tdst0 + (int)t;
+          if (td >= 0 && active) {
+            const u32 sb = scs[t - t0];
+            const float scale = SRC_BF16 ? __uint_as_float(sb << 16) : (float)__builtin_bit_cast(_Float16, (unsigned short)sb);
+            const float val = lut[s] * scale;
+            u16 bits;
+            if (DT_OUT == LMC_DTYPE_BF16) bits = __builtin_bit_cast(unsigned short, (__bf16)val);  // v_cvt_pk_bf16_f32, RNE
+            else bits = (u16)f2fp16(val);
+            const long long row = PAGED ? lmc_tok_off(a.dst, td) : (long long)td * a.dst.stride_token;
+            *(LMC_GLOBAL u16*)((LMC_GLOBAL u8*)(ubase + (u64)(row * 2)) + lane_off) = bits;
+          }
+        }
       }
     }
-  }
+  };
+  if (src_dtype == (u32)LMC_DTYPE_BF16) run(BoolTag<true>{});
+  else run(BoolTag<false>{});
+
   const bool state_bad = active && x != LMC_RANS_L;
-  if (bad || consumed != nwords || __ballot(state_bad)) {
+  if (consumed != nwords || __ballot(state_bad)) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_STREAM);
   }
 }

@@ -57,7 +57,6 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   const int chunk = (int)(pc / a.P);
   const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
   const int Tc = min(a.chunk_tokens, a.tok_end - tok0);
-  const int TQc = (Tc + 3) >> 2;
   const int c = g * 64 + lane;
   const bool active = c < a.C;
 
@@ -65,23 +64,37 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   const int8_t* symb = QUADSYM ? nullptr : a.sym8 + (long long)p * Tc * a.C + c;
 
   // ---- pass 1: histogram --------------------------------------------------
+  // Blocks of 8 quads (32 tokens).  Every block but the last is full, so the hot path carries no
+  // per-token guards; the next block's symbols are loaded while the current one is processed.
 #pragma unroll
   for (int i = 0; i < 16; i++) hist[i * 64 + lane] = 0;
   if (QUADSYM) {
-    for (int qb = 0; qb < TQc; qb += 8) {
-      u32 w[8];
+    const int nfull = Tc >> 5;  // full 32-token blocks
+    u32 w[8], wn[8];
+    if (nfull > 0) {
 #pragma unroll
-      for (int j = 0; j < 8; j++) w[j] = (active && qb + j < TQc) ? symq[(long long)(qb + j) * a.C] : 0u;
+      for (int j = 0; j < 8; j++) w[j] = active ? symq[(long long)j * a.C] : 0u;
+    }
+    for (int b = 0; b < nfull; b++) {
+      if (b + 1 < nfull) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) wn[j] = active ? symq[(long long)((b + 1) * 8 + j) * a.C] : 0u;
+      }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        if (qb + j >= TQc) break;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          if (4 * (qb + j) + k >= Tc) break;
           const u32 s = (w[j] >> (8 * k)) & 0xffu;
           atomicAdd(&hist[(s >> 1) * 64 + lane], 1u << ((s & 1u) * 16));  // ds_add_u32, bank = lane
         }
       }
+#pragma unroll
+      for (int j = 0; j < 8; j++) w[j] = wn[j];
+    }
+    for (int t = nfull * 32; t < Tc; t++) {  // ragged tail (< 32 tokens)
+      const u32 wq = active ? symq[(long long)(t >> 2) * a.C] : 0u;
+      const u32 s = (wq >> (8 * (t & 3))) & 0xffu;
+      atomicAdd(&hist[(s >> 1) * 64 + lane], 1u << ((s & 1u) * 16));
     }
   } else {
     for (int t = 0; t < Tc; t++) {
@@ -132,44 +145,59 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   // so they never satisfy the renormalisation test and the hot loop needs no lane predicate.
   u32 x = active ? LMC_RANS_L : 0u;
   u32 wcur = 0;  // wave-uniform word cursor
-  for (int qb = (TQc - 1) & ~7; qb >= 0; qb -= 8) {
-    u32 w[8];
+
+  // one token: renormalise (append this step's words in ascending lane order), then encode
+  auto code_token = [&](u32 st, u32 f) {
+    const bool emit = x >= (f << 16);
+    const u64 mask = __ballot(emit);
+    if (emit) out[wcur + lane_rank(mask)] = (u16)x;
+    x = emit ? x >> 16 : x;
+    wcur += (u32)__popcll(mask);
+    u32 q, r;
+    divmod_est(x, f, q, r);
+    x = (q << 16) + r + st;
+  };
+
+  // ragged head of the descending walk: tokens Tc-1 .. 32*nfull (< 32 of them), one at a time
+  const int nfull = Tc >> 5;
+  for (int t = Tc - 1; t >= nfull * 32; t--) {
+    const u32 wq = active ? symq[(long long)(t >> 2) * a.C] : 0u;
+    const u32 s = (wq >> (8 * (t & 3))) & 0xffu;
+    const u32 lo = tab[s * 64 + lane], hi = tab[s * 64 + 64 + lane];
+    code_token(lo, (hi - lo) & 0xffffu);
+  }
+  // full 32-token blocks, descending; software pipelined twice over:
+  //   - the next block's 8 symbol dwords are loaded while this block is coded,
+  //   - the table entries of token t-1 are fetched from LDS before token t is coded.
+  if (nfull > 0) {
+    u32 w[8], wn[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) w[j] = (active && qb + j < TQc) ? symq[(long long)(qb + j) * a.C] : 0u;
-    // software pipeline: the table entries of the next token are fetched before this token is coded
-    const int tfirst = min(4 * (qb + 8), Tc) - 1;  // first token of this block (descending order)
-    u32 lo_n, hi_n;
-    {
-      const int jf = (tfirst >> 2) - qb, sh = 8 * (tfirst & 3);  // uniform; w[] must be indexed statically
-      u32 wf = w[0];
+    for (int j = 0; j < 8; j++) w[j] = active ? symq[(long long)((nfull - 1) * 8 + j) * a.C] : 0u;
+    u32 lo_n = tab[(w[7] >> 24) * 64 + lane], hi_n = tab[(w[7] >> 24) * 64 + 64 + lane];
+    for (int b = nfull - 1; b >= 0; b--) {
+      if (b > 0) {
 #pragma unroll
-      for (int j = 1; j < 8; j++) wf = (j == jf) ? w[j] : wf;
-      const u32 s0 = (wf >> sh) & 0xffu;
-      lo_n = tab[s0 * 64 + lane];
-      hi_n = tab[s0 * 64 + 64 + lane];
-    }
-#pragma unroll
-    for (int j = 7; j >= 0; j--) {
-      if (qb + j >= TQc) continue;
-#pragma unroll
-      for (int k = 3; k >= 0; k--) {
-        const int t = 4 * (qb + j) + k;
-        if (t >= Tc) continue;
-        const u32 st = lo_n, f = (hi_n - lo_n) & 0xffffu;
-        if (!(j == 0 && k == 0)) {  // prefetch for token t-1 (same block)
-          const u32 sn = k > 0 ? (w[j] >> (8 * (k - 1))) & 0xffu : (w[j > 0 ? j - 1 : 0] >> 24) & 0xffu;
-          lo_n = tab[sn * 64 + lane];
-          hi_n = tab[sn * 64 + 64 + lane];
-        }
-        const bool emit = x >= (f << 16);
-        const u64 mask = __ballot(emit);
-        if (emit) out[wcur + lane_rank(mask)] = (u16)x;
-        x = emit ? x >> 16 : x;
-        wcur += (u32)__popcll(mask);
-        u32 q, r;
-        divmod_est(x, f, q, r);
-        x = (q << 16) + r + st;
+        for (int j = 0; j < 8; j++) wn[j] = active ? symq[(long long)((b - 1) * 8 + j) * a.C] : 0u;
       }
+#pragma unroll
+      for (int j = 7; j >= 0; j--) {
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+          const u32 st = lo_n, f = (hi_n - lo_n) & 0xffffu;
+          if (j > 0 || k > 0) {  // entries of the next token of this block
+            const u32 sn = k > 0 ? (w[j] >> (8 * (k - 1))) & 0xffu : (w[j > 0 ? j - 1 : 0] >> 24) & 0xffu;
+            lo_n = tab[sn * 64 + lane];
+            hi_n = tab[sn * 64 + 64 + lane];
+          } else if (b > 0) {     // ... or of the first token of the next block
+            const u32 sn = wn[7] >> 24;
+            lo_n = tab[sn * 64 + lane];
+            hi_n = tab[sn * 64 + 64 + lane];
+          }
+          code_token(st, f);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) w[j] = wn[j];
     }
   }
   x = active ? x : LMC_RANS_L;  // idle lanes (channel >= C) carry the initial state

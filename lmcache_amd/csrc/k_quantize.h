@@ -34,15 +34,19 @@ struct QuantArgs {
   long long scale_stride;
 };
 
-__device__ __forceinline__ u32 quant_one(float x, float factor, float maxf, bool special) {
+// Regular rows (finite, non-zero max): |x * factor| <= MAX(1 + 2^-23), so the rounded value is 0 .. 2*MAX.
+__device__ __forceinline__ u32 quant_fast(float x, float factor, float maxf) {
   float y = x * factor;  // rounded
   float z = y + maxf;    // rounded separately (no FMA: -ffp-contract=off)
+  return (u32)(int)__builtin_rintf(z);
+}
+// Special rows (max is 0 / denormal-tiny / inf / NaN): follow the reference's CPU float->int8
+// conversion: NaN and |r| >= 2^31 give INT_MIN whose low byte is 0.
+__device__ __forceinline__ u32 quant_special(float x, float factor, float maxf) {
+  float y = x * factor;
+  float z = y + maxf;
   float r = __builtin_rintf(z);
-  if (special) {
-    // torch CPU float->int8: NaN / |r| >= 2^31 -> INT_MIN -> low byte 0
-    return (__builtin_fabsf(r) < 2147483648.0f) ? ((u32)(int)r & 0xffu) : 0u;
-  }
-  return (u32)(int)r;  // 0 .. 2*MAX
+  return (__builtin_fabsf(r) < 2147483648.0f) ? ((u32)(int)r & 0xffu) : 0u;
 }
 
 template <int G, int NITER, int DT, bool QUAD>
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
     const u16* rowp = pbase + (tv[r] ? lmc_tok_off(a.src, tok0 + t) : 0);
 #pragma unroll
     for (int it = 0; it < NITER; it++) {
-      if (tv[r] && cval[it]) v[r][it] = *reinterpret_cast<const uint4*>(rowp + coff[it]);
+      if (tv[r] && cval[it]) v[r][it] = ld_global_u4(rowp + coff[it]);
       else v[r][it] = make_uint4(0, 0, 0, 0);
     }
   }
@@ -136,8 +140,17 @@ __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
       const u32 w[4] = {v[r][it].x, v[r][it].y, v[r][it].z, v[r][it].w};
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        sy[r][2 * k] = quant_one(h_lo<DT>(w[k]), factor[r], maxf, special[r]);
-        sy[r][2 * k + 1] = quant_one(h_hi<DT>(w[k]), factor[r], maxf, special[r]);
+        sy[r][2 * k] = quant_fast(h_lo<DT>(w[k]), factor[r], maxf);
+        sy[r][2 * k + 1] = quant_fast(h_hi<DT>(w[k]), factor[r], maxf);
+      }
+      if (__ballot(special[r])) {  // wave-uniform and rare: redo this row's lanes the careful way
+        if (special[r]) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            sy[r][2 * k] = quant_special(h_lo<DT>(w[k]), factor[r], maxf);
+            sy[r][2 * k + 1] = quant_special(h_hi<DT>(w[k]), factor[r], maxf);
+          }
+        }
       }
     }
     if (!cval[it] || !qvalid) continue;
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
       }
       u32* dst = a.sym4 + (((long long)chunk * a.P + p) * a.TQ + q) * a.C + c0[it];
       *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
-      *reinterpret_cast<uint4*>(dst + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+      *reinterpret_cast<uint4*>(dst + 4) = make_uint4(o[4], o[5], o[6], o[7]);  // kernel-arg pointers: global already
     } else {
 #pragma unroll
       for (int r = 0; r < 4; r++) {

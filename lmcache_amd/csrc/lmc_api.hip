@@ -37,6 +37,7 @@ struct lmc_ctx {
   hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
   bool ws_used = false;
   u32* status_h = nullptr;  // pinned, device-accessible
+  int sub_chunks = 0;  // chunks per sub-batch of lmc_encode_chunks (0 = whole job at once)
   // optional per-kernel timing (lmc_ctx_profile)
   bool profile = false;
   hipEvent_t pev[8] = {};
@@ -95,6 +96,13 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   for (int i = 0; i < 8; i++) if (c->pev[i]) (void)hipEventDestroy(c->pev[i]);
   if (c->status_h) (void)hipHostFree(c->status_h);
   delete c;
+  return LMC_OK;
+}
+
+int lmc_ctx_set_subbatch(lmc_ctx* c, int chunks_per_subbatch) {
+  if (!c || chunks_per_subbatch < 0) return LMC_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->sub_chunks = chunks_per_subbatch;
   return LMC_OK;
 }
 
@@ -289,52 +297,67 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   const u32 cap = lmc_group_cap_bytes((uint32_t)chunk_tokens);
   lmc_blob_header hl;
   lmc_blob_layout((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D, &hl);
+  const long long PG = (long long)P * G;
 
-  QuantArgs qa;
-  memset(&qa, 0, sizeof qa);
-  qa.src = to_addr(src); qa.bins = bins;
-  qa.tok_begin = tok_begin; qa.tok_end = tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = nchunks;
-  qa.P = P; qa.C = C; qa.TQ = TQ; qa.nquads = (long long)nchunks * P * TQ;
-  qa.sym4 = c->sym4;
-  qa.scale_base = (u8*)blobs + hl.off_scales;  // off_scales does not depend on T
-  qa.scale_stride = (long long)blob_stride;
+  // Launch the four kernels for chunks [c0, c0 + nc); the workspace slice starts at chunk slot `w0`.
+  auto launch_range = [&](int c0, int nc, int w0) -> int {
+    const int tb = tok_begin + c0 * chunk_tokens;
+    u8* blobs_b = (u8*)blobs + (uint64_t)c0 * blob_stride;
+    QuantArgs qa;
+    memset(&qa, 0, sizeof qa);
+    qa.src = to_addr(src); qa.bins = bins;
+    qa.tok_begin = tb; qa.tok_end = tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = nc;
+    qa.P = P; qa.C = C; qa.TQ = TQ; qa.nquads = (long long)nc * P * TQ;
+    qa.sym4 = c->sym4 + (long long)w0 * P * TQ * C;
+    qa.scale_base = blobs_b + hl.off_scales;  // off_scales does not depend on T
+    qa.scale_stride = (long long)blob_stride;
+    int r;
+    if ((r = prof_mark(c, s))) return r;
+    if ((r = launch_quant<true>(qa, s))) return r;
+    if ((r = prof_mark(c, s))) return r;
+
+    EncodeArgs ea;
+    memset(&ea, 0, sizeof ea);
+    ea.sym4 = qa.sym4;
+    ea.tok_begin = tb; ea.tok_end = tok_end; ea.chunk_tokens = chunk_tokens; ea.nchunks = nc;
+    ea.P = P; ea.C = C; ea.G = G; ea.TQ = TQ;
+    ea.blobs = blobs_b; ea.blob_stride = (long long)blob_stride;
+    ea.scratch = c->scratch + (long long)w0 * PG * cap; ea.cap = cap;
+    ea.glen = c->glen + (long long)w0 * PG; ea.status = c->status_h;
+    const long long ngroups = (long long)nc * PG;
+    hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, ea);
+    HIP_TRY(hipGetLastError());
+    if ((r = prof_mark(c, s))) return r;
+
+    ScanArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.blobs = blobs_b; sa.blob_stride = (long long)blob_stride;
+    sa.glen = ea.glen; sa.goff = c->goff + (long long)w0 * PG; sa.sizes = sizes + c0; sa.bins = bins;
+    sa.tok_begin = tb; sa.tok_end = tok_end; sa.chunk_tokens = chunk_tokens;
+    sa.L = L; sa.H = H; sa.D = D; sa.P = P; sa.C = C; sa.G = G; sa.dtype = src->dtype;
+    hipLaunchKernelGGL(k_scan_finalize, dim3((unsigned)nc), dim3(1024), 0, s, sa);
+    HIP_TRY(hipGetLastError());
+    if ((r = prof_mark(c, s))) return r;
+
+    PackArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.blobs = blobs_b; pa.blob_stride = (long long)blob_stride;
+    pa.scratch = ea.scratch; pa.cap = cap; pa.glen = ea.glen; pa.goff = sa.goff;
+    pa.tok_begin = tb; pa.tok_end = tok_end; pa.chunk_tokens = chunk_tokens;
+    pa.P = P; pa.C = C; pa.G = G; pa.ngroups_total = ngroups;
+    hipLaunchKernelGGL(k_pack_streams, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, pa);
+    HIP_TRY(hipGetLastError());
+    if ((r = prof_mark(c, s))) return r;
+    return LMC_OK;
+  };
+
   c->pn = 0;
-  if ((rc = prof_mark(c, s))) return rc;
-  rc = launch_quant<true>(qa, s);
-  if (rc) return rc;
-  if ((rc = prof_mark(c, s))) return rc;
-
-  EncodeArgs ea;
-  memset(&ea, 0, sizeof ea);
-  ea.sym4 = c->sym4;
-  ea.tok_begin = tok_begin; ea.tok_end = tok_end; ea.chunk_tokens = chunk_tokens; ea.nchunks = nchunks;
-  ea.P = P; ea.C = C; ea.G = G; ea.TQ = TQ;
-  ea.blobs = (u8*)blobs; ea.blob_stride = (long long)blob_stride;
-  ea.scratch = c->scratch; ea.cap = cap; ea.glen = c->glen; ea.status = c->status_h;
-  const long long ngroups = (long long)nchunks * P * G;
-  hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, ea);
-  HIP_TRY(hipGetLastError());
-  if ((rc = prof_mark(c, s))) return rc;
-
-  ScanArgs sa;
-  memset(&sa, 0, sizeof sa);
-  sa.blobs = (u8*)blobs; sa.blob_stride = (long long)blob_stride;
-  sa.glen = c->glen; sa.goff = c->goff; sa.sizes = sizes; sa.bins = bins;
-  sa.tok_begin = tok_begin; sa.tok_end = tok_end; sa.chunk_tokens = chunk_tokens;
-  sa.L = L; sa.H = H; sa.D = D; sa.P = P; sa.C = C; sa.G = G; sa.dtype = src->dtype;
-  hipLaunchKernelGGL(k_scan_finalize, dim3((unsigned)nchunks), dim3(1024), 0, s, sa);
-  HIP_TRY(hipGetLastError());
-  if ((rc = prof_mark(c, s))) return rc;
-
-  PackArgs pa;
-  memset(&pa, 0, sizeof pa);
-  pa.blobs = (u8*)blobs; pa.blob_stride = (long long)blob_stride;
-  pa.scratch = c->scratch; pa.cap = cap; pa.glen = c->glen; pa.goff = c->goff;
-  pa.tok_begin = tok_begin; pa.tok_end = tok_end; pa.chunk_tokens = chunk_tokens;
-  pa.P = P; pa.C = C; pa.G = G; pa.ngroups_total = ngroups;
-  hipLaunchKernelGGL(k_pack_streams, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, pa);
-  HIP_TRY(hipGetLastError());
-  if ((rc = prof_mark(c, s))) return rc;
+  const int per = (c->sub_chunks > 0 && !c->profile) ? c->sub_chunks : nchunks;
+  for (int c0 = 0; c0 < nchunks; c0 += per) {
+    // sub-batches reuse workspace slot 0: the symbol / scratch round trip then stays in L2 + Infinity Cache
+    rc = launch_range(c0, nchunks - c0 < per ? nchunks - c0 : per, per < nchunks ? 0 : c0);
+    if (rc) return rc;
+  }
 
   HIP_TRY(hipEventRecord(c->ws_free, s));
   c->ws_used = true;
@@ -364,10 +387,15 @@ int lmc_decode_chunks(lmc_ctx* c, const void* blobs, uint64_t blob_stride, int32
   std::lock_guard<std::mutex> lk(c->mu);
   c->pn = 0;
   if ((rc = prof_mark(c, (hipStream_t)stream))) return rc;
-  if (dst->dtype == LMC_DTYPE_BF16)
-    hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16>), grid, dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  const bool paged = dst->slot_mapping != nullptr;
+  hipStream_t hs = (hipStream_t)stream;
+  if (dst->dtype == LMC_DTYPE_BF16) {
+    if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, true>), grid, dim3(256), 0, hs, a);
+    else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, false>), grid, dim3(256), 0, hs, a);
+  } else {
+    if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, true>), grid, dim3(256), 0, hs, a);
+    else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, false>), grid, dim3(256), 0, hs, a);
+  }
   HIP_TRY(hipGetLastError());
   if ((rc = prof_mark(c, (hipStream_t)stream))) return rc;
   return LMC_OK;
@@ -383,7 +411,7 @@ int lmc_decode_symbols(lmc_ctx* c, const void* blob, int32_t L, int32_t H, int32
   a.sym_out = sym_out;
   HIP_TRY(hipSetDevice(c->device));
   const long long n = (long long)a.P * a.G;
-  hipLaunchKernelGGL((k_decode<true, LMC_DTYPE_BF16>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_decode<true, LMC_DTYPE_BF16, false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return LMC_OK;
 }

@@ -64,6 +64,22 @@ __device__ __forceinline__ BlobOff lmc_blob_off(u32 P, u32 T, u32 C, u32 G) {
   return o;
 }
 
+// Pointers that come out of a device pointer table are "generic" to the compiler and would be
+// accessed with flat_* instructions (which tick both vmcnt and lgkmcnt); KV and blobs always live
+// in global memory, so say so.
+#define LMC_GLOBAL __attribute__((address_space(1)))
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_global_u4(const u16* p) {
+  const u32x4_t v = *reinterpret_cast<const LMC_GLOBAL u32x4_t*>((const LMC_GLOBAL u16*)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_global_u4(u16* p, uint4 v) {
+  u32x4_t t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  *reinterpret_cast<LMC_GLOBAL u32x4_t*>((LMC_GLOBAL u16*)p) = t;
+}
+__device__ __forceinline__ void st_global_u16(u16* p, u16 v) { *((LMC_GLOBAL u16*)p) = v; }
+
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 // max of two packed u16 pairs (v_pk_max_u16)
