@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   u32 filled = 512;     // words [0, filled) are in the ring
   u32 consumed = 0;     // wave-uniform
   u32 trigger = 128;    // next ring event when consumed reaches this (= filled - 384, then filled - 256)
-  bool pending = false;
+  u32 pending = 0;      // loads for [filled, filled + 256) are in flight
   wave_lds_fence();
 
   // pivots of the first search level live in registers
@@ -190,22 +190,23 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
         x = __umul24(f, x >> 16) + slot - lo;
         const bool need = active && (x < LMC_RANS_L);
         const u64 mask = __ballot(need);
-        const u32 cnt = (u32)__popcll(mask);
+        const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)__popcll(mask));
         // the encoder appended this token's words in ascending lane order; counted from the tail that is
         // descending, so rank r of cnt takes consumption index consumed + cnt - 1 - r
         if (need) x = (x << 16) | (u32)ring[(consumed + cnt - 1u - lane_rank(mask)) & (DEC_RING_WORDS - 1)];
-        consumed += cnt;
+        // the ring bookkeeping is wave-uniform: pin it to SGPRs so its tests are scalar branches
+        consumed = (u32)__builtin_amdgcn_readfirstlane((int)(consumed + cnt));
         if (consumed >= trigger) {
-          if (!pending) {
+          if (pending == 0u) {
             ring_issue(filled);
-            pending = true;
-            trigger = filled - 256u;
+            pending = 1u;
+            trigger = (u32)__builtin_amdgcn_readfirstlane((int)(filled - 256u));
           } else {
             wave_lds_fence();  // every lane's reads of the older half are done
             ring_commit(filled);
-            filled += 256;
-            pending = false;
-            trigger = filled - 384u;
+            filled = (u32)__builtin_amdgcn_readfirstlane((int)(filled + 256u));
+            pending = 0u;
+            trigger = (u32)__builtin_amdgcn_readfirstlane((int)(filled - 384u));
             wave_lds_fence();
           }
         }
