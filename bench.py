@@ -90,7 +90,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the cpu_baseline sample (0 = auto)")
-    ap.add_argument("--subbatch", type=int, default=0, help="chunks per encode sub-batch (0 = whole context at once)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,7 +113,6 @@ def main():
     blobs = torch.empty(nchunks * stride, dtype=torch.uint8, device=dev)
     sizes = torch.zeros(nchunks, dtype=torch.int32, device=dev)
     ctx.reserve(L, H, D, CHUNK, nchunks)
-    ctx.set_subbatch(args.subbatch)
     raw_bytes = L * 2 * CTX * H * D * 2
 
     stream = torch.cuda.Stream(device=dev)

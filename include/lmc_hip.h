@@ -102,11 +102,6 @@ int lmc_ctx_reserve(lmc_ctx* ctx, int L, int H, int D, int chunk_tokens, int max
  * event / stream sync by the caller).  `clear` resets it. */
 int lmc_device_status(lmc_ctx* ctx, int clear);
 
-/* Cut lmc_encode_chunks jobs into sub-batches of this many chunks that reuse one workspace slice, so the
- * quantise -> coder -> pack round trip through the symbol / scratch buffers stays cache resident
- * (4 MiB L2 per XCD + 256 MiB Infinity Cache).  0 (default) = whole job in one set of launches. */
-int lmc_ctx_set_subbatch(lmc_ctx* ctx, int chunks_per_subbatch);
-
 /* Per-kernel timing of the NEXT lmc_encode_chunks / lmc_decode_chunks calls:
  * when enabled the call brackets each of its kernels with hipEvents on the
  * caller's stream.  lmc_ctx_profile_read (after the caller has synchronised

@@ -37,7 +37,6 @@ struct lmc_ctx {
   hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
   bool ws_used = false;
   u32* status_h = nullptr;  // pinned, device-accessible
-  int sub_chunks = 0;  // chunks per sub-batch of lmc_encode_chunks (0 = whole job at once)
   // optional per-kernel timing (lmc_ctx_profile)
   bool profile = false;
   hipEvent_t pev[8] = {};
@@ -96,13 +95,6 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   for (int i = 0; i < 8; i++) if (c->pev[i]) (void)hipEventDestroy(c->pev[i]);
   if (c->status_h) (void)hipHostFree(c->status_h);
   delete c;
-  return LMC_OK;
-}
-
-int lmc_ctx_set_subbatch(lmc_ctx* c, int chunks_per_subbatch) {
-  if (!c || chunks_per_subbatch < 0) return LMC_ERR_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
-  c->sub_chunks = chunks_per_subbatch;
   return LMC_OK;
 }
 
@@ -351,13 +343,11 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     return LMC_OK;
   };
 
+  // One set of launches for the whole job.  (Measured alternatives that lost: cutting the job into
+  // cache-resident sub-batches, and running quantise on a second stream ahead of the coder -- DESIGN.md 6.)
   c->pn = 0;
-  const int per = (c->sub_chunks > 0 && !c->profile) ? c->sub_chunks : nchunks;
-  for (int c0 = 0; c0 < nchunks; c0 += per) {
-    // sub-batches reuse workspace slot 0: the symbol / scratch round trip then stays in L2 + Infinity Cache
-    rc = launch_range(c0, nchunks - c0 < per ? nchunks - c0 : per, per < nchunks ? 0 : c0);
-    if (rc) return rc;
-  }
+  rc = launch_range(0, nchunks, 0);
+  if (rc) return rc;
 
   HIP_TRY(hipEventRecord(c->ws_free, s));
   c->ws_used = true;
