@@ -252,6 +252,32 @@ def test_paged_gather_encode_and_scatter_decode(nat, ctx, oracle, layout):
         assert (flat[:, ~touched] == 0).all()  # nothing written outside slot_mapping
 
 
+@pytest.mark.parametrize("case", ["T2048", "T768_fp16", "tiny_values"])
+def test_long_chunks_and_denormal_scales(nat, ctx, oracle, case):
+    """Chunks longer than the decoder's 512-token scale window and 512-word ring (many refills);
+    chunk_size=768 as in the reference's benchmark (tests/benchmarks/test_benchmark.py:46);
+    KV so small that scales and outputs are bf16 denormals (hardware bf16 conversion path)."""
+    if case == "T2048":
+        L, T, H, D, dt, scale = 1, 2048, 2, 64, torch.bfloat16, 1.0
+    elif case == "T768_fp16":
+        L, T, H, D, dt, scale = 2, 768, 8, 128, torch.float16, 1.0
+    else:
+        L, T, H, D, dt, scale = 2, 40, 2, 128, torch.bfloat16, 1e-39
+    g = torch.Generator().manual_seed(77)
+    kv = (torch.randn(L, 2, T, H, D, generator=g) * scale).to(dt)
+    bins = default_bins(L)
+    blobs, blob_dev, stride = encode(nat, ctx, nat.KVLayout.from_chunk(kv.to(DEV), "vllm"), 0, T, T, bins)
+    b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
+    ref = oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+    assert blobs[0] == ref
+    for odt, ocode in ((torch.bfloat16, oracle.BF16), (torch.float16, oracle.FP16)):
+        out = torch.zeros(L, 2, T, H, D, dtype=odt, device=DEV)
+        ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+        torch.cuda.synchronize()
+        ctx.raise_on_status("decode")
+        assert np.array_equal(bits_np(out).reshape(L, 2, T, H * D), oracle.decode_blob(ref, ocode))
+
+
 def test_corrupt_blob_is_flagged(nat, ctx):
     L, T, H, D = 1, 32, 1, 128
     kv = make_kv(L, T, H, D, torch.bfloat16, "randn", 1).to(DEV)

@@ -20,14 +20,18 @@ def main(path):
         print(f"| `{name[:110]}` | {n} | {tot / 1e6:.3f} | {avg / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | "
               f"{100.0 * tot / total:.1f} |")
     try:
-        pmc = db.execute("select name, counter_name, avg(value) from counters_collection "
-                         "group by name, counter_name order by name").fetchall()
+        pmc = db.execute("select kernel_name, counter_name, avg(value), avg(duration), count(*) "
+                         "from counters_collection group by kernel_name, counter_name "
+                         "order by kernel_name, counter_name").fetchall()
     except sqlite3.Error:
         pmc = []
     if pmc:
-        print("\n| kernel | counter | avg per dispatch |\n|---|---|---|")
-        for name, cn, v in pmc:
-            print(f"| `{name[:80]}` | {cn} | {v:.4g} |")
+        print("\n## PMC counters (average per dispatch; FETCH_SIZE / WRITE_SIZE in KiB)\n")
+        print("| kernel | counter | avg per dispatch | avg dispatch us | dispatches |\n|---|---|---|---|---|")
+        for name, cn, v, dur, n in pmc:
+            if name.startswith("void at::") or name.startswith("__amd"):
+                continue
+            print(f"| `{name[:60]}` | {cn} | {v:.5g} | {dur / 1e3:.1f} | {n} |")
 
 
 if __name__ == "__main__":
