@@ -70,10 +70,12 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   const int p = pg / a.G, g = pg - p * a.G;
   const u8* blob = a.blobs + (long long)chunk * a.blob_stride;
   const u32* hd = reinterpret_cast<const u32*>(blob);
-  const u32 T = __builtin_amdgcn_readfirstlane(hd[4]);
-  const u32 src_dtype = __builtin_amdgcn_readfirstlane(hd[2]);
+  // header words are the same for every lane: read them through SGPRs so all control flow below is scalar
+  auto hdw = [&](int i) { return (u32)__builtin_amdgcn_readfirstlane((int)hd[i]); };
+  const u32 T = hdw(4);
+  const u32 src_dtype = hdw(2);
   const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G);
-  if (hd[0] != LMC_BLOB_MAGIC || hd[7] != (u32)a.C || hd[8] != (u32)a.P || hd[15] != bo.streams) {
+  if (hdw(0) != LMC_BLOB_MAGIC || hdw(7) != (u32)a.C || hdw(8) != (u32)a.P || hdw(15) != bo.streams) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_HEADER);
     return;
   }
@@ -114,10 +116,10 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
 
   // ---- stream ----------------------------------------------------------------
   const u32* gend = reinterpret_cast<const u32*>(blob + bo.gend);
-  const u32 end = __builtin_amdgcn_readfirstlane(gend[pg]);
-  const u32 start = pg == 0 ? 0u : ((__builtin_amdgcn_readfirstlane(gend[pg - 1]) + 15u) & ~15u);
+  const u32 end = (u32)__builtin_amdgcn_readfirstlane((int)gend[pg]);
+  const u32 start = pg == 0 ? 0u : (((u32)__builtin_amdgcn_readfirstlane((int)gend[pg - 1]) + 15u) & ~15u);
   const u16* words = reinterpret_cast<const u16*>(blob + bo.streams + start);
-  if (end < start + 256u || bo.streams + end > hd[17]) {
+  if (end < start + 256u || bo.streams + end > hdw(17)) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_STREAM);
     return;
   }
@@ -167,9 +169,52 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   }
   const int tdst0 = a.dst_tok0 + chunk * a.chunk_tokens;
 
+  // One token: search, state update, word pop; returns the symbol.
+  auto decode_token = [&]() -> u32 {
+    u32 slot = x & 0xffffu;
+    asm volatile("" : "+v"(slot));  // keep `slot` a plain VGPR: SDWA compares would cost a wait state each
+    // level 1 on register pivots, levels 2-4 on LDS probes; then the symbol's own two CDF entries
+    u32 s = (p8 <= slot ? 8u : 0u) + (p16 <= slot ? 8u : 0u) + (p24 <= slot ? 8u : 0u);
+#pragma unroll
+    for (int step = 4; step >= 1; step >>= 1) {
+      const u32 v = cdfT[(s + step) * 64 + lane];
+      s = v <= slot ? s + step : s;
+    }
+    const u32 lo = cdfT[s * 64 + lane], hi = cdfT[s * 64 + 64 + lane];  // entry 32 is 65536 stored as 0
+    const u32 f = (hi - lo) & 0xffffu;
+    x = __umul24(f, x >> 16) + slot - lo;
+    const bool need = active && (x < LMC_RANS_L);
+    const u64 mask = __ballot(need);
+    const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)__popcll(mask));
+    // the encoder appended this token's words in ascending lane order; counted from the tail that is
+    // descending, so rank r of cnt takes consumption index consumed + cnt - 1 - r
+    if (need) x = (x << 16) | (u32)ring[(consumed + cnt - 1u - lane_rank(mask)) & (DEC_RING_WORDS - 1)];
+    // the ring bookkeeping is wave-uniform: pin it to SGPRs so its tests are scalar branches
+    consumed = (u32)__builtin_amdgcn_readfirstlane((int)(consumed + cnt));
+    if (consumed >= trigger) {
+      if (pending == 0u) {
+        ring_issue(filled);
+        pending = 1u;
+        trigger = (u32)__builtin_amdgcn_readfirstlane((int)(filled - 256u));
+      } else {
+        wave_lds_fence();  // every lane's reads of the older half are done
+        ring_commit(filled);
+        filled = (u32)__builtin_amdgcn_readfirstlane((int)(filled + 256u));
+        pending = 0u;
+        trigger = (u32)__builtin_amdgcn_readfirstlane((int)(filled - 384u));
+        wave_lds_fence();
+      }
+    }
+    return s;
+  };
+
+  const u32 nskip = SYMOUT ? 0u : (tdst0 < 0 ? min(T, (u32)(-tdst0)) : 0u);  // tokens that land below dst token 0
   auto run = [&](auto src_tag) {
     constexpr bool SRC_BF16 = decltype(src_tag)::value;
-    for (u32 t0 = 0; t0 < T; t0 += DEC_SCALE_TOKENS) {
+    for (u32 t = 0; t < nskip; t++) (void)decode_token();  // retrieve()'s first-chunk trim: decode, do not store
+    long long rowb = (long long)(tdst0 + (int)nskip) * a.dst.stride_token * 2;  // !PAGED: byte offset of the row
+    const long long row_step = a.dst.stride_token * 2;
+    for (u32 t0 = nskip; t0 < T; t0 += DEC_SCALE_TOKENS) {
       const u32 t1 = min(T, t0 + (u32)DEC_SCALE_TOKENS);
       if (!SYMOUT) {
         wave_lds_fence();
@@ -177,53 +222,21 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
         wave_lds_fence();
       }
       for (u32 t = t0; t < t1; t++) {
-        const u32 slot = x & 0xffffu;
-        // level 1 on register pivots, levels 2-4 on LDS probes; then the symbol's own two CDF entries
-        u32 s = (p8 <= slot ? 8u : 0u) + (p16 <= slot ? 8u : 0u) + (p24 <= slot ? 8u : 0u);
-#pragma unroll
-        for (int step = 4; step >= 1; step >>= 1) {
-          const u32 v = cdfT[(s + step) * 64 + lane];
-          s = v <= slot ? s + step : s;
-        }
-        const u32 lo = cdfT[s * 64 + lane], hi = cdfT[s * 64 + 64 + lane];  // entry 32 is 65536 stored as 0
-        const u32 f = (hi - lo) & 0xffffu;
-        x = __umul24(f, x >> 16) + slot - lo;
-        const bool need = active && (x < LMC_RANS_L);
-        const u64 mask = __ballot(need);
-        const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)__popcll(mask));
-        // the encoder appended this token's words in ascending lane order; counted from the tail that is
-        // descending, so rank r of cnt takes consumption index consumed + cnt - 1 - r
-        if (need) x = (x << 16) | (u32)ring[(consumed + cnt - 1u - lane_rank(mask)) & (DEC_RING_WORDS - 1)];
-        // the ring bookkeeping is wave-uniform: pin it to SGPRs so its tests are scalar branches
-        consumed = (u32)__builtin_amdgcn_readfirstlane((int)(consumed + cnt));
-        if (consumed >= trigger) {
-          if (pending == 0u) {
-            ring_issue(filled);
-            pending = 1u;
-            trigger = (u32)__builtin_amdgcn_readfirstlane((int)(filled - 256u));
-          } else {
-            wave_lds_fence();  // every lane's reads of the older half are done
-            ring_commit(filled);
-            filled = (u32)__builtin_amdgcn_readfirstlane((int)(filled + 256u));
-            pending = 0u;
-            trigger = (u32)__builtin_amdgcn_readfirstlane((int)(filled - 384u));
-            wave_lds_fence();
-          }
-        }
+        const u32 s = decode_token();
         if (SYMOUT) {
           if (active) *((LMC_GLOBAL int8_t*)(ubase + (u64)t * a.C) + lane_off) = (int8_t)s;
         } else {
-          const int td = tdst0 + (int)t;
-          if (td >= 0 && active) {
+          if (active) {
             const u32 sb = scs[t - t0];
             const float scale = SRC_BF16 ? __uint_as_float(sb << 16) : (float)__builtin_bit_cast(_Float16, (unsigned short)sb);
             const float val = lut[s] * scale;
             u16 bits;
             if (DT_OUT == LMC_DTYPE_BF16) bits = __builtin_bit_cast(unsigned short, (__bf16)val);  // v_cvt_pk_bf16_f32, RNE
             else bits = (u16)f2fp16(val);
-            const long long row = PAGED ? lmc_tok_off(a.dst, td) : (long long)td * a.dst.stride_token;
-            *(LMC_GLOBAL u16*)((LMC_GLOBAL u8*)(ubase + (u64)(row * 2)) + lane_off) = bits;
+            const long long row = PAGED ? lmc_tok_off(a.dst, tdst0 + (int)t) * 2 : rowb;
+            *(LMC_GLOBAL u16*)((LMC_GLOBAL u8*)(ubase + (u64)row) + lane_off) = bits;
           }
+          rowb += row_step;
         }
       }
     }

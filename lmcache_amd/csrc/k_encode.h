@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
       for (int j = 0; j < 8; j++) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const u32 s = (w[j] >> (8 * k)) & 0xffu;
-          atomicAdd(&hist[(s >> 1) * 64 + lane], 1u << ((s & 1u) * 16));  // ds_add_u32, bank = lane
+          const u32 pair = __builtin_amdgcn_ubfe(w[j], 8 * k + 1, 7), odd = __builtin_amdgcn_ubfe(w[j], 8 * k, 1);
+          atomicAdd(&hist[pair * 64 + lane], __umul24(odd, 65535u) + 1u);  // ds_add_u32, bank = lane
         }
       }
 #pragma unroll
@@ -147,11 +147,13 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   u32 wcur = 0;  // wave-uniform word cursor
 
   // one token: renormalise (append this step's words in ascending lane order), then encode
+  LMC_GLOBAL u8* const outb = (LMC_GLOBAL u8*)out;  // uniform base; per-lane 32-bit byte offsets
   auto code_token = [&](u32 st, u32 f) {
-    const bool emit = x >= (f << 16);
+    const u32 xh = x >> 16;
+    const bool emit = xh >= f;  // <=> x >= f << 16
     const u64 mask = __ballot(emit);
-    if (emit) out[wcur + lane_rank(mask)] = (u16)x;
-    x = emit ? x >> 16 : x;
+    if (emit) *(LMC_GLOBAL u16*)(outb + ((wcur + lane_rank(mask)) << 1)) = (u16)x;
+    x = emit ? xh : x;
     wcur += (u32)__popcll(mask);
     u32 q, r;
     divmod_est(x, f, q, r);
