@@ -197,41 +197,53 @@ def main():
                         "step from rocprofv3 FETCH_SIZE/WRITE_SIZE (profiles/), FETCH_SIZE doubled for the 16-B/lane "
                         "streams per MI355X_MICROARCH.md"}
 
-    # offload leg: blobs -> pinned host on a side stream, pipelined with the next step's kernels
-    offload = None
+    # store leg as the product runs it (LMCLocalBackend, local_serde="cachegen"): fused encode on the compute
+    # stream, blob sizes read back through a pinned word, exact-size hipMemcpyAsync of every blob to pinned host
+    # DRAM on the side stream.  PCIe-inclusive, so never `value`.
+    from lmcache_amd.storage_backend.serde.cachegen_device import PinnedArena, get_codec
+    offload = retrieve = None
     try:
-        pinned = native.PinnedBuffer(int(blob_bytes) + 4096)
-        copy_stream = torch.cuda.Stream(device=dev)
-        offs = np.concatenate([[0], np.cumsum(sz)])[:-1]
-        done = torch.cuda.Event()
+        codec = get_codec(local_rank)
+        with torch.cuda.stream(stream):
+            arena = PinnedArena(slab_bytes=int(blob_bytes) + (4 << 20))  # the backend's pinned slab, allocated once
 
-        def offload_step():
-            step()
-            done.record(stream)
-            copy_stream.wait_event(done)
-            for i in range(nchunks):
-                native.memcpy_async(pinned.ptr + int(offs[i]), blobs.data_ptr() + i * stride, int(sz[i]), "d2h",
-                                    copy_stream.cuda_stream)
-            # next step may overwrite the arena only after the copies have read it
-            e2 = torch.cuda.Event()
-            e2.record(copy_stream)
-            stream.wait_event(e2)
+            def store_once():
+                arena.reset()
+                job = codec.encode(layout, 0, CTX, CHUNK, bins)
+                sizes_h = codec.sizes_of(job)
+                hblobs, done = codec.offload(job, sizes_h, arena)
+                done.synchronize()
+                return hblobs
 
-        offload_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        nrep = 5
-        for _ in range(nrep):
-            offload_step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / nrep
-        offload = {"encode_plus_offload_GBps_raw_kv": round(raw_bytes / dt / 1e9, 1),
-                   "pcie_GBps_blob": round(blob_bytes / dt / 1e9, 1), "ms_per_step": round(dt * 1e3, 3),
-                   "blob_bytes": blob_bytes, "compression": round(raw_bytes / blob_bytes, 3),
-                   "note": "PCIe-inclusive; not `value`"}
-        pinned.free()
-    except Exception as e:  # the offload leg is informational
-        offload = {"error": repr(e)}
+            hblobs = store_once()  # warm: first touch of the pinned slab
+            t0 = time.perf_counter()
+            for _ in range(3):
+                hblobs = store_once()
+            dt = (time.perf_counter() - t0) / 3
+            offload = {"encode_plus_offload_GBps_raw_kv": round(raw_bytes / dt / 1e9, 1),
+                       "pcie_GBps_blob": round(blob_bytes / dt / 1e9, 1), "ms_per_context": round(dt * 1e3, 3),
+                       "blob_bytes": blob_bytes, "compression": round(raw_bytes / blob_bytes, 3),
+                       "note": "PCIe-inclusive (pinned slab pre-allocated, as in a running backend); not `value`"}
+            # warm-prefix retrieve: pinned host -> HBM on the side stream, decode straight into per-layer tensors,
+            # H2D of batch b+1 overlapping the decode of batch b
+            out_r = tuple((torch.empty_like(k), torch.empty_like(v)) for k, v in kv)
+            out_rl = native.KVLayout.from_kv_tuple(out_r, "vllm")
+            codec.decode(hblobs, out_rl, 0, CHUNK)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            codec.decode(hblobs, out_rl, 0, CHUNK)
+            torch.cuda.current_stream().synchronize()
+            dt = time.perf_counter() - t0
+            ctx.raise_on_status("bench retrieve")
+            retrieve = {"host_to_decoded_kv_GBps_raw": round(raw_bytes / dt / 1e9, 1), "ms_per_context": round(dt * 1e3, 3),
+                        "pcie_GBps_blob": round(blob_bytes / dt / 1e9, 1),
+                        "raw_h2d_would_take_ms": round(raw_bytes / (blob_bytes / dt) * 1e3, 1),
+                        "note": "warm 16k prefix: encoded chunks in pinned host DRAM -> decoded KV in HBM (PCIe-inclusive)"}
+            del out_r
+            arena.close()
+    except Exception as e:  # these legs are informational
+        offload = offload or {"error": repr(e)}
+        retrieve = retrieve or {"error": repr(e)}
 
     # decode leg (retrieve): blobs in HBM -> decoded KV written straight into per-layer tensors
     out = tuple((torch.empty_like(k), torch.empty_like(v)) for k, v in kv)
@@ -262,7 +274,7 @@ def main():
                                   "(BASELINE configs[1])",
                       "layers": L, "kv_heads": H, "head_dim": D, "context_tokens": CTX, "chunk_tokens": CHUNK,
                       "chunks": nchunks, "raw_kv_bytes": raw_bytes, "sharding": f"{world} x independent contexts"},
-           "roofline": roofline, "offload": offload, "decode": decode, "roundtrip_within_bound": err_ok}
+           "roofline": roofline, "offload": offload, "retrieve": retrieve, "decode": decode, "roundtrip_within_bound": err_ok}
     if not args.no_cpu_baseline:
         n = args.cpu_chunks or 32
         res["cpu_baseline"] = cpu_baseline(n)

@@ -105,6 +105,7 @@ class CacheGenDeviceCodec:
         self._dec_free: Optional[torch.cuda.Event] = None    # previous decode kernel done
         self._stage: Optional[native.PinnedBuffer] = None    # staging for pageable `bytes` inputs
         self._pending: Optional[EncodeJob] = None            # last job whose sizes were not read yet
+        self.decode_batch_chunks = 8                         # chunks per H2D/decode pipeline stage
 
     # ---- encode ------------------------------------------------------------------
     def encode(self, src: native.KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int,
@@ -166,8 +167,9 @@ class CacheGenDeviceCodec:
         return self._dec_arena
 
     def decode(self, host_blobs: Sequence, dst: native.KVLayout, dst_tok0: int, chunk_tokens: int) -> None:
-        """H2D every blob on the side stream, then ONE fused decode launch on the current stream that writes
-        straight into `dst`.  host_blobs: HostBlob (pinned) or bytes-like (staged through pinned memory)."""
+        """H2D the blobs on the side stream and decode them on the current stream straight into `dst`,
+        pipelined in batches of `decode_batch_chunks` (copy of batch b+1 overlaps the decode of batch b).
+        host_blobs: HostBlob (pinned) or bytes-like (staged through pinned memory)."""
         n = len(host_blobs)
         if n == 0:
             return
@@ -189,22 +191,30 @@ class CacheGenDeviceCodec:
                         self._stage = native.PinnedBuffer(need)
                     else:
                         self.copy_stream.synchronize()  # staging buffer is reused: earlier H2D must be done
-                for i, hb in enumerate(host_blobs):
-                    if isinstance(hb, HostBlob):
-                        src_ptr = hb.ptr
-                    else:
-                        data = hb if isinstance(hb, bytes) else bytes(hb)  # never mutates the caller's buffer
-                        ctypes.memmove(self._stage.ptr + staged_off, data, len(data))
-                        src_ptr = self._stage.ptr + staged_off
-                        staged_off += native.r16(len(data))
-                    native.memcpy_async(arena.data_ptr() + i * stride, src_ptr, sizes[i], "h2d", cs)
-                ready = torch.cuda.Event()
-                ready.record(self.copy_stream)
-                cur.wait_event(ready)
-                self.ctx.decode_chunks(arena.data_ptr(), stride, n, dst, dst_tok0, chunk_tokens, stream=cur.cuda_stream)
-                free = torch.cuda.Event()
-                free.record(cur)
-                self._dec_free = free
+                # H2D and decode are pipelined in batches: the copy stream runs ahead, the compute stream
+                # decodes batch b as soon as its blobs have landed (one event per batch)
+                B = self.decode_batch_chunks
+                last = None
+                for b0 in range(0, n, B):
+                    b1 = min(n, b0 + B)
+                    for i in range(b0, b1):
+                        hb = host_blobs[i]
+                        if isinstance(hb, HostBlob):
+                            src_ptr = hb.ptr
+                        else:
+                            data = hb if isinstance(hb, bytes) else bytes(hb)  # never mutates the caller's buffer
+                            ctypes.memmove(self._stage.ptr + staged_off, data, len(data))
+                            src_ptr = self._stage.ptr + staged_off
+                            staged_off += native.r16(len(data))
+                        native.memcpy_async(arena.data_ptr() + i * stride, src_ptr, sizes[i], "h2d", cs)
+                    ready = torch.cuda.Event()
+                    ready.record(self.copy_stream)
+                    cur.wait_event(ready)
+                    self.ctx.decode_chunks(arena.data_ptr() + b0 * stride, stride, b1 - b0, dst,
+                                           dst_tok0 + b0 * chunk_tokens, chunk_tokens, stream=cur.cuda_stream)
+                    last = torch.cuda.Event()
+                    last.record(cur)
+                self._dec_free = last
 
     def close(self):
         with self._lock:
