@@ -14,6 +14,7 @@
 #include "k_copy.h"
 #include "k_decode.h"
 #include "k_encode.h"
+#include "k_fused.h"
 #include "k_quantize.h"
 
 static thread_local int g_last_hip = 0;
@@ -37,6 +38,9 @@ struct lmc_ctx {
   hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
   bool ws_used = false;
   u32* status_h = nullptr;  // pinned, device-accessible
+  // k_fused_encode (C = 512 / 1024, chunks <= 256 tokens) moves half the HBM bytes of the general path but is
+  // ~4 % slower standalone (1 workgroup per CU, no overlap of its memory and coder phases): opt-in.
+  bool fused = false;
   // optional per-kernel timing (lmc_ctx_profile)
   bool profile = false;
   hipEvent_t pev[8] = {};
@@ -95,6 +99,13 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   for (int i = 0; i < 8; i++) if (c->pev[i]) (void)hipEventDestroy(c->pev[i]);
   if (c->status_h) (void)hipHostFree(c->status_h);
   delete c;
+  return LMC_OK;
+}
+
+int lmc_ctx_set_fused(lmc_ctx* c, int enable) {
+  if (!c) return LMC_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->fused = enable != 0;
   return LMC_OK;
 }
 
@@ -304,9 +315,32 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     qa.scale_base = blobs_b + hl.off_scales;  // off_scales does not depend on T
     qa.scale_stride = (long long)blob_stride;
     int r;
+    const bool use_fused = c->fused && (C == 512 || C == 1024) && chunk_tokens <= 256;
     if ((r = prof_mark(c, s))) return r;
-    if ((r = launch_quant<true>(qa, s))) return r;
-    if ((r = prof_mark(c, s))) return r;
+    if (use_fused) {
+      FusedArgs fa;
+      memset(&fa, 0, sizeof fa);
+      fa.src = qa.src; fa.bins = bins;
+      fa.tok_begin = tb; fa.tok_end = tok_end; fa.chunk_tokens = chunk_tokens; fa.nchunks = nc;
+      fa.P = P; fa.C = C; fa.G = G;
+      fa.blobs = blobs_b; fa.blob_stride = (long long)blob_stride;
+      fa.scratch = c->scratch + (long long)w0 * PG * cap; fa.cap = cap;
+      fa.glen = c->glen + (long long)w0 * PG; fa.status = c->status_h;
+      const dim3 grid((unsigned)(nc * P));
+      const bool bf = src->dtype == LMC_DTYPE_BF16;
+      if (C == 1024) {
+        if (bf) hipLaunchKernelGGL((k_fused_encode<2, LMC_DTYPE_BF16>), grid, dim3(1024), 0, s, fa);
+        else hipLaunchKernelGGL((k_fused_encode<2, LMC_DTYPE_FP16>), grid, dim3(1024), 0, s, fa);
+      } else {
+        if (bf) hipLaunchKernelGGL((k_fused_encode<1, LMC_DTYPE_BF16>), grid, dim3(512), 0, s, fa);
+        else hipLaunchKernelGGL((k_fused_encode<1, LMC_DTYPE_FP16>), grid, dim3(512), 0, s, fa);
+      }
+      HIP_TRY(hipGetLastError());
+      if ((r = prof_mark(c, s))) return r;
+    } else {
+      if ((r = launch_quant<true>(qa, s))) return r;
+      if ((r = prof_mark(c, s))) return r;
+    }
 
     EncodeArgs ea;
     memset(&ea, 0, sizeof ea);
@@ -317,8 +351,10 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     ea.scratch = c->scratch + (long long)w0 * PG * cap; ea.cap = cap;
     ea.glen = c->glen + (long long)w0 * PG; ea.status = c->status_h;
     const long long ngroups = (long long)nc * PG;
-    hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, ea);
-    HIP_TRY(hipGetLastError());
+    if (!use_fused) {
+      hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, ea);
+      HIP_TRY(hipGetLastError());
+    }
     if ((r = prof_mark(c, s))) return r;
 
     ScanArgs sa;

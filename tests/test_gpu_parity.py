@@ -278,6 +278,37 @@ def test_long_chunks_and_denormal_scales(nat, ctx, oracle, case):
         assert np.array_equal(bits_np(out).reshape(L, 2, T, H * D), oracle.decode_blob(ref, ocode))
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 8, 128, torch.bfloat16), (3, 236, 8, 128, torch.float16),
+                                   (2, 100, 4, 128, torch.bfloat16), (1, 256, 4, 128, torch.float16),
+                                   (2, 5, 8, 128, torch.bfloat16), (1, 129, 16, 64, torch.bfloat16)])
+def test_fused_and_general_encoders_agree_with_oracle(nat, ctx, oracle, shape):
+    """k_fused_encode (C = 512 / 1024, T <= 256) and the general k_quantize + k_cdf_encode path must both
+    produce the oracle's bytes; multi-chunk with a ragged tail and edge rows included."""
+    L, T, H, D, dt = shape
+    g = torch.Generator().manual_seed(T * 7 + H)
+    Ttot = 2 * T + 37 if T >= 100 else T  # several chunks + short tail for the larger cases
+    kv = torch.randn(L, 2, Ttot, H, D, generator=g).to(dt)
+    kv[0, 0, 0] = 0                      # all-zero row -> "special" path
+    if Ttot > 3:
+        kv[0, 1, 2, 0, 0] = float("inf")
+    bins = default_bins(L)
+    lay = nat.KVLayout.from_chunk(kv.to(DEV), "vllm")
+    try:
+        ctx.set_fused(True)
+        fused, _, _ = encode(nat, ctx, lay, 0, Ttot, T, bins)
+        ctx.set_fused(False)
+        general, _, _ = encode(nat, ctx, lay, 0, Ttot, T, bins)
+    finally:
+        ctx.set_fused(False)
+    assert len(fused) == len(general)
+    for i, (a, b) in enumerate(zip(fused, general)):
+        t0, t1 = i * T, min(Ttot, (i + 1) * T)
+        bits, code = oracle.torch_to_bits(kv[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
+        ref = oracle.encode_blob(bits, code, H, D, np.array(bins, np.int32))
+        assert a == ref, f"fused chunk {i}"
+        assert b == ref, f"general chunk {i}"
+
+
 def test_corrupt_blob_is_flagged(nat, ctx):
     L, T, H, D = 1, 32, 1, 128
     kv = make_kv(L, T, H, D, torch.bfloat16, "randn", 1).to(DEV)
