@@ -169,7 +169,7 @@ def main():
     G = (C + 63) // 64
     # algorithmic bytes per step, SURVEY.md 8(d): B_enc = P*T*C*e + S + P*C*66 + P*C*4 + P*T*2 per chunk,
     # with OUR container: lengths are one u32 per 64-channel group (P*G*4) instead of per channel
-    static = native.blob_static_bytes(L, CHUNK, H, D)
+    static = native.blob_static_bytes(L, CHUNK, H, D, bins)
     S = blob_bytes - nchunks * static
     algo_bytes = raw_bytes + blob_bytes
 

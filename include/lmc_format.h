@@ -19,11 +19,18 @@
  *
  *   header   128 B          struct lmc_blob_header
  *   bins     u8  [P]        quantisation bins of each plane (32 or 16 ...)
+ *   rowpre   u16 [P+1]      rowpre[p] = sum over planes before p of R, R = bins - 2
  *   scales   u16 [P][T]     per-(plane,token) absmax, raw bits of the KV dtype
  *                           (= max_tensors_key ++ max_tensors_value)
- *   cdf      u16 [P][C][LP] 16-bit CDF per (plane, channel); LP = 33.
- *                           Same layout and values as the reference's `cdf`
- *                           tensor; entry LP-1 is 65536 stored as 0.
+ *   cdf      per plane p: u16 [C][R_p], the entries cdf[1 .. R_p] of each channel's
+ *                           16-bit CDF (plane p starts C * rowpre[p] entries in).
+ *                           The values are exactly those of the reference's `cdf`
+ *                           tensor [2L, C, 33]; the entries left out are implied by
+ *                           the quantiser's symbol range 0 .. bins-2:
+ *                             cdf[0] = 0,  cdf[i] = 65504 + i (mod 2^16) for i > R_p
+ *                           (n_i = T there, and RNE(T*65504/T) = 65504).  Storing
+ *                           30 / 14 entries instead of 33 shrinks a Llama-3-8B chunk
+ *                           blob from 11.1 MB to 9.0 MB (3.0x -> 3.7x).
  *   gend     u32 [P][G]     EXACT end offset (bytes, relative to the streams
  *                           section) of group stream (p,g); G = ceil(C/64).
  *                           Stream (p,g) starts at roundup16(gend[prev]) (0 for
@@ -52,7 +59,7 @@ extern "C" {
 #endif
 
 #define LMC_BLOB_MAGIC 0x31434D4Cu /* "LMC1" */
-#define LMC_BLOB_VERSION 1u
+#define LMC_BLOB_VERSION 2u
 #define LMC_HEADER_BYTES 128u
 
 #define LMC_DTYPE_BF16 0
@@ -85,13 +92,19 @@ typedef struct lmc_blob_header {
   uint32_t off_streams;
   uint32_t stream_bytes; /* padded size of the streams section */
   uint32_t total_bytes;  /* off_streams + stream_bytes */
-  uint32_t reserved[14];
+  uint32_t off_rowpre;
+  uint32_t cdf_rows;     /* rowpre[P] = sum of R over all planes */
+  uint32_t reserved[12];
 } lmc_blob_header;
 
 static inline uint32_t lmc_r16(uint32_t x) { return (x + 15u) & ~15u; }
 
-/* Static section offsets for a chunk geometry (everything but stream sizes). */
-static inline void lmc_blob_layout(uint32_t L, uint32_t T, uint32_t H, uint32_t D,
+/* CDF entries stored per channel of a plane quantised with `bins` bins. */
+static inline uint32_t lmc_cdf_row(uint32_t bins) { return bins - 2u; }
+
+/* Section offsets for a chunk geometry.  cdf_rows = sum over planes of lmc_cdf_row(bins[p]);
+ * pass 30 * P (all planes at 32 bins) for an upper bound. */
+static inline void lmc_blob_layout(uint32_t L, uint32_t T, uint32_t H, uint32_t D, uint32_t cdf_rows,
                                    lmc_blob_header* h) {
   uint32_t C = H * D, P = 2u * L, G = (C + LMC_LANES - 1u) / LMC_LANES;
   h->magic = LMC_BLOB_MAGIC;
@@ -99,10 +112,12 @@ static inline void lmc_blob_layout(uint32_t L, uint32_t T, uint32_t H, uint32_t 
   h->header_bytes = LMC_HEADER_BYTES;
   h->num_layers = L; h->ntokens = T; h->num_heads = H; h->head_size = D;
   h->nchannels = C; h->nplanes = P; h->ngroups = G; h->lp = LMC_LP;
+  h->cdf_rows = cdf_rows;
   h->off_bins = LMC_HEADER_BYTES;
-  h->off_scales = h->off_bins + lmc_r16(P);
+  h->off_rowpre = h->off_bins + lmc_r16(P);
+  h->off_scales = h->off_rowpre + lmc_r16(2u * (P + 1u));
   h->off_cdf = h->off_scales + lmc_r16(2u * P * T);
-  h->off_gend = h->off_cdf + lmc_r16(2u * P * C * LMC_LP);
+  h->off_gend = h->off_cdf + lmc_r16(2u * C * cdf_rows);
   h->off_streams = h->off_gend + lmc_r16(4u * P * G);
 }
 
@@ -113,10 +128,10 @@ static inline uint32_t lmc_group_cap_bytes(uint32_t T) {
   return lmc_r16(LMC_LANES * (T + 8u));
 }
 
-/* Worst-case blob size for a chunk geometry. */
+/* Worst-case blob size for a chunk geometry (every plane at 32 bins). */
 static inline uint64_t lmc_blob_bound(uint32_t L, uint32_t T, uint32_t H, uint32_t D) {
   lmc_blob_header h;
-  lmc_blob_layout(L, T, H, D, &h);
+  lmc_blob_layout(L, T, H, D, 30u * 2u * L, &h);
   return (uint64_t)h.off_streams + (uint64_t)h.nplanes * h.ngroups * lmc_group_cap_bytes(T);
 }
 

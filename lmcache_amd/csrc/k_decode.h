@@ -74,8 +74,10 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   auto hdw = [&](int i) { return (u32)__builtin_amdgcn_readfirstlane((int)hd[i]); };
   const u32 T = hdw(4);
   const u32 src_dtype = hdw(2);
-  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G);
-  if (hdw(0) != LMC_BLOB_MAGIC || hdw(7) != (u32)a.C || hdw(8) != (u32)a.P || hdw(15) != bo.streams) {
+  const u32 cdf_rows = hdw(19);
+  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, cdf_rows);
+  if (hdw(0) != LMC_BLOB_MAGIC || (hdw(1) & 0xffffu) != LMC_BLOB_VERSION || hdw(7) != (u32)a.C ||
+      hdw(8) != (u32)a.P || hdw(15) != bo.streams || cdf_rows > 30u * (u32)a.P) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_HEADER);
     return;
   }
@@ -83,24 +85,32 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   const bool active = c < a.C;
 
   // ---- CDF rows of this group -> LDS [entry][lane] (coalesced 2-byte loads, transposed LDS writes) ----
+  // The blob stores entries 1..R of each row (R = bins - 2); entry 0 is 0 and entries above R are
+  // 65504 + i (lmc_format.h).
   {
-    const u32 total = (u32)min(64, a.C - g * 64) * LMC_LP;
-    const u16* src = reinterpret_cast<const u16*>(blob + bo.cdf) + ((long long)p * a.C + g * 64) * LMC_LP;
+    const u32 R = min(30u, max(2u, (u32)__builtin_amdgcn_readfirstlane((int)blob[bo.bins + p]) - 2u));
+    const u32 rp = (u32)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const u16*>(blob + bo.rowpre)[p]);
+    const float rcpR = 1.0f / (float)R;
+    const u32 total = (u32)min(64, a.C - g * 64) * R;
+    const u16* src = reinterpret_cast<const u16*>(blob + bo.cdf) + (long long)a.C * rp + (long long)g * 64 * R;
 #pragma unroll 1
-    for (u32 e0 = 0; e0 < total; e0 += 64 * 11) {  // 33 = 3 x 11 sweeps; 11 loads in flight
-      u16 v[11];
+    for (u32 e0 = 0; e0 < total; e0 += 64 * 10) {  // <= 30 sweeps of 64, 10 loads in flight
+      u16 v[10];
 #pragma unroll
-      for (int i = 0; i < 11; i++) {
+      for (int i = 0; i < 10; i++) {
         const u32 e = e0 + i * 64 + lane;
         v[i] = e < total ? src[e] : (u16)0;
       }
 #pragma unroll
-      for (int i = 0; i < 11; i++) {
+      for (int i = 0; i < 10; i++) {
         const u32 e = e0 + i * 64 + lane;
-        const u32 cl = div33(e), s = e - cl * LMC_LP;
-        if (e < total) cdfT[s * 64 + cl] = v[i];
+        u32 cl, s;
+        divmod_small(e, R, rcpR, cl, s);
+        if (e < total) cdfT[(s + 1u) * 64 + cl] = v[i];
       }
     }
+    cdfT[lane] = 0;
+    for (u32 i = R + 1u; i < (u32)LMC_LP; i++) cdfT[i * 64 + lane] = (u16)(LMC_CDF_SCALE + i);
     if (!active) {  // idle lanes: any strictly increasing column keeps the search in range
 #pragma unroll
       for (int i = 0; i < 33; i++) cdfT[i * 64 + lane] = (u16)i;

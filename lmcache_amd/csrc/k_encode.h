@@ -35,6 +35,7 @@ struct EncodeArgs {
   u32 cap;              // bytes per scratch slot
   u32* glen;            // [nchunks*P*G] exact stream bytes
   u32* status;
+  BinsArg bins;         // ENCODE: bins and CDF row prefix per plane
 };
 
 #define ENC_WAVE_DWORDS 1056  // 4224 B per wave: histogram [16][64] u32, then (aliased) CDF table [33][64] u16
@@ -120,18 +121,25 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
     }
   }
   wave_lds_fence();  // columns are read by other lanes below
-  {
-    // channel-major [c][33] rows of this group are contiguous in the blob: write them with
-    // consecutive lanes on consecutive u16 (128 B per store), reading LDS transposed
-    const u32 total = (u32)min(64, a.C - g * 64) * LMC_LP;
-    u16* dst;
-    if (ENCODE) {
-      const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G);
-      dst = reinterpret_cast<u16*>(a.blobs + (long long)chunk * a.blob_stride + bo.cdf);
-    } else {
-      dst = a.cdf_out;
+  if (ENCODE) {
+    // The blob keeps entries 1..R of every channel row (R = bins - 2; the rest is implied, lmc_format.h).
+    // This group's rows are contiguous: write them with consecutive lanes on consecutive u16 (128 B per
+    // store), reading LDS transposed.
+    const u32 R = (u32)a.bins.b[p] - 2u;
+    const float rcpR = 1.0f / (float)R;
+    const u32 total = (u32)min(64, a.C - g * 64) * R;
+    const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
+    u16* dst = reinterpret_cast<u16*>(a.blobs + (long long)chunk * a.blob_stride + bo.cdf) +
+               (long long)a.C * a.bins.rowpre[p] + (long long)g * 64 * R;
+    for (u32 e = lane; e < total; e += 64) {
+      u32 cl, s;
+      divmod_small(e, R, rcpR, cl, s);
+      dst[e] = tab[(s + 1u) * 64 + cl];
     }
-    dst += ((long long)p * a.C + g * 64) * LMC_LP;
+  } else {
+    // lmc_calculate_cdf: the reference's full [P][C][33] layout
+    const u32 total = (u32)min(64, a.C - g * 64) * LMC_LP;
+    u16* dst = a.cdf_out + ((long long)p * a.C + g * 64) * LMC_LP;
     for (u32 e = lane; e < total; e += 64) {
       const u32 cl = div33(e), s = e - cl * LMC_LP;
       dst[e] = tab[s * 64 + cl];
@@ -240,7 +248,8 @@ __global__ __launch_bounds__(1024) void k_scan_finalize(ScanArgs a) {
   const u32 T = (u32)min(a.chunk_tokens, a.tok_end - tok0);
   const int n = a.P * a.G;
   u8* blob = a.blobs + (long long)chunk * a.blob_stride;
-  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G);
+  const u32 cdf_rows = a.bins.rowpre[a.P];
+  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, cdf_rows);
   u32* gend = reinterpret_cast<u32*>(blob + bo.gend);
   if (tid == 0) carry_s = 0;
   __syncthreads();
@@ -270,7 +279,9 @@ __global__ __launch_bounds__(1024) void k_scan_finalize(ScanArgs a) {
   }
   const u32 stream_bytes = carry_s;
   // bins + zeroed pads (the oracle memsets the static region)
-  for (u32 i = tid; i < bo.scales - bo.bins; i += 1024) blob[bo.bins + i] = i < (u32)a.P ? a.bins.b[i] : (u8)0;
+  for (u32 i = tid; i < bo.rowpre - bo.bins; i += 1024) blob[bo.bins + i] = i < (u32)a.P ? a.bins.b[i] : (u8)0;
+  for (u32 i = tid; i < (bo.scales - bo.rowpre) / 2; i += 1024)
+    reinterpret_cast<u16*>(blob + bo.rowpre)[i] = i <= (u32)a.P ? a.bins.rowpre[i] : (u16)0;
   for (u32 i = bo.scales + 2u * a.P * T + tid; i < bo.cdf; i += 1024) blob[i] = 0;
   for (u32 i = bo.gend + 4u * n + tid; i < bo.streams; i += 1024) blob[i] = 0;
   if (tid < 32) {
@@ -294,6 +305,8 @@ __global__ __launch_bounds__(1024) void k_scan_finalize(ScanArgs a) {
       case 15: v = bo.streams; break;
       case 16: v = stream_bytes; break;
       case 17: v = bo.streams + stream_bytes; break;
+      case 18: v = bo.rowpre; break;
+      case 19: v = cdf_rows; break;
       default: v = 0;
     }
     reinterpret_cast<u32*>(blob)[tid] = v;
@@ -312,6 +325,7 @@ struct PackArgs {
   const u32* goff;
   int tok_begin, tok_end, chunk_tokens;
   int P, C, G;
+  u32 cdf_rows;
   long long ngroups_total;
 };
 
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(256) void k_pack_streams(PackArgs a) {
   const int chunk = (int)(gid / n);
   const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
   const u32 T = (u32)min(a.chunk_tokens, a.tok_end - tok0);
-  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G);
+  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, a.cdf_rows);
   const u32 n16 = ((a.glen[gid] + 15u) & ~15u) >> 4;
   const uint4* src = reinterpret_cast<const uint4*>(a.scratch + gid * (long long)a.cap);
   uint4* dst = reinterpret_cast<uint4*>(a.blobs + (long long)chunk * a.blob_stride + bo.streams + a.goff[gid]);

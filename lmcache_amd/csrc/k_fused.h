@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512 * NITER, 4) void k_fused_encode(FusedArgs a) {
   const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
   const int Tc = min(a.chunk_tokens, a.tok_end - tok0);
   const u32 T = (u32)Tc;
-  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)C, (u32)NW);
+  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)C, (u32)NW, (u32)a.bins.rowpre[a.P]);
   u8* blob = a.blobs + (long long)chunk * a.blob_stride;
 
   for (int i = tid; i < 16 * C; i += C) hist[i] = 0;
@@ -190,10 +190,14 @@ __global__ __launch_bounds__(512 * NITER, 4) void k_fused_encode(FusedArgs a) {
       if (i < 32) n += (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
     }
     __syncthreads();
-    u16* dst = reinterpret_cast<u16*>(blob + bo.cdf) + (long long)p * C * LMC_LP;
-    for (u32 e = tid; e < (u32)(C * LMC_LP); e += C) {
-      const u32 cl = e / LMC_LP, s = e - cl * LMC_LP;
-      dst[e] = tab[s * C + cl];
+    // entries 1..R of every row (R = bins - 2), coalesced
+    const u32 R = (u32)a.bins.b[p] - 2u;
+    const float rcpR = 1.0f / (float)R;
+    u16* dst = reinterpret_cast<u16*>(blob + bo.cdf) + (long long)C * a.bins.rowpre[p];
+    for (u32 e = tid; e < (u32)C * R; e += C) {
+      u32 cl, s;
+      divmod_small(e, R, rcpR, cl, s);
+      dst[e] = tab[(s + 1u) * C + cl];
     }
   }
 

@@ -164,11 +164,15 @@ static KvAddr to_addr(const lmc_kv_layout* l) {
 static bool bins_ok(const int32_t* bins_h, int P, BinsArg* out) {
   if (!bins_h) return false;
   memset(out, 0, sizeof *out);
+  u32 acc = 0;
   for (int p = 0; p < P; p++) {
     // MAX = bins//2 - 1 >= 1 and symbols 0..2*MAX must fit the 32-entry CDF
     if (bins_h[p] < 4 || bins_h[p] > LMC_MAX_BINS) return false;
     out->b[p] = (u8)bins_h[p];
+    out->rowpre[p] = (u16)acc;
+    acc += lmc_cdf_row((uint32_t)bins_h[p]);
   }
+  out->rowpre[P] = (u16)acc;
   return true;
 }
 
@@ -299,7 +303,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   const int TQ = (chunk_tokens + 3) / 4;
   const u32 cap = lmc_group_cap_bytes((uint32_t)chunk_tokens);
   lmc_blob_header hl;
-  lmc_blob_layout((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D, &hl);
+  lmc_blob_layout((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D, bins.rowpre[P], &hl);
   const long long PG = (long long)P * G;
 
   // Launch the four kernels for chunks [c0, c0 + nc); the workspace slice starts at chunk slot `w0`.
@@ -350,6 +354,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     ea.blobs = blobs_b; ea.blob_stride = (long long)blob_stride;
     ea.scratch = c->scratch + (long long)w0 * PG * cap; ea.cap = cap;
     ea.glen = c->glen + (long long)w0 * PG; ea.status = c->status_h;
+    ea.bins = bins;
     const long long ngroups = (long long)nc * PG;
     if (!use_fused) {
       hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, ea);
@@ -372,7 +377,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     pa.blobs = blobs_b; pa.blob_stride = (long long)blob_stride;
     pa.scratch = ea.scratch; pa.cap = cap; pa.glen = ea.glen; pa.goff = sa.goff;
     pa.tok_begin = tb; pa.tok_end = tok_end; pa.chunk_tokens = chunk_tokens;
-    pa.P = P; pa.C = C; pa.G = G; pa.ngroups_total = ngroups;
+    pa.P = P; pa.C = C; pa.G = G; pa.cdf_rows = bins.rowpre[P]; pa.ngroups_total = ngroups;
     hipLaunchKernelGGL(k_pack_streams, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, pa);
     HIP_TRY(hipGetLastError());
     if ((r = prof_mark(c, s))) return r;
@@ -518,13 +523,14 @@ int lmc_blob_info(const void* blob_h, size_t nbytes, lmc_blob_header* out) {
   lmc_blob_header h;
   memcpy(&h, blob_h, sizeof h);
   if (h.magic != LMC_BLOB_MAGIC || h.version != LMC_BLOB_VERSION || h.header_bytes != LMC_HEADER_BYTES) return LMC_ERR_INVALID;
+  if (h.num_layers == 0 || h.ntokens == 0 || h.num_heads == 0 || h.head_size == 0) return LMC_ERR_INVALID;
+  if (h.num_layers > LMC_MAX_PLANES / 2 || h.cdf_rows > 30u * 2u * h.num_layers) return LMC_ERR_INVALID;
   lmc_blob_header ref;
   memset(&ref, 0, sizeof ref);
-  if (h.num_layers == 0 || h.ntokens == 0 || h.num_heads == 0 || h.head_size == 0) return LMC_ERR_INVALID;
-  lmc_blob_layout(h.num_layers, h.ntokens, h.num_heads, h.head_size, &ref);
+  lmc_blob_layout(h.num_layers, h.ntokens, h.num_heads, h.head_size, h.cdf_rows, &ref);
   if (h.nchannels != ref.nchannels || h.nplanes != ref.nplanes || h.ngroups != ref.ngroups || h.lp != ref.lp ||
-      h.off_bins != ref.off_bins || h.off_scales != ref.off_scales || h.off_cdf != ref.off_cdf ||
-      h.off_gend != ref.off_gend || h.off_streams != ref.off_streams)
+      h.off_bins != ref.off_bins || h.off_rowpre != ref.off_rowpre || h.off_scales != ref.off_scales ||
+      h.off_cdf != ref.off_cdf || h.off_gend != ref.off_gend || h.off_streams != ref.off_streams)
     return LMC_ERR_INVALID;
   if (h.total_bytes != h.off_streams + h.stream_bytes || h.total_bytes > nbytes) return LMC_ERR_INVALID;
   *out = h;

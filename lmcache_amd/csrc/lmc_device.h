@@ -32,6 +32,7 @@ struct KvAddr {
 
 struct BinsArg {
   u8 b[LMC_MAX_PLANES];
+  u16 rowpre[LMC_MAX_PLANES + 1];  // rowpre[p] = sum over planes before p of (bins - 2): CDF rows stored per channel
 };
 
 __device__ __forceinline__ const u16* lmc_plane_base(const KvAddr& a, int p) {
@@ -52,16 +53,24 @@ __device__ __forceinline__ long long lmc_tok_off(const KvAddr& a, int t) {
 
 // Section offsets of a chunk blob with T tokens (mirror of lmc_blob_layout).
 struct BlobOff {
-  u32 bins, scales, cdf, gend, streams;
+  u32 bins, rowpre, scales, cdf, gend, streams;
 };
-__device__ __forceinline__ BlobOff lmc_blob_off(u32 P, u32 T, u32 C, u32 G) {
+__device__ __forceinline__ BlobOff lmc_blob_off(u32 P, u32 T, u32 C, u32 G, u32 cdf_rows) {
   BlobOff o;
   o.bins = LMC_HEADER_BYTES;
-  o.scales = o.bins + ((P + 15u) & ~15u);
+  o.rowpre = o.bins + ((P + 15u) & ~15u);
+  o.scales = o.rowpre + ((2u * (P + 1u) + 15u) & ~15u);
   o.cdf = o.scales + ((2u * P * T + 15u) & ~15u);
-  o.gend = o.cdf + ((2u * P * C * LMC_LP + 15u) & ~15u);
+  o.gend = o.cdf + ((2u * C * cdf_rows + 15u) & ~15u);
   o.streams = o.gend + ((4u * P * G + 15u) & ~15u);
   return o;
+}
+
+// e / R and e % R for small uniform R (2..30) and e < 2^15: exact through one float multiply
+// ((e + 0.5) / R is never within 1/60 of an integer; checked exhaustively on the host).
+__device__ __forceinline__ void divmod_small(u32 e, u32 R, float rcpR, u32& q, u32& r) {
+  q = (u32)(((float)e + 0.5f) * rcpR);
+  r = e - q * R;
 }
 
 // Pointers that come out of a device pointer table are "generic" to the compiler and would be

@@ -55,7 +55,8 @@ class BlobHeader(ctypes.Structure):
                 ("nplanes", ctypes.c_uint32), ("ngroups", ctypes.c_uint32), ("lp", ctypes.c_uint32),
                 ("off_bins", ctypes.c_uint32), ("off_scales", ctypes.c_uint32), ("off_cdf", ctypes.c_uint32),
                 ("off_gend", ctypes.c_uint32), ("off_streams", ctypes.c_uint32), ("stream_bytes", ctypes.c_uint32),
-                ("total_bytes", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 14)]
+                ("total_bytes", ctypes.c_uint32), ("off_rowpre", ctypes.c_uint32), ("cdf_rows", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32 * 12)]
 
 
 # name -> (restype, argtypes); every symbol include/lmc_hip.h declares
@@ -148,12 +149,16 @@ def group_cap_bytes(T: int) -> int:
     return r16(LANES * (T + 8))
 
 
-def blob_static_bytes(L: int, T: int, H: int, D: int) -> int:
+def blob_static_bytes(L: int, T: int, H: int, D: int, bins: Optional[Sequence[int]] = None) -> int:
+    """Bytes in front of the streams section (lmc_blob_layout): header, bins, rowpre, scales, the tight CDF
+    rows (bins - 2 entries per channel; every plane at 32 bins when `bins` is None) and gend."""
     C, P = H * D, 2 * L
     G = (C + LANES - 1) // LANES
+    rows = 30 * P if bins is None else sum(int(b) - 2 for b in bins)
     off = HEADER_BYTES + r16(P)
+    off += r16(2 * (P + 1))
     off += r16(2 * P * T)
-    off += r16(2 * P * C * LP)
+    off += r16(2 * C * rows)
     off += r16(4 * P * G)
     return off
 

@@ -113,10 +113,19 @@ class CacheGenGPUEncoderOutput:
 
     @property
     def cdf(self) -> torch.Tensor:
-        """int16 [2L, C, 33] -- same layout as the reference's `cdf` tensor."""
+        """int16 [2L, C, 33] -- the reference's `cdf` tensor, rebuilt from the blob's tight rows: the blob
+        stores entries 1..bins-2 of every channel; entry 0 is 0 and the entries above are 65504 + i."""
         h = self.header
-        a = self._section(h.off_cdf, h.nplanes * h.nchannels * h.lp, np.int16)
-        return torch.from_numpy(a.reshape(h.nplanes, h.nchannels, h.lp).copy())
+        P, C, LP = int(h.nplanes), int(h.nchannels), int(h.lp)
+        rowpre = self._section(h.off_rowpre, P + 1, np.uint16).astype(np.int64)
+        rows = self._section(h.off_cdf, C * int(rowpre[P]), np.uint16)
+        full = np.empty((P, C, LP), np.uint16)
+        full[:, :, 0] = 0
+        for p, b in enumerate(self.bins):
+            R = b - 2
+            full[p, :, 1:R + 1] = rows[C * rowpre[p]:C * rowpre[p + 1]].reshape(C, R)
+            full[p, :, R + 1:] = (65504 + np.arange(R + 1, LP)).astype(np.uint16)
+        return torch.from_numpy(full.view(np.int16))
 
     def _scales(self) -> torch.Tensor:
         h = self.header

@@ -56,6 +56,8 @@ def lib() -> ctypes.CDLL:
         L.lmco_decode_group.restype = i32
         L.lmco_encode_blob.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, sz, vp]
         L.lmco_encode_blob.restype = i32
+        L.lmco_blob_cdf.argtypes = [vp, sz, vp]
+        L.lmco_blob_cdf.restype = i32
         L.lmco_decode_blob_symbols.argtypes = [vp, sz, vp]
         L.lmco_decode_blob_symbols.restype = i32
         L.lmco_decode_blob.argtypes = [vp, sz, vp, i32]
@@ -167,12 +169,22 @@ def encode_blob(kv_bits: np.ndarray, dtype: int, H: int, D: int, bins: np.ndarra
 def parse_header(blob: bytes) -> dict:
     names = ["dtype", "num_layers", "ntokens", "num_heads", "head_size", "nchannels", "nplanes", "ngroups",
              "lp", "off_bins", "off_scales", "off_cdf", "off_gend", "off_streams", "stream_bytes",
-             "total_bytes"]
+             "total_bytes", "off_rowpre", "cdf_rows"]
     head = np.frombuffer(blob[:128], dtype=np.uint32)
     assert head[0] == 0x31434D4C, "bad magic"
     d = {n: int(v) for n, v in zip(names, head[2:2 + len(names)])}
     d["version"] = int(head[1] & 0xffff)
     return d
+
+
+def blob_cdf(blob: bytes) -> np.ndarray:
+    """The reference's `cdf` tensor [2L, C, 33] rebuilt from the blob's tight rows."""
+    h = parse_header(blob)
+    out = np.zeros((h["nplanes"], h["nchannels"], LP), np.uint16)
+    buf = np.frombuffer(blob, dtype=np.uint8).copy()
+    rc = lib().lmco_blob_cdf(_p(buf), len(blob), _p(out))
+    assert rc == 0, f"lmco_blob_cdf rc={rc}"
+    return out
 
 
 def decode_blob_symbols(blob: bytes) -> np.ndarray:

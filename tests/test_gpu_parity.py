@@ -338,7 +338,9 @@ def test_full_size_llama8b_chunk_vs_oracle(nat, ctx, oracle):
     ref = oracle.encode_blob(b, code, H, D, bins)
     assert blobs[0] == ref
     ratio = kv.numel() * 2 / len(ref)
-    assert 2.5 < ratio < 3.3, ratio  # ~3.0x on uniform data
+    # SURVEY.md 8a/a11 measured ~3.0x for the reference's container on uniform data; ours stores 30 / 14 CDF
+    # entries per channel instead of 33 (lmc_format.h), which brings the same streams to ~3.7x
+    assert 3.3 < ratio < 4.2, ratio
     out = torch.zeros(L, 2, T, H, D, dtype=torch.bfloat16, device=DEV)
     ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
     torch.cuda.synchronize()
