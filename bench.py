@@ -175,16 +175,16 @@ def main():
 
     # per-kernel HIP-event timing on the launch stream (lmc_ctx_profile)
     ctx.profile(True)
-    ksum = np.zeros(4)
+    knames = (["k_fused_encode", "(coder folded into k_fused_encode)", "k_scan_finalize", "k_pack_streams"]
+              if args.fused else ["k_quantize", "k_cdf_encode"])
+    ksum = np.zeros(len(knames))
     reps = max(3, min(10, args.steps))
     for _ in range(reps):
         step()
         torch.cuda.synchronize()
-        ksum += np.array(ctx.profile_read()[:4])
+        ksum += np.array(ctx.profile_read()[:len(knames)])
     ctx.profile(False)
     kms = ksum / reps
-    knames = ["k_fused_encode" if kms[1] < 0.01 else "k_quantize", "k_cdf_encode (folded into k_fused_encode)"
-              if kms[1] < 0.01 else "k_cdf_encode", "k_scan_finalize", "k_pack_streams"]
     achieved = algo_bytes / (gpu_ms_per_step / 1e3) / 1e9
     serial = algo_bytes / (float(kms.sum()) / 1e3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -113,8 +113,8 @@ int lmc_ctx_set_fused(lmc_ctx* ctx, int enable);
  * when enabled the call brackets each of its kernels with hipEvents on the
  * caller's stream.  lmc_ctx_profile_read (after the caller has synchronised
  * that stream) returns the durations in ms of the last profiled call, in
- * launch order (encode: quantize, cdf_encode, scan_finalize, pack_streams -- with the
- * fused kernel the first entry is k_fused_encode and the second ~0; decode: decode) and the number of entries written (<= cap). */
+ * launch order (encode: k_quantize, k_cdf_encode [which also compacts the streams into the
+ * blob]; with lmc_ctx_set_fused: k_fused_encode, ~0, k_scan_finalize, k_pack_streams; decode: k_decode) and the number of entries written (<= cap). */
 int lmc_ctx_profile(lmc_ctx* ctx, int enable);
 int lmc_ctx_profile_read(lmc_ctx* ctx, float* ms_out, int cap);
 

@@ -36,22 +36,133 @@ struct EncodeArgs {
   u32* glen;            // [nchunks*P*G] exact stream bytes
   u32* status;
   BinsArg bins;         // ENCODE: bins and CDF row prefix per plane
+  // in-kernel stream compaction (single-pass prefix over the padded group lengths of a chunk)
+  unsigned long long* agg;  // [nchunks][P*G], zeroed before the launch: flag << 62 | value
+  u32* sizes;               // [nchunks] total blob bytes
+  int L, H, D, dtype;       // for the header
 };
+
+// 64-bit {flag, value} granules of the decoupled look-back: one naturally aligned 8-byte agent-scope
+// store / load each, so the value and its flag can never be seen torn or out of order.
+#define AGG_X 0ull  // not published yet
+#define AGG_A 1ull  // value = this group's own padded length
+#define AGG_P 2ull  // value = inclusive prefix up to and including this group
+__device__ __forceinline__ void agg_store(unsigned long long* p, unsigned long long flag, u32 v) {
+  __hip_atomic_store(p, (flag << 62) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long agg_load(unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Header, bins, rowpre and the zero pads between sections (what the oracle memsets): by one wave.
+__device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, const EncodeArgs& a, u32 T,
+                                                  u32 stream_bytes, int lane) {
+  const u32 P = (u32)a.P, n = (u32)(a.P * a.G), cdf_rows = a.bins.rowpre[a.P];
+  for (u32 i = lane; i < bo.rowpre - bo.bins; i += 64) blob[bo.bins + i] = i < P ? a.bins.b[i] : (u8)0;
+  for (u32 i = lane; i < (bo.scales - bo.rowpre) / 2; i += 64)
+    reinterpret_cast<u16*>(blob + bo.rowpre)[i] = i <= P ? a.bins.rowpre[i] : (u16)0;
+  for (u32 i = bo.scales + 2u * P * T + lane; i < bo.cdf; i += 64) blob[i] = 0;
+  for (u32 i = bo.gend + 4u * n + lane; i < bo.streams; i += 64) blob[i] = 0;
+  if (lane < 32) {
+    u32 v = 0;
+    switch (lane) {
+      case 0: v = LMC_BLOB_MAGIC; break;
+      case 1: v = LMC_BLOB_VERSION | (LMC_HEADER_BYTES << 16); break;
+      case 2: v = (u32)a.dtype; break;
+      case 3: v = (u32)a.L; break;
+      case 4: v = T; break;
+      case 5: v = (u32)a.H; break;
+      case 6: v = (u32)a.D; break;
+      case 7: v = (u32)a.C; break;
+      case 8: v = P; break;
+      case 9: v = (u32)a.G; break;
+      case 10: v = LMC_LP; break;
+      case 11: v = bo.bins; break;
+      case 12: v = bo.scales; break;
+      case 13: v = bo.cdf; break;
+      case 14: v = bo.gend; break;
+      case 15: v = bo.streams; break;
+      case 16: v = stream_bytes; break;
+      case 17: v = bo.streams + stream_bytes; break;
+      case 18: v = bo.rowpre; break;
+      case 19: v = cdf_rows; break;
+      default: v = 0;
+    }
+    reinterpret_cast<u32*>(blob)[lane] = v;
+  }
+}
 
 #define ENC_WAVE_DWORDS 1056  // 4224 B per wave: histogram [16][64] u32, then (aliased) CDF table [33][64] u16
 
-template <bool QUADSYM, bool ENCODE>
+struct PendingTile {
+  int chunk, pg;
+  u32 exact, T;
+  const u16* out;
+};
+
+// In-kernel compaction: where does a finished stream go?  Single-pass prefix sum over the padded lengths of
+// the chunk's P*G groups (decoupled look-back): every wave publishes its length as soon as a stream is coded,
+// and later looks back over its predecessors' granules until it meets an inclusive prefix, publishes its own
+// inclusive prefix, then moves the stream from its scratch slot to its final place.  Replaces
+// k_scan_finalize + k_pack_streams behind this kernel (the cumsum + gather of collect_bytes,
+// cachegen_encoder.py:230-238).  Predecessors have lower stream ids: they were taken by workgroups dispatched
+// no later than ours, in an earlier or the same round, and never wait on us.
+__device__ __forceinline__ void compact_stream(const EncodeArgs& a, const PendingTile& t, int lane) {
+  const int n = a.P * a.G;
+  const u32 padded = (t.exact + 15u) & ~15u;
+  unsigned long long* agg = a.agg + (long long)t.chunk * n;
+  u32 excl = 0;
+  if (t.pg > 0) {
+    int base = t.pg - 1;
+    u32 spins = 0;
+    for (;;) {
+      const int idx = base - lane;
+      const unsigned long long v = idx >= 0 ? agg_load(agg + idx) : ((AGG_P << 62) | 0ull);  // virtual group -1
+      const u32 flag = (u32)(v >> 62);
+      const u64 mP = __ballot(flag == (u32)AGG_P), mX = __ballot(flag == (u32)AGG_X);
+      const int first = mP ? __builtin_ctzll(mP) : 64;  // nearest predecessor with a full prefix
+      const u64 below = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
+      if (mX & below) {  // someone we need has not published yet
+        if (++spins > (1u << 24)) {
+          if (lane == 0) atomicOr(a.status, LMC_ST_LOOKBACK_TIMEOUT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      excl += wave_sum_u32(lane <= first ? (u32)v : 0u);
+      if (mP) break;
+      base -= 64;
+    }
+  }
+  if (lane == 0) agg_store(agg + t.pg, AGG_P, excl + padded);
+  const BlobOff bo = lmc_blob_off((u32)a.P, t.T, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
+  u8* blob = a.blobs + (long long)t.chunk * a.blob_stride;
+  if (lane == 0) reinterpret_cast<u32*>(blob + bo.gend)[t.pg] = excl + t.exact;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stream stores have landed before it re-reads them
+  const uint4* src = reinterpret_cast<const uint4*>(t.out);
+  uint4* dst = reinterpret_cast<uint4*>(blob + bo.streams + excl);
+  const u32 n16 = padded >> 4;
+#pragma unroll 4
+  for (u32 i = lane; i < n16; i += 64) dst[i] = src[i];
+  if (t.pg == n - 1) {  // the last group knows the chunk's size: header, static sections, size word
+    write_blob_static(blob, bo, a, t.T, excl + padded, lane);
+    if (lane == 0) a.sizes[t.chunk] = bo.streams + excl + padded;
+  }
+}
+
+template <bool QUADSYM, bool ENCODE, bool COMPACT>
 __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   __shared__ __attribute__((aligned(16))) u32 lds_all[4 * ENC_WAVE_DWORDS];
   const int lane = threadIdx.x & 63;
   // everything derived from the wave id is wave-uniform: keep it in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long gid = (long long)blockIdx.x * 4 + wave;
   const long long ngroups_total = (long long)a.nchunks * a.P * a.G;
-  if (gid >= ngroups_total) return;
   u32* hist = lds_all + wave * ENC_WAVE_DWORDS;    // [16][64] u32: two u16 counters per dword
   u16* tab = reinterpret_cast<u16*>(hist);          // [33][64] u16 CDF, written after hist is in registers
 
+  const long long gid = (long long)blockIdx.x * 4 + wave;
+  if (gid >= ngroups_total) return;
   const int g = (int)(gid % a.G);
   const long long pc = gid / a.G;
   const int p = (int)(pc % a.P);
@@ -218,9 +329,18 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   const u32 exact = wcur * 2;
   const u32 padw = ((16u - (exact & 15u)) & 15u) >> 1;
   if ((u32)lane < padw) out[wcur + lane] = 0;
-  if (lane == 0) {
-    a.glen[gid] = exact;
-    if (exact + 16 > a.cap) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);
+  if (lane == 0 && exact + 16 > a.cap) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);
+  if (!COMPACT) {
+    if (lane == 0) a.glen[gid] = exact;
+    return;
+  }
+  // publish this stream's padded length, then compact it (waits for predecessors that are still coding)
+  {
+    const int n = a.P * a.G;
+    PendingTile t;
+    t.chunk = chunk; t.pg = p * a.G + g; t.exact = exact; t.T = T; t.out = out;
+    if (lane == 0 && t.pg > 0) agg_store(a.agg + (long long)chunk * n + t.pg, AGG_A, (exact + 15u) & ~15u);
+    compact_stream(a, t, lane);
   }
 }
 

@@ -35,8 +35,10 @@ struct lmc_ctx {
   u32* sym4 = nullptr;  size_t sym4_bytes = 0;
   u8* scratch = nullptr; size_t scratch_bytes = 0;
   u32* glen = nullptr;  u32* goff = nullptr; size_t glen_bytes = 0;
+  unsigned long long* agg = nullptr; size_t agg_bytes = 0;  // look-back granules of the in-kernel compaction
   hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
   bool ws_used = false;
+  int num_cus = 256;
   u32* status_h = nullptr;  // pinned, device-accessible
   // k_fused_encode (C = 512 / 1024, chunks <= 256 tokens) moves half the HBM bytes of the general path but is
   // ~4 % slower standalone (1 workgroup per CU, no overlap of its memory and coder phases): opt-in.
@@ -78,6 +80,10 @@ int lmc_ctx_create(int device, lmc_ctx** out) {
   lmc_ctx* c = new (std::nothrow) lmc_ctx();
   if (!c) return LMC_ERR_NOMEM;
   c->device = device;
+  {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->num_cus = v;
+  }
   hipError_t e = hipHostMalloc((void**)&c->status_h, 64, hipHostMallocMapped | hipHostMallocPortable);
   if (e != hipSuccess) { g_last_hip = (int)e; delete c; return LMC_ERR_HIP; }
   memset(c->status_h, 0, 64);
@@ -95,6 +101,7 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->glen) (void)hipFree(c->glen);
   if (c->goff) (void)hipFree(c->goff);
+  if (c->agg) (void)hipFree(c->agg);
   if (c->ws_free) (void)hipEventDestroy(c->ws_free);
   for (int i = 0; i < 8; i++) if (c->pev[i]) (void)hipEventDestroy(c->pev[i]);
   if (c->status_h) (void)hipHostFree(c->status_h);
@@ -220,12 +227,15 @@ static int reserve_locked(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int
   const size_t need_sym = (size_t)max_chunks * P * TQ * C * 4;
   const size_t need_scr = (size_t)max_chunks * P * G * lmc_group_cap_bytes((uint32_t)chunk_tokens);
   const size_t need_len = (size_t)max_chunks * P * G * 4;
-  if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && need_len <= c->glen_bytes) return LMC_OK;
+  if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && need_len <= c->glen_bytes &&
+      2 * need_len <= c->agg_bytes)
+    return LMC_OK;
   // growing frees memory that queued kernels may still use: wait for them (this call only)
   if (c->ws_used) HIP_TRY(hipEventSynchronize(c->ws_free));
   int rc;
   if ((rc = ws_grow((void**)&c->sym4, &c->sym4_bytes, need_sym))) return rc;
   if ((rc = ws_grow((void**)&c->scratch, &c->scratch_bytes, need_scr))) return rc;
+  if ((rc = ws_grow((void**)&c->agg, &c->agg_bytes, 2 * need_len))) return rc;
   if (need_len > c->glen_bytes) {
     size_t h1 = c->glen_bytes, h2 = c->glen_bytes;
     if ((rc = ws_grow((void**)&c->glen, &h1, need_len))) return rc;
@@ -275,7 +285,7 @@ int lmc_calculate_cdf(lmc_ctx* c, const int8_t* sym, int32_t P, int32_t T, int32
   a.status = c->status_h;
   HIP_TRY(hipSetDevice(c->device));
   long long n = (long long)P * a.G;
-  hipLaunchKernelGGL((k_cdf_encode<false, false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_cdf_encode<false, false, false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return LMC_OK;
 }
@@ -355,10 +365,17 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     ea.scratch = c->scratch + (long long)w0 * PG * cap; ea.cap = cap;
     ea.glen = c->glen + (long long)w0 * PG; ea.status = c->status_h;
     ea.bins = bins;
+    ea.agg = c->agg + (long long)w0 * PG; ea.sizes = sizes + c0;
+    ea.L = L; ea.H = H; ea.D = D; ea.dtype = src->dtype;
     const long long ngroups = (long long)nc * PG;
     if (!use_fused) {
-      hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, ea);
+      // the coder also compacts its streams into the blob (single-pass prefix over the group lengths):
+      // k_scan_finalize / k_pack_streams are only needed behind the fused tile kernel
+      HIP_TRY(hipMemsetAsync(ea.agg, 0, (size_t)ngroups * 8, s));
+      hipLaunchKernelGGL((k_cdf_encode<true, true, true>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, ea);
       HIP_TRY(hipGetLastError());
+      if ((r = prof_mark(c, s))) return r;
+      return LMC_OK;
     }
     if ((r = prof_mark(c, s))) return r;
 

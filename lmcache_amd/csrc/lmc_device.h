@@ -19,6 +19,7 @@ typedef uint64_t u64;
 #define LMC_ST_STREAM_OVERFLOW 1u
 #define LMC_ST_BAD_HEADER 2u
 #define LMC_ST_BAD_STREAM 4u
+#define LMC_ST_LOOKBACK_TIMEOUT 8u
 
 // Device copy of lmc_kv_layout (include/lmc_hip.h), strides in elements.
 struct KvAddr {
@@ -128,6 +129,12 @@ __device__ __forceinline__ u32 f2fp16(float f) {  // v_cvt_f16_f32, RNE
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) v += (u32)__shfl_xor((int)v, off);
+  return v;
 }
 
 __device__ __forceinline__ u32 lane_rank(u64 mask) {  // # set bits of mask below this lane
