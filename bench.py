@@ -39,7 +39,7 @@ CTX, CHUNK = 16384, 256
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per step from the PMC passes committed under profiles/ (see profiles/r01_*_pmc.md): updated by hand
 # whenever the kernels' data flow changes; None until measured.
-TRAFFIC_BYTES_PER_STEP = 5_823_000_000  # profiles/r01_b_pmc.md
+TRAFFIC_BYTES_PER_STEP = 5_526_000_000  # profiles/r01_c_pmc.md
 
 
 def cachegen_bins_llama8b():
@@ -195,7 +195,7 @@ def main():
                 "achieved_serial": round(serial, 1),
                 "algorithmic_bytes_per_step": int(algo_bytes),
                 "note": "achieved = (raw KV read once + blob written once) per step / HIP-event time of one step "
-                        "(the whole encode job = its four kernels) on the launch stream over the timed region; "
+                        "(the whole encode job: k_quantize + k_cdf_encode) on the launch stream over the timed region; "
                         "kernels_ms_serial = per-kernel HIP events of one job (lmc_ctx_profile); traffic = HBM bytes per "
                         "step from rocprofv3 FETCH_SIZE/WRITE_SIZE (profiles/), FETCH_SIZE doubled for the 16-B/lane "
                         "streams per MI355X_MICROARCH.md"}
