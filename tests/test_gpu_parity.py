@@ -309,6 +309,76 @@ def test_fused_and_general_encoders_agree_with_oracle(nat, ctx, oracle, shape):
         assert b == ref, f"general chunk {i}"
 
 
+def test_llama70b_tp8_rank_shape(nat, ctx, oracle):
+    """BASELINE config 4, one rank of Llama-3-70B TP=8: 80 layers (160 planes), one KV head per rank
+    (C = 128), per-layer tensors, two chunks with a short tail."""
+    from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
+    L, H, D, Ttot, cs = 80, 1, 128, 300, 256
+    bins = CacheGenConfig.from_model_name("Llama-3-70B").plane_bins(L)
+    g = torch.Generator().manual_seed(70)
+    kvt = tuple((torch.randn(Ttot, H, D, generator=g).to(torch.bfloat16).to(DEV),
+                 torch.randn(Ttot, H, D, generator=g).to(torch.bfloat16).to(DEV)) for _ in range(L))
+    blobs, blob_dev, stride = encode(nat, ctx, nat.KVLayout.from_kv_tuple(kvt, "vllm"), 0, Ttot, cs, bins)
+    full = torch.stack([torch.stack(p, 0) for p in kvt], 0).cpu()
+    for i, blob in enumerate(blobs):
+        t0, t1 = i * cs, min(Ttot, (i + 1) * cs)
+        b, code = oracle.torch_to_bits(full[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
+        assert blob == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)), f"chunk {i}"
+    outt = tuple((torch.zeros_like(k), torch.zeros_like(v)) for k, v in kvt)
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, len(blobs), nat.KVLayout.from_kv_tuple(outt, "vllm"), 0, cs)
+    torch.cuda.synchronize()
+    ctx.raise_on_status("decode")
+    want0 = oracle.decode_blob(blobs[0], oracle.BF16)
+    assert np.array_equal(bits_np(outt[79][1][:cs]).reshape(cs, H * D), want0[79, 1])
+
+
+def test_concurrent_calls_share_one_context(nat, ctx, oracle):
+    """Re-entrancy (SURVEY.md 8b threading): two host threads, each on its own stream, encode and decode
+    different KV through the SAME context; the workspace is ordered by events, results must not mix."""
+    import threading
+    L, T, H, D = 2, 200, 8, 128
+    bins = default_bins(L)
+    results, errors = {}, []
+
+    def worker(seed):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            kv = make_kv(L, T, H, D, torch.bfloat16, "randn", seed)
+            kvd = kv.to(DEV)
+            stride = nat.r16(nat.blob_bound(L, T, H, D))
+            for it in range(6):
+                blobs = torch.zeros(stride, dtype=torch.uint8, device=DEV)
+                sizes = torch.zeros(1, dtype=torch.int32, device=DEV)
+                out = torch.zeros_like(kvd)
+                with torch.cuda.stream(st):
+                    ctx.encode_chunks(nat.KVLayout.from_chunk(kvd, "vllm"), 0, T, T, bins, blobs.data_ptr(), stride,
+                                      sizes.data_ptr(), stream=st.cuda_stream)
+                    ctx.decode_chunks(blobs.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T,
+                                      stream=st.cuda_stream)
+                st.synchronize()
+                results[(seed, it)] = (blobs[:int(sizes.item())].cpu().numpy().tobytes(), bits_np(out))
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in (11, 22, 33)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert ctx.status(clear=True) == 0
+    for seed in (11, 22, 33):
+        kv = make_kv(L, T, H, D, torch.bfloat16, "randn", seed)
+        b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
+        ref = oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+        want = oracle.decode_blob(ref, oracle.BF16)
+        for it in range(6):
+            blob, dec = results[(seed, it)]
+            assert blob == ref, (seed, it)
+            assert np.array_equal(dec.reshape(L, 2, T, H * D), want), (seed, it)
+
+
 def test_corrupt_blob_is_flagged(nat, ctx):
     L, T, H, D = 1, 32, 1, 128
     kv = make_kv(L, T, H, D, torch.bfloat16, "randn", 1).to(DEV)
