@@ -379,6 +379,57 @@ def test_concurrent_calls_share_one_context(nat, ctx, oracle):
             assert np.array_equal(dec.reshape(L, 2, T, H * D), want), (seed, it)
 
 
+def test_full_16k_context_roundtrip_equals_reference_formula(nat, ctx):
+    """BASELINE config 2 at FULL size (32 layers x 16384 tokens x 8 x 128 bf16 = 2 GiB, 64 chunks): the
+    size-independent property decode(encode(x)) == do_dequantize(torch_quant_vectorized(x)).to(bf16), with the
+    right-hand side evaluated plane by plane by torch ON THE CPU exactly as the reference writes it
+    (cachegen_encoder.py:54-59, cachegen_decoder.py:31-35,190-193; eager ops, so mul and add round separately).
+    The same formula run by torch's own GPU kernels is checked against it on two layers (informational)."""
+    from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
+    L, Ttot, H, D, cs = 32, 16384, 8, 128, 256
+    cfg = CacheGenConfig.from_model_name("meta-llama/Llama-3.1-8B-Instruct")
+    bins = cfg.plane_bins(L)
+    g = torch.Generator(device=DEV).manual_seed(123)
+    kv = tuple((torch.randn((Ttot, H, D), generator=g, device=DEV).to(torch.bfloat16),
+                (torch.rand((Ttot, H, D), generator=g, device=DEV) * 3 - 1).to(torch.bfloat16)) for _ in range(L))
+    n = Ttot // cs
+    stride = nat.r16(nat.blob_bound(L, cs, H, D))
+    blobs = torch.empty(n * stride, dtype=torch.uint8, device=DEV)
+    sizes = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ctx.encode_chunks(nat.KVLayout.from_kv_tuple(kv, "vllm"), 0, Ttot, cs, bins, blobs.data_ptr(), stride, sizes.data_ptr())
+    out = tuple((torch.empty_like(k), torch.empty_like(v)) for k, v in kv)
+    ctx.decode_chunks(blobs.data_ptr(), stride, n, nat.KVLayout.from_kv_tuple(out, "vllm"), 0, cs)
+    torch.cuda.synchronize()
+    ctx.raise_on_status("full context")
+    sz = sizes.cpu()
+    assert int(sz.min()) > 0 and 3.0 < (L * 2 * Ttot * H * D * 2) / int(sz.sum()) < 4.5
+
+    def reference(x, nbins):  # x [T, H, D] bf16
+        xc = x.reshape(x.shape[0], H * D)
+        # [1, 1] like the reference's (bins // 2 - 1)[:, None, None]: a dim>0 fp32 tensor, so MAX / max1 is fp32
+        # (a 0-dim tensor would not take part in type promotion and the division would happen in bf16)
+        MAX = torch.full((1, 1), float(nbins // 2 - 1), device=x.device)
+        max1 = torch.amax(torch.abs(xc), dim=-1, keepdim=True)
+        factor = MAX / max1
+        xq = torch.round(xc * factor + MAX).to(torch.int8)
+        t = xq.to(torch.uint8).float()
+        t = t - MAX
+        t = t / MAX
+        t = t * max1
+        return t.to(torch.bfloat16).reshape(x.shape)
+
+    gpu_torch_mismatch = 0
+    for l in range(L):
+        for kvi in range(2):
+            want = reference(kv[l][kvi].cpu(), bins[kvi * L + l])
+            got = out[l][kvi].cpu()
+            assert torch.equal(got, want), (l, kvi)
+            if l < 2:  # informational: the same formula run by torch's GPU kernels
+                gpu_torch_mismatch += int((reference(kv[l][kvi], bins[kvi * L + l]).cpu() != want).sum())
+    print(f"torch-GPU vs torch-CPU evaluation of the reference formula: {gpu_torch_mismatch} mismatches in "
+          f"{4 * Ttot * H * D} elements")
+
+
 def test_corrupt_blob_is_flagged(nat, ctx):
     L, T, H, D = 1, 32, 1, 128
     kv = make_kv(L, T, H, D, torch.bfloat16, "randn", 1).to(DEV)
