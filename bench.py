@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the cpu_baseline sample (0 = auto)")
+    ap.add_argument("--exchange", action="store_true",
+                    help="N>1 only, opt-in: time one RCCL/xGMI exchange step of the encoded chunks between ranks "
+                         "(XgmiShardStore; outside the timed region, reported as `exchange`)")
     ap.add_argument("--fused", action="store_true", help="use the fused tile encoder (half the HBM traffic, ~4 %% slower)")
     args = ap.parse_args()
 
@@ -154,6 +157,33 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * raw_bytes * args.steps / elapsed / 1e9
+
+    # ---- optional: one exchange step of the encoded chunks over RCCL/xGMI (row f1; outside the timed region) ----
+    exchange = None
+    if args.exchange and world > 1:
+        import torch.distributed as dist
+        from lmcache_amd.storage_backend.connector.xgmi_exchange import XgmiShardStore
+        szs = sizes.cpu().tolist()
+        store = XgmiShardStore()
+        items = [(f"bench@{world}@{rank}@{i:04x}", blobs[i * stride:i * stride + szs[i]]) for i in range(nchunks)]
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        store.exchange_put(items)
+        torch.cuda.synchronize(); dist.barrier()
+        t_put = time.perf_counter() - t0
+        peer = (rank + 1) % world
+        want = [f"bench@{world}@{peer}@{i:04x}" for i in range(nchunks)]
+        t0 = time.perf_counter()
+        got = store.exchange_get(want)
+        torch.cuda.synchronize(); dist.barrier()
+        t_get = time.perf_counter() - t0
+        nbytes = torch.tensor([float(sum(szs))], device=dev, dtype=torch.float64)
+        dist.all_reduce(nbytes)
+        ok = all(g is not None for g in got)
+        exchange = {"put_GBps_blob_all_ranks": round(float(nbytes.item()) / t_put / 1e9, 1),
+                    "get_GBps_blob_all_ranks": round(float(nbytes.item()) / t_get / 1e9, 1),
+                    "put_ms": round(t_put * 1e3, 2), "get_ms": round(t_get * 1e3, 2), "all_hits": ok,
+                    "note": "one batch_isend_irecv per call; includes the all_gather_object control round trips"}
 
     if rank != 0:
         if world > 1:
@@ -278,6 +308,8 @@ def main():
                       "layers": L, "kv_heads": H, "head_dim": D, "context_tokens": CTX, "chunk_tokens": CHUNK,
                       "chunks": nchunks, "raw_kv_bytes": raw_bytes, "sharding": f"{world} x independent contexts"},
            "roofline": roofline, "offload": offload, "retrieve": retrieve, "decode": decode, "roundtrip_within_bound": err_ok}
+    if exchange is not None:
+        res["exchange"] = exchange
     if not args.no_cpu_baseline:
         n = args.cpu_chunks or 32
         res["cpu_baseline"] = cpu_baseline(n)

@@ -58,3 +58,65 @@ def test_owner_rank_is_stable():
         counts[owner_rank(k + str(i), 8)] += 1
     assert min(counts) > 50
     assert whole_job_rate([2.0, 2.0], 0.5) == 8.0
+
+
+def _exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lmcache_amd.storage_backend.connector.xgmi_exchange import XgmiShardStore
+    store = XgmiShardStore()
+    assert store.device.type == "cpu" and store.world == world
+
+    def blob_of(key):  # deterministic, ragged sizes
+        g = torch.Generator().manual_seed(sum(key.encode()))
+        n = 1000 + (sum(key.encode()) * 37) % 5000
+        return torch.randint(0, 256, (n,), dtype=torch.uint8, generator=g)
+
+    keys = [f"vllm@m@{world}@{r}@{i:04x}" for r in range(world) for i in range(6)]
+    mine = [k for k in keys if k.split("@")[3] == str(rank)]
+    owned_now = store.exchange_put([(k, blob_of(k)) for k in mine])
+    assert owned_now == sum(1 for k in keys if store.owner(k) == rank)
+    assert sorted(store.list_local()) == sorted(k for k in keys if store.owner(k) == rank)
+    # every rank asks for a different mix: all keys rotated by rank, plus two misses
+    want = keys[rank:] + keys[:rank]
+    want.insert(3, "vllm@m@missing@a")
+    want.append("vllm@m@missing@b")
+    got = store.exchange_get(want)
+    assert len(got) == len(want)
+    for k, t in zip(want, got):
+        if "missing" in k:
+            assert t is None
+        else:
+            assert t is not None and torch.equal(t, blob_of(k)), k
+    # an empty request from one rank must not wedge the others
+    got2 = store.exchange_get([] if rank == 0 else keys[:2])
+    assert (got2 == []) if rank == 0 else all(torch.equal(t, blob_of(k)) for k, t in zip(keys[:2], got2))
+    # byte-like inputs are accepted too
+    store.exchange_put([(f"bytes@{rank}", bytes([rank, 1, 2, 3]))])
+    back = store.exchange_get([f"bytes@{r}" for r in range(world)])
+    assert [bytes(t.tolist()) for t in back] == [bytes([r, 1, 2, 3]) for r in range(world)]
+    dist.barrier()
+    q.put(rank)
+    dist.destroy_process_group()
+
+
+def _run_world(target, world, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    return sorted(q.get(timeout=5) for _ in range(world))
+
+
+def test_shard_exchange_world2():
+    assert _run_world(_exchange_worker, 2, 31533 + os.getpid() % 2000) == [0, 1]
+
+
+def test_shard_exchange_world3():
+    assert _run_world(_exchange_worker, 3, 33533 + os.getpid() % 2000) == [0, 1, 2]
