@@ -52,7 +52,7 @@ __device__ __forceinline__ u64 uniform_ptr(const void* p) {  // a pointer every 
 }
 
 template <bool SYMOUT, int DT_OUT, bool PAGED>
-__global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_decode(DecodeArgs a) {
   __shared__ __attribute__((aligned(16))) u8 lds_all[4 * DEC_WAVE_BYTES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform -> SGPRs
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   // ---- CDF rows of this group -> LDS [entry][lane] (coalesced 2-byte loads, transposed LDS writes) ----
   // The blob stores entries 1..R of each row (R = bins - 2); entry 0 is 0 and entries above R are
   // 65504 + i (lmc_format.h).
+  const u32 R = min(30u, max(2u, (u32)__builtin_amdgcn_readfirstlane((int)blob[bo.bins + p]) - 2u));
   {
-    const u32 R = min(30u, max(2u, (u32)__builtin_amdgcn_readfirstlane((int)blob[bo.bins + p]) - 2u));
     const u32 rp = (u32)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const u16*>(blob + bo.rowpre)[p]);
     const float rcpR = 1.0f / (float)R;
     const u32 total = (u32)min(64, a.C - g * 64) * R;
@@ -163,8 +163,14 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   u32 pending = 0;      // loads for [filled, filled + 256) are in flight
   wave_lds_fence();
 
-  // pivots of the first search level live in registers
-  const u32 p8 = cdfT[8 * 64 + lane], p16 = cdfT[16 * 64 + lane], p24 = cdfT[24 * 64 + lane];
+  // The symbol search is a binary search over the lane's CDF column.  Symbols are 0 .. R-1 (R = bins - 2),
+  // so planes with R <= 15 (16 bins: most of them) search entries 0..15 only (TOP = 4), the others 0..31
+  // (TOP = 8).  Its first two levels run on three pivots held in registers.
+  const u16* const col = cdfT + lane;
+  const u32 top = R <= 15u ? 4u : 8u;  // wave-uniform
+  const u16* const colB = col + 2u * top * 64u;
+  const u32 pA = col[top * 64u], pB = colB[0], pC = col[3u * top * 64u];
+  const u32 Lv = active ? LMC_RANS_L : 0u;  // idle lanes never renormalise: x < 0 is never true
 
   // destination: uniform base (SGPRs) + per-lane 32-bit byte offset
   u32 lane_off = 0;
@@ -180,27 +186,37 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   const int tdst0 = a.dst_tok0 + chunk * a.chunk_tokens;
 
   // One token: search, state update, word pop; returns the symbol.
-  auto decode_token = [&]() -> u32 {
+  auto decode_token = [&](auto top_tag) -> u32 {
+    constexpr int TOP = decltype(top_tag)::value;
     u32 slot = x & 0xffffu;
     asm volatile("" : "+v"(slot));  // keep `slot` a plain VGPR: SDWA compares would cost a wait state each
-    // level 1 on register pivots, levels 2-4 on LDS probes; then the symbol's own two CDF entries
-    u32 s = (p8 <= slot ? 8u : 0u) + (p16 <= slot ? 8u : 0u) + (p24 <= slot ? 8u : 0u);
-#pragma unroll
-    for (int step = 4; step >= 1; step >>= 1) {
-      const u32 v = cdfT[(s + step) * 64 + lane];
-      s = v <= slot ? s + step : s;
+    // q walks the column: q = &cdf[s] for the largest probed s with cdf[s] <= slot
+    const bool geB = pB <= slot;
+    const u32 pm = geB ? pC : pA;
+    const u16* q = geB ? colB : col;
+    {
+      const u16* const q2 = q + TOP * 64;
+      q = pm <= slot ? q2 : q;
     }
-    const u32 lo = cdfT[s * 64 + lane], hi = cdfT[s * 64 + 64 + lane];  // entry 32 is 65536 stored as 0
+#pragma unroll
+    for (int step = TOP / 2; step >= 1; step >>= 1) {
+      const u16* const q2 = q + step * 64;
+      const u32 v = *q2;
+      q = v <= slot ? q2 : q;
+    }
+    const u32 lo = q[0], hi = q[64];  // the symbol's own two entries; entry 32 is 65536 stored as 0
+    const u32 s = (u32)(q - col) >> 6;
     const u32 f = (hi - lo) & 0xffffu;
     x = __umul24(f, x >> 16) + slot - lo;
-    const bool need = active && (x < LMC_RANS_L);
+    const bool need = x < Lv;
     const u64 mask = __ballot(need);
-    const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)__popcll(mask));
+    const u32 cnt = (u32)__popcll(mask);
     // the encoder appended this token's words in ascending lane order; counted from the tail that is
     // descending, so rank r of cnt takes consumption index consumed + cnt - 1 - r
-    if (need) x = (x << 16) | (u32)ring[(consumed + cnt - 1u - lane_rank(mask)) & (DEC_RING_WORDS - 1)];
+    const u32 last = consumed + cnt - 1u;
+    if (need) x = (x << 16) | (u32)ring[(last - lane_rank(mask)) & (DEC_RING_WORDS - 1)];
     // the ring bookkeeping is wave-uniform: pin it to SGPRs so its tests are scalar branches
-    consumed = (u32)__builtin_amdgcn_readfirstlane((int)(consumed + cnt));
+    consumed += cnt;
     if (consumed >= trigger) {
       if (pending == 0u) {
         ring_issue(filled);
@@ -219,9 +235,9 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   };
 
   const u32 nskip = SYMOUT ? 0u : (tdst0 < 0 ? min(T, (u32)(-tdst0)) : 0u);  // tokens that land below dst token 0
-  auto run = [&](auto src_tag) {
+  auto run = [&](auto src_tag, auto top_tag) {
     constexpr bool SRC_BF16 = decltype(src_tag)::value;
-    for (u32 t = 0; t < nskip; t++) (void)decode_token();  // retrieve()'s first-chunk trim: decode, do not store
+    for (u32 t = 0; t < nskip; t++) (void)decode_token(top_tag);  // retrieve()'s first-chunk trim: decode, do not store
     long long rowb = (long long)(tdst0 + (int)nskip) * a.dst.stride_token * 2;  // !PAGED: byte offset of the row
     const long long row_step = a.dst.stride_token * 2;
     for (u32 t0 = nskip; t0 < T; t0 += DEC_SCALE_TOKENS) {
@@ -232,7 +248,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
         wave_lds_fence();
       }
       for (u32 t = t0; t < t1; t++) {
-        const u32 s = decode_token();
+        const u32 s = decode_token(top_tag);
         if (SYMOUT) {
           if (active) *((LMC_GLOBAL int8_t*)(ubase + (u64)t * a.C) + lane_off) = (int8_t)s;
         } else {
@@ -251,8 +267,13 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
       }
     }
   };
-  if (src_dtype == (u32)LMC_DTYPE_BF16) run(BoolTag<true>{});
-  else run(BoolTag<false>{});
+  if (src_dtype == (u32)LMC_DTYPE_BF16) {
+    if (top == 4u) run(BoolTag<true>{}, IntTag<4>{});
+    else run(BoolTag<true>{}, IntTag<8>{});
+  } else {
+    if (top == 4u) run(BoolTag<false>{}, IntTag<4>{});
+    else run(BoolTag<false>{}, IntTag<8>{});
+  }
 
   const bool state_bad = active && x != LMC_RANS_L;
   if (consumed != nwords || __ballot(state_bad)) {

@@ -9,14 +9,15 @@
 // wave-private (its LDS slice, its scratch slot), so there is no barrier in
 // this kernel; 4 waves share a workgroup only to share the CU.
 //
-//   pass 1  per-lane histogram in LDS [bin pair][lane] (2 x u16 counters per
-//           dword, ds_add, bank = lane: conflict free)
+//   pass 1  per-lane histogram in LDS, u16 counters [symbol][lane]; lanes 2i and
+//           2i+1 share a dword and add 1 / 1 << 16 with ds_add_u32 (bank = lane / 2)
 //   CDF     cdf[i] = RNE(n_i * 65504 / T) + i, exact integer arithmetic, kept in
 //           LDS as tab[entry][lane] u16 (aliases the dead histogram: 4.2 KiB per
 //           wave -> 8 waves per SIMD) and written to the blob's cdf section with
 //           coalesced 2-byte stores read transposed from LDS
 //   pass 2  tokens T-1..0: renormalise (ballot + mbcnt append of 16-bit words,
 //           ascending lane order), then x = (x/f << 16) + x%f + start
+//           computed as x + (x/f) * (2^16 - f) + start (rans_put)
 //   tail    64 states, zero pad to 16 B, exact length -> glen
 #pragma once
 #include "lmc_device.h"
@@ -92,7 +93,7 @@ __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, c
   }
 }
 
-#define ENC_WAVE_DWORDS 1056  // 4224 B per wave: histogram [16][64] u32, then (aliased) CDF table [33][64] u16
+#define ENC_WAVE_DWORDS 1056  // 4224 B per wave: histogram [32][64] u16, then (aliased) CDF table [33][64] u16
 
 struct PendingTile {
   int chunk, pg;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   // everything derived from the wave id is wave-uniform: keep it in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long ngroups_total = (long long)a.nchunks * a.P * a.G;
-  u32* hist = lds_all + wave * ENC_WAVE_DWORDS;    // [16][64] u32: two u16 counters per dword
+  u32* hist = lds_all + wave * ENC_WAVE_DWORDS;    // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
   u16* tab = reinterpret_cast<u16*>(hist);          // [33][64] u16 CDF, written after hist is in registers
 
   const long long gid = (long long)blockIdx.x * 4 + wave;
@@ -180,6 +181,11 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   // per-token guards; the next block's symbols are loaded while the current one is processed.
 #pragma unroll
   for (int i = 0; i < 16; i++) hist[i * 64 + lane] = 0;
+  // counter of (symbol s, lane) = u16 at [s][lane], the layout of the CDF table that replaces it: the
+  // pair of lanes sharing a dword add 1 and 1 << 16 (a constant per lane, so a symbol costs one bfe and
+  // one shift-add); equal symbols in a pair are serialised by the LDS atomic unit.
+  u32* const hrow = hist + (lane >> 1);
+  const u32 one = 1u << ((lane & 1) * 16);
   if (QUADSYM) {
     const int nfull = Tc >> 5;  // full 32-token blocks
     u32 w[8], wn[8];
@@ -196,8 +202,8 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
       for (int j = 0; j < 8; j++) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const u32 pair = __builtin_amdgcn_ubfe(w[j], 8 * k + 1, 7), odd = __builtin_amdgcn_ubfe(w[j], 8 * k, 1);
-          atomicAdd(&hist[pair * 64 + lane], __umul24(odd, 65535u) + 1u);  // ds_add_u32, bank = lane
+          const u32 sk = __builtin_amdgcn_ubfe(w[j], 8 * k, 8);
+          atomicAdd(&hrow[sk * 32], one);  // ds_add_u32 of this lane's half of the dword, bank = lane / 2
         }
       }
 #pragma unroll
@@ -206,17 +212,17 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
     for (int t = nfull * 32; t < Tc; t++) {  // ragged tail (< 32 tokens)
       const u32 wq = active ? symq[(long long)(t >> 2) * a.C] : 0u;
       const u32 s = (wq >> (8 * (t & 3))) & 0xffu;
-      atomicAdd(&hist[(s >> 1) * 64 + lane], 1u << ((s & 1u) * 16));
+      atomicAdd(&hrow[s * 32], one);
     }
   } else {
     for (int t = 0; t < Tc; t++) {
       const u32 s = active ? min((u32)(u8)symb[(long long)t * a.C], 31u) : 0u;
-      atomicAdd(&hist[(s >> 1) * 64 + lane], 1u << ((s & 1u) * 16));
+      atomicAdd(&hrow[s * 32], one);
     }
   }
-  u32 hreg[16];
+  u32 hreg[16];  // this lane's 32 counts, two per register
 #pragma unroll
-  for (int i = 0; i < 16; i++) hreg[i] = hist[i * 64 + lane];
+  for (int i = 0; i < 16; i++) hreg[i] = (u32)tab[(2 * i) * 64 + lane] | ((u32)tab[(2 * i + 1) * 64 + lane] << 16);
   wave_lds_fence();  // hist is dead from here on: tab aliases it
 
   // ---- CDF ------------------------------------------------------------------
@@ -274,9 +280,7 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
     if (emit) *(LMC_GLOBAL u16*)(outb + ((wcur + lane_rank(mask)) << 1)) = (u16)x;
     x = emit ? xh : x;
     wcur += (u32)__popcll(mask);
-    u32 q, r;
-    divmod_est(x, f, q, r);
-    x = (q << 16) + r + st;
+    x = rans_put(x, f, 0x10000u - f, st);
   };
 
   // ragged head of the descending walk: tokens Tc-1 .. 32*nfull (< 32 of them), one at a time

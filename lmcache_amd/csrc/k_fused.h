@@ -30,8 +30,6 @@
 #include "k_quantize.h"
 
 // Compile-time loop: the register array sym[][] must only ever be indexed by constants.
-template <int I>
-struct IntTag { static constexpr int value = I; };
 template <int N, int I = 0, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -214,9 +212,7 @@ __global__ __launch_bounds__(512 * NITER, 4) void k_fused_encode(FusedArgs a) {
     if (emit) *(LMC_GLOBAL u16*)(outb + ((wcur + lane_rank(mask)) << 1)) = (u16)x;
     x = emit ? xh : x;
     wcur += (u32)__popcll(mask);
-    u32 q, r;
-    divmod_est(x, f, q, r);
-    x = (q << 16) + r + st;
+    x = rans_put(x, f, 0x10000u - f, st);
   };
   const bool full = Tc == 256;
   static_for<QPW>([&](auto rtag) {

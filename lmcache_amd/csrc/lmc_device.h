@@ -168,5 +168,23 @@ __device__ __forceinline__ void divmod_est(u32 x, u32 f, u32& q, u32& r) {
   r = fix ? re - f : re;
 }
 
+// One rANS state update x' = ((x / f) << 16) + (x % f) + st for x < f * 2^16, 1 <= f < 2^16,
+// c = 2^16 - f.  With q = x / f:  x' = x + q * c + st, so only the quotient is needed.
+// qe = trunc(fma(float(x), rcp(f), -0.05)): float(x) is off by <= 2^-24 relative, v_rcp_f32 by
+// <= 1 ulp (2^-23), the fma rounds once (<= 2^-9 absolute below 2^16); with x / f < 2^16 the sum
+// is < 0.014 (< 0.03 even at 4 ulp), so the biased estimate never exceeds x / f and is short of it
+// by < 0.1: qe is q or q - 1, and q = qe + (x >= (qe + 1) * f).  (qe + 1) * f <= x + f < 2^32.
+__device__ __forceinline__ u32 rans_put(u32 x, u32 f, u32 c, u32 st) {
+  const float qf = __builtin_fmaf((float)x, __builtin_amdgcn_rcpf((float)f), -0.05f);
+  const u32 qe = (u32)qf;
+  const u32 q = qe + (x >= __umul24(qe, f) + f ? 1u : 0u);
+  u32 t;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(q), "v"(c), "v"(x));  // q * c + x in one op
+  return t + st;
+}
+
+template <int I>
+struct IntTag { static constexpr int value = I; };  // compile-time integer passed as a value
+
 // e / 33 for e < 8192 (CDF rows are 33 entries)
 __device__ __forceinline__ u32 div33(u32 e) { return (e * 1986u) >> 16; }
