@@ -35,11 +35,11 @@ struct DecodeArgs {
   u32* status;
 };
 
-// per-wave LDS: cdfT [33][64] u16 (4224) | word ring 512 x u16 (1024) | scales 512 x u16 (1024) | lut 32 x f32 (128)
+// per-wave LDS: cdfT [33][64] u16 (4224) | word ring: 64-word mirror prefix + 512 x u16 (1152) | lut 32 x f32 (128)
 #define DEC_CDF_BYTES 4224
-#define DEC_WAVE_BYTES (DEC_CDF_BYTES + 1024 + 1024 + 128)
 #define DEC_RING_WORDS 512
-#define DEC_SCALE_TOKENS 512
+#define DEC_RING_BYTES (2 * (64 + DEC_RING_WORDS))
+#define DEC_WAVE_BYTES (DEC_CDF_BYTES + DEC_RING_BYTES + 128)
 
 template <bool B>
 struct BoolTag { static constexpr bool value = B; };
@@ -61,9 +61,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   if (gid >= (long long)a.nchunks * n) return;
   u8* wl = lds_all + wave * DEC_WAVE_BYTES;
   u16* cdfT = reinterpret_cast<u16*>(wl);                           // [33][64]: entry-major, bank = lane/2
-  u16* ring = reinterpret_cast<u16*>(wl + DEC_CDF_BYTES);           // stream words, by consumption order
-  u16* scs = reinterpret_cast<u16*>(wl + DEC_CDF_BYTES + 1024);     // raw per-token scales (one window)
-  float* lut = reinterpret_cast<float*>(wl + DEC_CDF_BYTES + 2048);  // (q - C) / C
+  u16* ring = reinterpret_cast<u16*>(wl + DEC_CDF_BYTES) + 64;      // stream words by consumption order; ring[-64..-1] mirrors ring[448..511]
+  float* lut = reinterpret_cast<float*>(wl + DEC_CDF_BYTES + DEC_RING_BYTES);  // (q - C) / C
 
   const int chunk = (int)(gid / n);
   const int pg = (int)(gid - (long long)chunk * n);
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
       for (int i = 0; i < 33; i++) cdfT[i * 64 + lane] = (u16)i;
     }
   }
-  // ---- dequantisation LUT; scales are staged one 512-token window at a time inside the loop ----
+  // ---- dequantisation LUT; the per-token scales are fetched 64 tokens at a time inside the loop ----
   const u16* scl = reinterpret_cast<const u16*>(blob + bo.scales) + (long long)p * T;
   if (!SYMOUT && lane < 32) {
     const float Cf = (float)((int)blob[bo.bins + p] / 2 - 1);
@@ -152,6 +151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   auto ring_commit = [&](u32 k0) {
 #pragma unroll
     for (int i = 0; i < 4; i++) ring[(k0 + i * 64 + lane) & (DEC_RING_WORDS - 1)] = pend[i];
+    if (k0 & 256u) ring[lane - 64] = pend[3];  // mirror of ring[448 + lane]: lets the consumer index without a wrap
   };
   ring_issue(0);
   ring_commit(0);
@@ -166,10 +166,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   // The symbol search is a binary search over the lane's CDF column.  Symbols are 0 .. R-1 (R = bins - 2),
   // so planes with R <= 15 (16 bins: most of them) search entries 0..15 only (TOP = 4), the others 0..31
   // (TOP = 8).  Its first two levels run on three pivots held in registers.
-  const u16* const col = cdfT + lane;
+  typedef const __attribute__((address_space(3))) u16* lds_u16p;  // 32-bit LDS pointers: no generic-pointer math
+  const lds_u16p col = (lds_u16p)cdfT + lane;
   const u32 top = R <= 15u ? 4u : 8u;  // wave-uniform
-  const u16* const colB = col + 2u * top * 64u;
+  const lds_u16p colB = col + 2u * top * 64u;
   const u32 pA = col[top * 64u], pB = colB[0], pC = col[3u * top * 64u];
+  typedef const __attribute__((address_space(3))) float* lds_f32p;
+  const u32 col_addr = (u32)(size_t)col;
+  const u32 lut_bias = col_addr - ((u32)(size_t)(lds_f32p)lut << 5);
+  const lds_u16p ringl = (lds_u16p)ring;
   const u32 Lv = active ? LMC_RANS_L : 0u;  // idle lanes never renormalise: x < 0 is never true
 
   // destination: uniform base (SGPRs) + per-lane 32-bit byte offset
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   }
   const int tdst0 = a.dst_tok0 + chunk * a.chunk_tokens;
 
-  // One token: search, state update, word pop; returns the symbol.
+  // One token: search, state update, word pop; returns the LDS address of the symbol's CDF entry.
   auto decode_token = [&](auto top_tag) -> u32 {
     constexpr int TOP = decltype(top_tag)::value;
     u32 slot = x & 0xffffu;
@@ -193,19 +198,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
     // q walks the column: q = &cdf[s] for the largest probed s with cdf[s] <= slot
     const bool geB = pB <= slot;
     const u32 pm = geB ? pC : pA;
-    const u16* q = geB ? colB : col;
+    lds_u16p q = geB ? colB : col;
     {
-      const u16* const q2 = q + TOP * 64;
+      const lds_u16p q2 = q + TOP * 64;
       q = pm <= slot ? q2 : q;
     }
 #pragma unroll
     for (int step = TOP / 2; step >= 1; step >>= 1) {
-      const u16* const q2 = q + step * 64;
+      const lds_u16p q2 = q + step * 64;
       const u32 v = *q2;
       q = v <= slot ? q2 : q;
     }
     const u32 lo = q[0], hi = q[64];  // the symbol's own two entries; entry 32 is 65536 stored as 0
-    const u32 s = (u32)(q - col) >> 6;
+    const u32 qa = (u32)(size_t)q;
     const u32 f = (hi - lo) & 0xffffu;
     x = __umul24(f, x >> 16) + slot - lo;
     const bool need = x < Lv;
@@ -213,8 +218,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
     const u32 cnt = (u32)__popcll(mask);
     // the encoder appended this token's words in ascending lane order; counted from the tail that is
     // descending, so rank r of cnt takes consumption index consumed + cnt - 1 - r
-    const u32 last = consumed + cnt - 1u;
-    if (need) x = (x << 16) | (u32)ring[(last - lane_rank(mask)) & (DEC_RING_WORDS - 1)];
+    const int last = (int)((consumed + cnt - 1u) & (DEC_RING_WORDS - 1));  // scalar; last - rank is in [-63, 511]
+    if (need) x = (x << 16) | (u32)ringl[last - (int)lane_rank(mask)];
     // the ring bookkeeping is wave-uniform: pin it to SGPRs so its tests are scalar branches
     consumed += cnt;
     if (consumed >= trigger) {
@@ -231,38 +236,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
         wave_lds_fence();
       }
     }
-    return s;
+    return qa;
   };
 
   const u32 nskip = SYMOUT ? 0u : (tdst0 < 0 ? min(T, (u32)(-tdst0)) : 0u);  // tokens that land below dst token 0
   auto run = [&](auto src_tag, auto top_tag) {
     constexpr bool SRC_BF16 = decltype(src_tag)::value;
     for (u32 t = 0; t < nskip; t++) (void)decode_token(top_tag);  // retrieve()'s first-chunk trim: decode, do not store
-    long long rowb = (long long)(tdst0 + (int)nskip) * a.dst.stride_token * 2;  // !PAGED: byte offset of the row
+    // !PAGED: the row of token t starts at rowp (uniform), one stride_token further each token
+    LMC_GLOBAL u8* rowp = (LMC_GLOBAL u8*)ubase + (long long)(tdst0 + (int)nskip) * a.dst.stride_token * 2;
     const long long row_step = a.dst.stride_token * 2;
-    for (u32 t0 = nskip; t0 < T; t0 += DEC_SCALE_TOKENS) {
-      const u32 t1 = min(T, t0 + (u32)DEC_SCALE_TOKENS);
-      if (!SYMOUT) {
-        wave_lds_fence();
-        for (u32 t = t0 + lane; t < t1; t += 64) scs[t - t0] = scl[t];
-        wave_lds_fence();
-      }
+    // per-token scales: lane i of `sc` holds the fp32 scale of token t0 + i (64 tokens per block), fetched with
+    // one coalesced load a block ahead and handed to all lanes with v_readlane
+    auto scale_bits = [&](u32 tb) -> u32 { return (!SYMOUT && tb + lane < T) ? (u32)scl[tb + lane] : 0u; };
+    auto scale_f32 = [&](u32 sb) -> float {
+      return SRC_BF16 ? __uint_as_float(sb << 16) : (float)__builtin_bit_cast(_Float16, (unsigned short)sb);
+    };
+    u32 sc_next = scale_bits(nskip);
+    u32 off = lane_off;
+    for (u32 t0 = nskip; t0 < T; t0 += 64) {
+      const u32 t1 = min(T, t0 + 64u);
+      const float sc = scale_f32(sc_next);
+      sc_next = scale_bits(t1);
       for (u32 t = t0; t < t1; t++) {
-        const u32 s = decode_token(top_tag);
+        const u32 qa = decode_token(top_tag);
         if (SYMOUT) {
-          if (active) *((LMC_GLOBAL int8_t*)(ubase + (u64)t * a.C) + lane_off) = (int8_t)s;
+          if (active) *((LMC_GLOBAL int8_t*)(ubase + (u64)t * a.C) + lane_off) = (int8_t)((qa - col_addr) >> 7);
         } else {
+          const float scale = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), (int)(t - t0)));
           if (active) {
-            const u32 sb = scs[t - t0];
-            const float scale = SRC_BF16 ? __uint_as_float(sb << 16) : (float)__builtin_bit_cast(_Float16, (unsigned short)sb);
-            const float val = lut[s] * scale;
+            // lut[s] with s = (qa - col) / 128: its LDS address is ((qa - col) >> 5) + &lut = (qa - lut_bias) >> 5
+            const float val = *(lds_f32p)(size_t)((qa - lut_bias) >> 5) * scale;
             u16 bits;
             if (DT_OUT == LMC_DTYPE_BF16) bits = __builtin_bit_cast(unsigned short, (__bf16)val);  // v_cvt_pk_bf16_f32, RNE
             else bits = (u16)f2fp16(val);
-            const long long row = PAGED ? lmc_tok_off(a.dst, tdst0 + (int)t) * 2 : rowb;
-            *(LMC_GLOBAL u16*)((LMC_GLOBAL u8*)(ubase + (u64)row) + lane_off) = bits;
+            LMC_GLOBAL u8* const row = PAGED ? (LMC_GLOBAL u8*)ubase + lmc_tok_off(a.dst, tdst0 + (int)t) * 2 : rowp;
+            asm volatile("" : "+v"(off));  // keeps the zero-extension next to the store: SGPR base + 32-bit VGPR offset
+            *(LMC_GLOBAL u16*)(row + off) = bits;
           }
-          rowb += row_step;
+          rowp += row_step;
         }
       }
     }
