@@ -1,7 +1,7 @@
 """Backend factory (mirror of lmcache/storage_backend/__init__.py:13-44): the same
 (local_device, remote_url) -> backend decision table and the same ValueError.
 
-  remote only                -> LMCRemoteBackend (serde + connector)
+  remote only                -> LMCRemoteBackend (serde + connector), LMCPipelinedRemoteBackend if pipelined_backend
   local "cpu" / "cuda"       -> LMCLocalBackend  (HBM, pinned raw, or pinned CacheGen via local_serde)
   local path (disk) / hybrid -> outside the hot path (file I/O, orchestration: SURVEY.md section 2 #3, #5)
 """
@@ -15,7 +15,9 @@ logger = init_logger(__name__)
 def CreateStorageBackend(config: LMCacheEngineConfig, metadata: LMCacheEngineMetadata) -> LMCBackendInterface:
     local, remote = config.local_device, config.remote_url
     if local is None and remote is not None:
-        from lmcache_amd.storage_backend.remote_backend import LMCRemoteBackend
+        from lmcache_amd.storage_backend.remote_backend import LMCPipelinedRemoteBackend, LMCRemoteBackend
+        if config.pipelined_backend:  # lmcache/storage_backend/hybrid_backend.py:30-33 makes the same choice
+            return LMCPipelinedRemoteBackend(config, metadata)
         return LMCRemoteBackend(config, metadata)
     if local is not None and remote is None:
         if local in ("cpu", "cuda"):

@@ -3,7 +3,7 @@
 Mirror of lmcache/storage_backend/remote_backend.py:23-180: the ONLY caller of
 the CacheGen serde in the reference (put_blocking :119-126, get :154-168), with
 the same async-put worker thread (:51-69) and existing-keys cache (:111-117).
-The pipelined variant (:183-275) is a "next" row.
+The pipelined variant (:183-275) is LMCPipelinedRemoteBackend below.
 """
 import queue
 import threading
@@ -98,3 +98,173 @@ class LMCRemoteBackend(LMCBackendInterface):
             self.close()
         except Exception:
             pass
+
+
+class LMCPipelinedRemoteBackend(LMCRemoteBackend):
+    """Pipelined retrieve: mirror of LMCPipelinedRemoteBackend
+    (lmcache/storage_backend/remote_backend.py:183-275).
+
+    The reference runs a network thread and a deserialise thread joined through Python queues and
+    returns `result_list` -- which silently drops misses, so results no longer line up with the keys
+    (:224-226, :238-243).  Here:
+
+      * one fetch thread pulls blobs from the connector (blocking I/O is what a thread is for);
+      * everything after the bytes arrive is stream work, not thread work: blobs are staged through
+        pinned memory, copied H2D on the side stream and decoded on the caller's stream, ordered by
+        events (CacheGenDeviceCodec.decode) -- the fetch of blob k+1 overlaps the copy and the decode
+        of blob k;
+      * `batched_get` returns one entry PER KEY (None for a miss);
+      * with remote_serde == "cachegen" the backend speaks the engine's range protocol
+        (put_kv_range / chunk_meta / get_kv_range): chunks are encoded straight from the per-layer KV
+        tensors and decoded straight into the caller's output tensor, no per-chunk tensors in between.
+    """
+
+    def __init__(self, config: LMCacheEngineConfig, metadata: LMCacheEngineMetadata):
+        super().__init__(config, metadata)
+        from concurrent.futures import ThreadPoolExecutor
+        self.fmt = metadata.fmt
+        self.supports_kv_layout = config.remote_serde == "cachegen"
+        self.cachegen_config = None
+        if self.supports_kv_layout:
+            from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
+            self.cachegen_config = CacheGenConfig.from_model_name(metadata.model_name)
+        self.fetch_batch = 8                      # blobs handed to one decode call at most
+        self._fetcher = ThreadPoolExecutor(max_workers=1, thread_name_prefix="lmc-fetch")
+        self._prefetched = {}                     # key -> bytes fetched by chunk_meta, consumed by the next read
+        self._host_arena = None
+
+    # ---- fetch stage ---------------------------------------------------------------------------------
+    def _fetch_into(self, keys, out_q: "queue.Queue") -> None:
+        try:
+            for idx, key in enumerate(keys):
+                bs = self._prefetched.pop(key, None)
+                if bs is None and self.contains(key):
+                    bs = self.connection.get(key.to_string())
+                out_q.put((idx, bs if bs else None))
+        except Exception as e:  # hand the failure to the consumer instead of dying silently
+            out_q.put(e)
+        out_q.put(RemoteBackendEndSignal())
+
+    def _arrivals(self, keys):
+        """Yield (idx, bytes-or-None) in key order while the fetch thread runs ahead."""
+        q: "queue.Queue" = queue.Queue()
+        self._fetcher.submit(self._fetch_into, list(keys), q)
+        while True:
+            item = q.get()
+            if isinstance(item, RemoteBackendEndSignal):
+                return
+            if isinstance(item, Exception):
+                raise item
+            yield item
+
+    # ---- reference API ---------------------------------------------------------------------------------
+    @_lmcache_nvtx_annotate
+    def batched_get(self, keys):
+        results: List[Optional[torch.Tensor]] = []
+        for _, bs in self._arrivals(keys):
+            results.append(None if bs is None else self.deserializer.from_bytes(bs).to(self.dst_device))
+        return results
+
+    # ---- range protocol (cachegen serde) ------------------------------------------------------------------
+    def chunk_meta(self, key: CacheEngineKey):
+        from lmcache_amd import native
+        from lmcache_amd.storage_backend.serde.cachegen_decoder import output_spec
+        bs = self._prefetched.get(key)
+        if bs is None:
+            bs = self.connection.get(key.to_string())
+            if not bs:
+                raise KeyError(key)
+            self._prefetched[key] = bs
+        h = native.blob_info(bs)
+        return output_spec(self.fmt, h.num_layers, h.ntokens, h.num_heads, h.head_size)
+
+    def put_kv_range(self, keys, src, fmt: str, tok_begin: int, tok_end: int, chunk_tokens: int,
+                     blocking: bool = True) -> int:
+        from lmcache_amd.storage_backend.serde.cachegen_device import PinnedArena, get_codec
+        n = (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
+        assert n == len(keys), "one key per chunk"
+        if n == 0:
+            return 0
+        codec = get_codec(src.device.index)
+        with torch.cuda.device(src.device):
+            job = codec.encode(src, tok_begin, tok_end, chunk_tokens, self.cachegen_config.plane_bins(src.L))
+        # drain the device arena now (the next encode reuses it); only the connector writes may be deferred
+        sizes = codec.sizes_of(job)
+        if self._host_arena is None:
+            self._host_arena = PinnedArena(slab_bytes=max(64 << 20, sum(sizes) + (1 << 20)))
+        self._host_arena.reset()
+        blobs, done = codec.offload(job, sizes, self._host_arena)
+        done.synchronize()
+        payload = _DeferredSets([(k, hb.tobytes()) for k, hb in zip(keys, blobs)])
+        if blocking:
+            self._apply_sets(payload)
+        else:
+            self.put_queue.put(payload)
+        return n
+
+    def get_kv_range(self, keys, dst, fmt: str, dst_tok0: int, chunk_tokens: int) -> None:
+        """Decode chunk i (stored under keys[i]) into dst tokens dst_tok0 + i*chunk_tokens ...; every key
+        must be present (the engine probes `contains` first)."""
+        from lmcache_amd.storage_backend.serde.cachegen_device import get_codec
+        codec = get_codec(dst.device.index)
+        batch, first = [], 0
+
+        def flush():
+            nonlocal batch, first
+            if batch:
+                with torch.cuda.device(dst.device):
+                    codec.decode(batch, dst, dst_tok0 + first * chunk_tokens, chunk_tokens)
+                first += len(batch)
+                batch = []
+
+        q: "queue.Queue" = queue.Queue()
+        self._fetcher.submit(self._fetch_into, list(keys), q)
+        while True:
+            item = q.get()
+            if isinstance(item, RemoteBackendEndSignal):
+                break
+            if isinstance(item, Exception):
+                raise item
+            idx, bs = item
+            if bs is None:
+                raise KeyError(f"chunk {idx} of the requested range is not in the remote store")
+            batch.append(bs)
+            # decode what has arrived as soon as the fetch thread falls behind, or a full batch is there
+            if len(batch) >= self.fetch_batch or q.empty():
+                flush()
+        flush()
+
+    def _apply_sets(self, item: "_DeferredSets") -> None:
+        for key, bs in item.payload:
+            self.connection.set(key.to_string(), bs)
+            self.existing_keys.add(key)
+
+    def put_worker(self):
+        if self._cuda_device is not None:
+            torch.cuda.set_device(self._cuda_device)
+        while True:
+            item = self.put_queue.get()
+            if isinstance(item, RemoteBackendEndSignal):
+                break
+            try:
+                if isinstance(item, _DeferredSets):
+                    self._apply_sets(item)
+                else:
+                    key, value = item
+                    self.put_blocking(key, value)
+            except Exception:
+                logger.exception("asynchronous remote put failed")
+
+    def close(self):
+        super().close()
+        if getattr(self, "_fetcher", None) is not None:
+            self._fetcher.shutdown(wait=True)
+            self._fetcher = None
+        if getattr(self, "_host_arena", None) is not None:
+            self._host_arena.close()
+            self._host_arena = None
+
+
+class _DeferredSets:
+    def __init__(self, payload):
+        self.payload = payload

@@ -134,7 +134,8 @@ def make_cfg(backend, chunk_size=256):
         return LMCacheEngineConfig.from_legacy(chunk_size=chunk_size, backend="cpu", local_serde="cachegen")
     if backend.startswith("mem://"):
         serde = "cachegen" if backend.endswith("1") else "torch"
-        return LMCacheEngineConfig.from_legacy(chunk_size=chunk_size, backend=backend, remote_serde=serde)
+        return LMCacheEngineConfig.from_legacy(chunk_size=chunk_size, backend=backend, remote_serde=serde,
+                                               pipelined_backend="pipe" in backend)
     return LMCacheEngineConfig.from_legacy(chunk_size=chunk_size, backend=backend)
 
 
@@ -156,7 +157,7 @@ def test_retrieve_device(backend, src_device):
 
 
 @pytest.mark.parametrize("fmt", ["vllm", "huggingface"])
-@pytest.mark.parametrize("backend", ["cuda", "cpu", "mem://lossless:0"])
+@pytest.mark.parametrize("backend", ["cuda", "cpu", "mem://lossless:0", "mem://losslesspipe:0"])
 def test_same_retrieve_store_lossless(fmt, backend):
     """store -> retrieve is bit exact for the lossless paths (tests/test_cache_engine.py:108-151)."""
     num_tokens = 2000
@@ -173,7 +174,7 @@ def test_same_retrieve_store_lossless(fmt, backend):
 
 
 @pytest.mark.parametrize("fmt", ["vllm", "huggingface"])
-@pytest.mark.parametrize("backend", ["cachegen-host", "mem://cachegen:1"])
+@pytest.mark.parametrize("backend", ["cachegen-host", "mem://cachegen:1", "mem://cachegenpipe:1"])
 def test_same_retrieve_store_cachegen_equals_oracle(fmt, backend, oracle):
     """The CacheGen paths return exactly do_dequantize(torch_quant_vectorized(x)) per chunk."""
     num_tokens, cs, nl = 600, 256, 4
@@ -332,3 +333,48 @@ def test_store_asserts():
             engine.store(generate_tokens(10, "cuda"), ())
     finally:
         engine.close()
+
+
+# ------------------------------------------------------------------ pipelined remote backend (row f3)
+def test_pipelined_remote_backend_range_protocol_and_misses(oracle):
+    """LMCPipelinedRemoteBackend: (1) the engine takes the range protocol (encode from the per-layer tensors,
+    decode into the output tensor) and returns what the plain remote backend returns, also for a masked
+    prefix and a non-blocking store; (2) batched_get keeps one entry per key (the reference drops misses,
+    remote_backend.py:224-243)."""
+    from lmcache_amd.storage_backend.remote_backend import LMCPipelinedRemoteBackend
+    fmt, cs, nl, num_tokens = "vllm", 128, 4, 1000
+    tokens = generate_tokens(num_tokens, "cuda")
+    kv_cache = generate_kv_cache(num_tokens, fmt, "cuda", num_layers=nl)
+    plain = LMCacheEngine(make_cfg("mem://plainref:1", cs), dumb_metadata(fmt, MODEL))
+    piped = LMCacheEngine(make_cfg("mem://pipedpipe:1", cs), dumb_metadata(fmt, MODEL))
+    try:
+        assert isinstance(piped.engine_, LMCPipelinedRemoteBackend) and piped.engine_.supports_kv_layout
+        piped.engine_.fetch_batch = 3  # several decode calls per range
+        plain.store(tokens, kv_cache)
+        piped.store(tokens[:300], tuple((k[:300], v[:300]) for k, v in kv_cache), blocking=False)
+        piped.store(tokens, kv_cache)  # skip_existing: only the chunks after the first two are new
+        a, ma = plain.retrieve(tokens)
+        b, mb = piped.retrieve(tokens)
+        assert int(ma.sum()) == int(mb.sum()) == num_tokens
+        for (ka, va), (kb, vb) in zip(a, b):
+            assert torch.equal(ka, kb) and torch.equal(va, vb)
+        # masked prefix: first 200 tokens not wanted -> chunk 1 is trimmed by 72 tokens
+        mask = torch.ones(num_tokens, dtype=torch.bool)
+        mask[:200] = False
+        c, mc = piped.retrieve(tokens, mask)
+        assert int(mc.sum()) == num_tokens - 200
+        for (kb, vb), (kc, vc) in zip(b, c):
+            assert torch.equal(kb[200:], kc) and torch.equal(vb[200:], vc)
+        # batched_get: one entry per key, None for the miss in the middle
+        keys = [piped._make_key(h, fmt) for h in piped._prefix_hash(piped._chunk_tokens(tokens))]
+        bogus = CacheEngineKey(fmt, MODEL, 3, 123, "0" * 64)
+        got = piped.engine_.batched_get(iter([keys[0], bogus, keys[2]]))
+        assert len(got) == 3 and got[1] is None and got[0] is not None and got[2] is not None
+        assert torch.equal(got[2][:, 0], torch.stack([k[2 * cs:3 * cs] for k, _ in b]))
+        with pytest.raises(KeyError):
+            out = torch.empty((nl, 2, cs, 8, 128), dtype=torch.bfloat16, device="cuda")
+            from lmcache_amd import native
+            piped.engine_.get_kv_range([bogus], native.KVLayout.from_chunk(out, fmt), fmt, 0, cs)
+    finally:
+        plain.close()
+        piped.close()

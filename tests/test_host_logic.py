@@ -193,3 +193,42 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "lmc_oracle" in src or "liblmc_oracle" in src:
                     bad.append(fn)
     assert not bad, bad
+
+
+def test_pipelined_remote_backend_keeps_one_result_per_key():
+    """Host logic of LMCPipelinedRemoteBackend (row f3) with the lossless torch serde on CPU tensors:
+    the factory picks it for pipelined_backend=True, batched_get lines results up with the keys (the
+    reference's result_list drops misses, remote_backend.py:224-243), async puts land, close() joins."""
+    import torch
+    from lmcache_amd.config import LMCacheEngineConfig, LMCacheEngineMetadata
+    from lmcache_amd.storage_backend import CreateStorageBackend
+    from lmcache_amd.storage_backend.remote_backend import LMCPipelinedRemoteBackend, LMCRemoteBackend
+    from lmcache_amd.utils import CacheEngineKey
+    meta = LMCacheEngineMetadata("test_model", 1, 0, "vllm", "half")
+    plain = CreateStorageBackend(LMCacheEngineConfig.from_legacy(backend="mem://hostpipe:7", remote_serde="torch"), meta)
+    assert type(plain) is LMCRemoteBackend
+    plain.close()
+    be = CreateStorageBackend(LMCacheEngineConfig.from_legacy(backend="mem://hostpipe:7", remote_serde="torch",
+                                                              pipelined_backend=True), meta)
+    try:
+        assert isinstance(be, LMCPipelinedRemoteBackend) and not be.supports_kv_layout
+        be.dst_device = "cpu"
+        keys = [CacheEngineKey("vllm", "test_model", 1, 0, f"{i:064x}") for i in range(6)]
+        vals = [torch.full((2, 2, 4, 1, 8), float(i), dtype=torch.bfloat16) for i in range(6)]
+        for i in (0, 1, 3):
+            be.put(keys[i], vals[i], blocking=True)
+        be.put(keys[5], vals[5], blocking=False)
+        import time
+        for _ in range(200):
+            if be.contains(keys[5]):
+                break
+            time.sleep(0.01)
+        got = be.batched_get(iter(keys))
+        assert len(got) == 6
+        assert [g is None for g in got] == [False, False, True, False, True, False]
+        for i in (0, 1, 3, 5):
+            assert torch.equal(got[i], vals[i])
+        assert be.batched_get(iter([])) == []
+    finally:
+        be.close()
+    assert be._fetcher is None
