@@ -27,14 +27,24 @@ struct QuantArgs {
   BinsArg bins;
   int tok_begin, tok_end, chunk_tokens, nchunks;
   int P, C, TQ;          // TQ = ceil(chunk_tokens / 4)
-  long long nquads;      // nchunks * P * TQ
+  int pc_limit;          // plane-chunks (chunk * P + plane) to quantise: nchunks * P
   u32* sym4;             // QUAD: [nchunks][P][TQ][C]
   int8_t* sym8;          // !QUAD: [P][T][C]
   u8* scale_base;        // scale of (chunk, p, t) at scale_base + chunk*scale_stride + 2*(p*Tc + t)
   long long scale_stride;
 };
 
-// Regular rows (finite, non-zero max): |x * factor| <= MAX(1 + 2^-23), so the rounded value is 0 .. 2*MAX.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// Regular rows (finite, non-zero max): |x * factor| <= MAX(1 + 2^-23), so z = x*factor + MAX lies in
+// [-MAX 2^-23, 2 MAX + ...] and round-half-even gives 0 .. 2*MAX.  Two elements per instruction with the
+// packed fp32 multiply and add (each rounded on its own: no FMA), and v_cvt_pk_u8_f32 does the RNE
+// conversion, the clamp at 0 (-0.x -> 0) and the byte insertion in one op (probed on gfx950:
+// tools/probes/cvt_pk_u8.hip -- RNE, saturating, NaN -> 0).
+__device__ __forceinline__ f32x2_t quant_z2(float xlo, float xhi, f32x2_t factor2, f32x2_t maxf2) {
+  f32x2_t x = {xlo, xhi};
+  f32x2_t y = x * factor2;  // v_pk_mul_f32, rounded
+  return y + maxf2;         // v_pk_add_f32, rounded separately (-ffp-contract=off)
+}
 __device__ __forceinline__ u32 quant_fast(float x, float factor, float maxf) {
   float y = x * factor;  // rounded
   float z = y + maxf;    // rounded separately (no FMA: -ffp-contract=off)
@@ -49,21 +59,16 @@ __device__ __forceinline__ u32 quant_special(float x, float factor, float maxf) 
   return (__builtin_fabsf(r) < 2147483648.0f) ? ((u32)(int)r & 0xffu) : 0u;
 }
 
-template <int G, int NITER, int DT, bool QUAD>
-__global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
-  constexpr int RPW = LMC_WAVE / G;  // row quads per wave
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane / G, sl = lane % G;
-  long long qid = ((long long)blockIdx.x * 4 + wave) * RPW + sub;
-  const bool qvalid = qid < a.nquads;
-  if (!qvalid) qid = a.nquads - 1;
-  const int q = (int)(qid % a.TQ);
-  const long long pc = qid / a.TQ;
-  const int p = (int)(pc % a.P);
-  const int chunk = (int)(pc / a.P);
-  const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
-  const int Tc = min(a.chunk_tokens, a.tok_end - tok0);
-
+// One row quad (4 consecutive tokens q*4 .. q*4+3 of plane p of one chunk) by the G lanes sl = 0..G-1.
+//   sym4_quad   QUAD: &sym4[chunk][p][q][0]          sym8_plane  !QUAD: &sym8[p][0][0]
+//   scale_quad  &scales[chunk][p][q*4]
+// ROWS (4 or 2): rows loaded and reduced together -- 4 keeps 4*NITER 16-byte loads in flight per lane,
+// 2 halves the registers.
+template <int G, int NITER, int DT, bool QUAD, int ROWS = 4>
+__device__ __forceinline__ void quantize_quad(const KvAddr& src, int p, int tok0, int Tc, int q, bool qvalid, int C,
+                                              float maxf, u32* sym4_quad, int8_t* sym8_plane, u16* scale_quad,
+                                              int sl) {
+  static_assert(ROWS == 2 || ROWS == 4, "row quads are processed in one or two passes");
   // per-lane channel runs (row independent)
   long long coff[NITER];
   int c0[NITER];
@@ -71,110 +76,153 @@ __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
 #pragma unroll
   for (int it = 0; it < NITER; it++) {
     c0[it] = (it * G + sl) * 8;
-    cval[it] = c0[it] < a.C;
-    int h = c0[it] / a.src.D, d = c0[it] - h * a.src.D;
-    coff[it] = (long long)h * a.src.stride_head + d;
+    cval[it] = c0[it] < C;
+    int h = c0[it] / src.D, d = c0[it] - h * src.D;
+    coff[it] = (long long)h * src.stride_head + d;
   }
-
-  const u16* pbase = lmc_plane_base(a.src, p);
-  uint4 v[4][NITER];
-  bool tv[4];
+  const u16* pbase = lmc_plane_base(src, p);
+  const f32x2_t maxf2 = {maxf, maxf};
+  // QUAD: o[it][e] byte r = symbol of (token 4q + r, channel c0[it] + e); bytes of tokens past the end of a
+  // ragged chunk are never read by the coder, so they need no masking
+  u32 o[NITER][8];
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    int t = q * 4 + r;
-    tv[r] = qvalid && t < Tc;
-    const u16* rowp = pbase + (tv[r] ? lmc_tok_off(a.src, tok0 + t) : 0);
+  for (int it = 0; it < NITER; it++)
 #pragma unroll
-    for (int it = 0; it < NITER; it++) {
-      if (tv[r] && cval[it]) v[r][it] = ld_global_u4(rowp + coff[it]);
-      else v[r][it] = make_uint4(0, 0, 0, 0);
-    }
-  }
-
-  // row |x| max on bit patterns
-  u32 mrow[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    u32 m = 0;
-#pragma unroll
-    for (int it = 0; it < NITER; it++) {
-      m = pk_max_u16(m, v[r][it].x & 0x7fff7fffu);
-      m = pk_max_u16(m, v[r][it].y & 0x7fff7fffu);
-      m = pk_max_u16(m, v[r][it].z & 0x7fff7fffu);
-      m = pk_max_u16(m, v[r][it].w & 0x7fff7fffu);
-    }
-    mrow[r] = max(m & 0xffffu, m >> 16);
-  }
-  u32 m01 = mrow[0] | (mrow[1] << 16), m23 = mrow[2] | (mrow[3] << 16);
-#pragma unroll
-  for (int off = 1; off < G; off <<= 1) {
-    m01 = pk_max_u16(m01, (u32)__shfl_xor((int)m01, off));
-    m23 = pk_max_u16(m23, (u32)__shfl_xor((int)m23, off));
-  }
-  mrow[0] = m01 & 0xffffu; mrow[1] = m01 >> 16; mrow[2] = m23 & 0xffffu; mrow[3] = m23 >> 16;
-
-  const float maxf = (float)((int)a.bins.b[p] / 2 - 1);
-
-  // scales: first lane of the group
-  if (sl == 0) {
-    u16* sp = reinterpret_cast<u16*>(a.scale_base + (long long)chunk * a.scale_stride) + ((long long)p * Tc + q * 4);
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-      if (tv[r]) sp[r] = (u16)mrow[r];
-  }
-
-  float factor[4];
-  bool special[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    float sf = h2f_rt(mrow[r], DT);
-    factor[r] = maxf / sf;  // IEEE fp32 division
-    special[r] = !(__builtin_fabsf(factor[r]) < __builtin_inff()) || !(sf < __builtin_inff());
-  }
+    for (int e = 0; e < 8; e++) o[it][e] = 0;
 
 #pragma unroll
-  for (int it = 0; it < NITER; it++) {
-    u32 sy[4][8];
+  for (int r0 = 0; r0 < 4; r0 += ROWS) {
+    uint4 v[ROWS][NITER];
+    bool tv[ROWS];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const u32 w[4] = {v[r][it].x, v[r][it].y, v[r][it].z, v[r][it].w};
+    for (int r = 0; r < ROWS; r++) {
+      int t = q * 4 + r0 + r;
+      tv[r] = qvalid && t < Tc;
+      const u16* rowp = pbase + (tv[r] ? lmc_tok_off(src, tok0 + t) : 0);
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        sy[r][2 * k] = quant_fast(h_lo<DT>(w[k]), factor[r], maxf);
-        sy[r][2 * k + 1] = quant_fast(h_hi<DT>(w[k]), factor[r], maxf);
+      for (int it = 0; it < NITER; it++) {
+        if (tv[r] && cval[it]) v[r][it] = ld_global_u4(rowp + coff[it]);
+        else v[r][it] = make_uint4(0, 0, 0, 0);
       }
-      if (__ballot(special[r])) {  // wave-uniform and rare: redo this row's lanes the careful way
-        if (special[r]) {
+    }
+
+    // row |x| max on bit patterns, two rows per register through the xor-shuffle reduction
+    u32 mrow[ROWS];
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            sy[r][2 * k] = quant_special(h_lo<DT>(w[k]), factor[r], maxf);
-            sy[r][2 * k + 1] = quant_special(h_hi<DT>(w[k]), factor[r], maxf);
+    for (int r = 0; r < ROWS; r++) {
+      u32 m = 0;
+#pragma unroll
+      for (int it = 0; it < NITER; it++) {
+        m = pk_max_u16(m, v[r][it].x & 0x7fff7fffu);
+        m = pk_max_u16(m, v[r][it].y & 0x7fff7fffu);
+        m = pk_max_u16(m, v[r][it].z & 0x7fff7fffu);
+        m = pk_max_u16(m, v[r][it].w & 0x7fff7fffu);
+      }
+      mrow[r] = max(m & 0xffffu, m >> 16);
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r += 2) {
+      u32 m2 = mrow[r] | (mrow[r + 1] << 16);
+#pragma unroll
+      for (int off = 1; off < G; off <<= 1) m2 = pk_max_u16(m2, (u32)__shfl_xor((int)m2, off));
+      mrow[r] = m2 & 0xffffu;
+      mrow[r + 1] = m2 >> 16;
+    }
+
+    // scales: first lane of the group
+    if (sl == 0) {
+#pragma unroll
+      for (int r = 0; r < ROWS; r++)
+        if (tv[r]) scale_quad[r0 + r] = (u16)mrow[r];
+    }
+
+    float factor[ROWS];
+    bool special[ROWS];
+    bool any_special = false;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      float sf = h2f_rt(mrow[r], DT);
+      factor[r] = maxf / sf;  // IEEE fp32 division
+      special[r] = !(__builtin_fabsf(factor[r]) < __builtin_inff()) || !(sf < __builtin_inff());
+      any_special |= special[r];
+    }
+    const bool slow = __ballot(any_special) != 0;  // wave-uniform and rare (zero / inf / NaN rows, ragged tails)
+    // one symbol at a time; special rows follow the CPU float -> int8 conversion of the reference
+    auto sym_of = [&](int r, float x) -> u32 {
+      return (special[r] ? quant_special(x, factor[r], maxf) : quant_fast(x, factor[r], maxf)) & 0xffu;
+    };
+
+#pragma unroll
+    for (int it = 0; it < NITER; it++) {
+      if (!cval[it] || !qvalid) continue;
+      if (QUAD) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+          const u32 w[4] = {v[r][it].x, v[r][it].y, v[r][it].z, v[r][it].w};
+          if (!slow) {  // four chained byte-inserting conversions per output dword
+            const f32x2_t f2 = {factor[r], factor[r]};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const f32x2_t z = quant_z2(h_lo<DT>(w[k]), h_hi<DT>(w[k]), f2, maxf2);
+              o[it][2 * k] = __builtin_amdgcn_cvt_pk_u8_f32(z.x, r0 + r, o[it][2 * k]);
+              o[it][2 * k + 1] = __builtin_amdgcn_cvt_pk_u8_f32(z.y, r0 + r, o[it][2 * k + 1]);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              o[it][2 * k] |= sym_of(r, h_lo<DT>(w[k])) << (8 * (r0 + r));
+              o[it][2 * k + 1] |= sym_of(r, h_hi<DT>(w[k])) << (8 * (r0 + r));
+            }
           }
+        }
+      } else {  // int8 [P][T][C] output of lmc_quantize
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+          if (!tv[r]) continue;
+          const u32 w[4] = {v[r][it].x, v[r][it].y, v[r][it].z, v[r][it].w};
+          u32 lo = 0, hi = 0;
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            lo |= (sym_of(r, h_lo<DT>(w[k])) << (16 * k)) | (sym_of(r, h_hi<DT>(w[k])) << (16 * k + 8));
+            hi |= (sym_of(r, h_lo<DT>(w[k + 2])) << (16 * k)) | (sym_of(r, h_hi<DT>(w[k + 2])) << (16 * k + 8));
+          }
+          int8_t* dst = sym8_plane + ((long long)(q * 4 + r0 + r)) * C + c0[it];
+          *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
         }
       }
     }
-    if (!cval[it] || !qvalid) continue;
-    if (QUAD) {
-      u32 o[8];
+  }
+  if (QUAD && qvalid) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        u32 d = 0;
-#pragma unroll
-        for (int r = 0; r < 4; r++) d |= (tv[r] ? sy[r][e] : 0u) << (8 * r);
-        o[e] = d;
-      }
-      u32* dst = a.sym4 + (((long long)chunk * a.P + p) * a.TQ + q) * a.C + c0[it];
-      *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
-      *reinterpret_cast<uint4*>(dst + 4) = make_uint4(o[4], o[5], o[6], o[7]);  // kernel-arg pointers: global already
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        if (!tv[r]) continue;
-        u32 lo = sy[r][0] | (sy[r][1] << 8) | (sy[r][2] << 16) | (sy[r][3] << 24);
-        u32 hi = sy[r][4] | (sy[r][5] << 8) | (sy[r][6] << 16) | (sy[r][7] << 24);
-        int8_t* dst = a.sym8 + ((long long)p * Tc + (q * 4 + r)) * a.C + c0[it];
-        *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
-      }
+    for (int it = 0; it < NITER; it++) {
+      if (!cval[it]) continue;
+      u32* dst = sym4_quad + c0[it];
+      const uint4 a0 = make_uint4(o[it][0], o[it][1], o[it][2], o[it][3]);
+      const uint4 a1 = make_uint4(o[it][4], o[it][5], o[it][6], o[it][7]);
+      *reinterpret_cast<uint4*>(dst) = a0;  // kernel-arg pointers: global already
+      *reinterpret_cast<uint4*>(dst + 4) = a1;
     }
   }
+}
+
+// grid = (ceil(TQ / (4 * RPW)), P, chunks): plane and chunk come straight from the block index, and with
+// G = 64 (one row quad per wave) everything but the channel offset is wave-uniform and lives in SGPRs.
+template <int G, int NITER, int DT, bool QUAD>
+__global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
+  constexpr int RPW = LMC_WAVE / G;  // row quads per wave
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int sub = lane / G, sl = lane % G;
+  const int p = (int)blockIdx.y, chunk = (int)blockIdx.z;
+  int q = ((int)blockIdx.x * 4 + wave) * RPW + sub;
+  const bool qvalid = q < a.TQ && chunk * a.P + p < a.pc_limit;
+  if (!qvalid) q = 0;
+  const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
+  const int Tc = min(a.chunk_tokens, a.tok_end - tok0);
+  const float maxf = (float)((int)a.bins.b[p] / 2 - 1);
+  u16* scale_quad =
+      reinterpret_cast<u16*>(a.scale_base + (long long)chunk * a.scale_stride) + ((long long)p * Tc + q * 4);
+  u32* sym4_quad = QUAD ? a.sym4 + (((long long)chunk * a.P + p) * a.TQ + q) * a.C : nullptr;
+  int8_t* sym8_plane = QUAD ? nullptr : a.sym8 + (long long)p * Tc * a.C;
+  quantize_quad<G, NITER, DT, QUAD>(a.src, p, tok0, Tc, q, qvalid, a.C, maxf, sym4_quad, sym8_plane, scale_quad, sl);
 }

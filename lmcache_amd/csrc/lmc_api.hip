@@ -186,12 +186,13 @@ static bool bins_ok(const int32_t* bins_h, int P, BinsArg* out) {
 template <int DT, bool QUAD>
 static int launch_quant_dt(const QuantArgs& a, hipStream_t s) {
   const int C = a.C;
-  long long nq = a.nquads;
+  if (a.pc_limit < 1) return LMC_OK;
+  const unsigned nz = (unsigned)((a.pc_limit + a.P - 1) / a.P);  // chunks that hold the plane-chunks to do
 #define LQ(G, N)                                                                                   \
   do {                                                                                             \
-    long long per_wg = 4LL * (64 / (G));                                                           \
-    unsigned grid = (unsigned)((nq + per_wg - 1) / per_wg);                                        \
-    hipLaunchKernelGGL((k_quantize<G, N, DT, QUAD>), dim3(grid), dim3(256), 0, s, a);              \
+    const int per_wg = 4 * (64 / (G));                                                             \
+    dim3 grid((unsigned)((a.TQ + per_wg - 1) / per_wg), (unsigned)a.P, nz);                        \
+    hipLaunchKernelGGL((k_quantize<G, N, DT, QUAD>), grid, dim3(256), 0, s, a);                    \
   } while (0)
   if (C <= 128) LQ(16, 1);
   else if (C <= 256) LQ(32, 1);
@@ -265,7 +266,7 @@ int lmc_quantize(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_
   a.C = src->num_heads * src->head_size;
   a.tok_begin = tok_begin; a.tok_end = tok_begin + ntok; a.chunk_tokens = ntok; a.nchunks = 1;
   a.TQ = (ntok + 3) / 4;
-  a.nquads = (long long)a.P * a.TQ;
+  a.pc_limit = a.P;
   a.sym8 = sym_out;
   a.scale_base = (u8*)scale_out; a.scale_stride = 0;
   HIP_TRY(hipSetDevice(c->device));
@@ -324,7 +325,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     memset(&qa, 0, sizeof qa);
     qa.src = to_addr(src); qa.bins = bins;
     qa.tok_begin = tb; qa.tok_end = tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = nc;
-    qa.P = P; qa.C = C; qa.TQ = TQ; qa.nquads = (long long)nc * P * TQ;
+    qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = nc * P;
     qa.sym4 = c->sym4 + (long long)w0 * P * TQ * C;
     qa.scale_base = blobs_b + hl.off_scales;  // off_scales does not depend on T
     qa.scale_stride = (long long)blob_stride;

@@ -37,7 +37,7 @@ struct BinsArg {
 };
 
 __device__ __forceinline__ const u16* lmc_plane_base(const KvAddr& a, int p) {
-  int kv = p / a.L, l = p - kv * a.L;
+  int kv = p >= a.L ? 1 : 0, l = p - kv * a.L;  // planes are K of every layer, then V (P = 2L)
   if (a.plane_ptrs) return a.plane_ptrs[2 * l + kv];
   return a.base + (long long)l * a.stride_layer + (long long)kv * a.stride_kv;
 }

@@ -280,33 +280,63 @@ def test_long_chunks_and_denormal_scales(nat, ctx, oracle, case):
 
 @pytest.mark.parametrize("shape", [(2, 256, 8, 128, torch.bfloat16), (3, 236, 8, 128, torch.float16),
                                    (2, 100, 4, 128, torch.bfloat16), (1, 256, 4, 128, torch.float16),
-                                   (2, 5, 8, 128, torch.bfloat16), (1, 129, 16, 64, torch.bfloat16)])
+                                   (2, 5, 8, 128, torch.bfloat16), (1, 129, 16, 64, torch.bfloat16),
+                                   (4, 64, 8, 128, torch.bfloat16), (3, 40, 8, 64, torch.float16)])
 def test_fused_and_general_encoders_agree_with_oracle(nat, ctx, oracle, shape):
     """k_fused_encode (C = 512 / 1024, T <= 256) and the general k_quantize + k_cdf_encode path must both
     produce the oracle's bytes; multi-chunk with a ragged tail and edge rows included."""
     L, T, H, D, dt = shape
     g = torch.Generator().manual_seed(T * 7 + H)
-    Ttot = 2 * T + 37 if T >= 100 else T  # several chunks + short tail for the larger cases
+    Ttot = 6 * T + 37 if T >= 40 else T  # several chunks + short tail for the larger cases
     kv = torch.randn(L, 2, Ttot, H, D, generator=g).to(dt)
     kv[0, 0, 0] = 0                      # all-zero row -> "special" path
     if Ttot > 3:
         kv[0, 1, 2, 0, 0] = float("inf")
     bins = default_bins(L)
     lay = nat.KVLayout.from_chunk(kv.to(DEV), "vllm")
+    got = {}
     try:
-        ctx.set_fused(True)
-        fused, _, _ = encode(nat, ctx, lay, 0, Ttot, T, bins)
-        ctx.set_fused(False)
-        general, _, _ = encode(nat, ctx, lay, 0, Ttot, T, bins)
+        for fused in (True, False):
+            ctx.set_fused(fused)
+            got[fused], _, _ = encode(nat, ctx, lay, 0, Ttot, T, bins)
     finally:
         ctx.set_fused(False)
-    assert len(fused) == len(general)
-    for i, (a, b) in enumerate(zip(fused, general)):
+    for i in range(len(got[False])):
         t0, t1 = i * T, min(Ttot, (i + 1) * T)
         bits, code = oracle.torch_to_bits(kv[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
         ref = oracle.encode_blob(bits, code, H, D, np.array(bins, np.int32))
-        assert a == ref, f"fused chunk {i}"
-        assert b == ref, f"general chunk {i}"
+        for fused, blobs in got.items():
+            assert len(blobs) == len(got[False])
+            assert blobs[i] == ref, f"fused={fused} chunk {i}"
+
+
+def test_encode_repeated_on_changing_paged_data(nat, ctx, oracle):
+    """The encode workspace (symbols, scratch streams, look-back granules) is re-used by every call: encode
+    repeatedly from a paged source whose data and block table change (a stale read would show as a wrong blob)."""
+    L, T, H, D, nchunks, bs = 4, 64, 8, 128, 7, 16
+    ntok = nchunks * T - 9
+    bins = default_bins(L)
+    nblocks = (ntok + bs - 1) // bs + 3
+    g = torch.Generator().manual_seed(77)
+    try:
+        for it in range(4):
+            kv = torch.randn(L, 2, ntok, H, D, generator=g).to(torch.bfloat16)
+            perm = torch.randperm(nblocks, generator=g)
+            slot = torch.empty(ntok, dtype=torch.int64)
+            for t in range(ntok):
+                slot[t] = perm[t // bs] * bs + t % bs
+            paged = torch.zeros(L, 2, nblocks, bs, H, D, dtype=torch.bfloat16)
+            for t in range(ntok):
+                paged[:, :, slot[t] // bs, slot[t] % bs] = kv[:, :, t]
+            caches = [paged[l].contiguous().to(DEV) for l in range(L)]
+            lay = nat.KVLayout.paged(caches, slot, bs, "NBHD")
+            blobs, _, _ = encode(nat, ctx, lay, 0, ntok, T, bins)
+            for i, b in enumerate(blobs):
+                t0, t1 = i * T, min(ntok, (i + 1) * T)
+                bits, code = oracle.torch_to_bits(kv[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
+                assert b == oracle.encode_blob(bits, code, H, D, np.array(bins, np.int32)), f"iter {it} chunk {i}"
+    finally:
+        pass
 
 
 def test_llama70b_tp8_rank_shape(nat, ctx, oracle):
