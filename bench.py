@@ -93,7 +93,6 @@ def main():
     ap.add_argument("--exchange", action="store_true",
                     help="N>1 only, opt-in: time one RCCL/xGMI exchange step of the encoded chunks between ranks "
                          "(XgmiShardStore; outside the timed region, reported as `exchange`)")
-    ap.add_argument("--fused", action="store_true", help="use the fused tile encoder (half the HBM traffic, ~4 %% slower)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,7 +116,6 @@ def main():
     blobs = torch.empty(nchunks * stride, dtype=torch.uint8, device=dev)
     sizes = torch.zeros(nchunks, dtype=torch.int32, device=dev)
     ctx.reserve(L, H, D, CHUNK, nchunks)
-    ctx.set_fused(args.fused)
     raw_bytes = L * 2 * CTX * H * D * 2
 
     stream = torch.cuda.Stream(device=dev)
@@ -205,8 +203,7 @@ def main():
 
     # per-kernel HIP-event timing on the launch stream (lmc_ctx_profile)
     ctx.profile(True)
-    knames = (["k_fused_encode", "(coder folded into k_fused_encode)", "k_scan_finalize", "k_pack_streams"]
-              if args.fused else ["k_quantize", "k_cdf_encode"])
+    knames = ["k_quantize", "k_cdf_encode"]
     ksum = np.zeros(len(knames))
     reps = max(3, min(10, args.steps))
     for _ in range(reps):

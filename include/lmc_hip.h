@@ -102,19 +102,12 @@ int lmc_ctx_reserve(lmc_ctx* ctx, int L, int H, int D, int chunk_tokens, int max
  * event / stream sync by the caller).  `clear` resets it. */
 int lmc_device_status(lmc_ctx* ctx, int clear);
 
-/* enable = 1: lmc_encode_chunks uses the fused tile kernel (quantise + CDF + coder in one launch, symbols
- * kept in registers/LDS) when the geometry allows: C = 512 or 1024 channels and chunks of at most 256
- * tokens.  It writes the same bytes as the general three-kernel path (the tests cross-check both) and moves
- * only the algorithmic HBM bytes (no symbol round trip), but measured ~4 % slower standalone on MI355X, so
- * the default is 0; it is the better choice when the encode shares HBM with a bandwidth-bound model step. */
-int lmc_ctx_set_fused(lmc_ctx* ctx, int enable);
-
 /* Per-kernel timing of the NEXT lmc_encode_chunks / lmc_decode_chunks calls:
  * when enabled the call brackets each of its kernels with hipEvents on the
  * caller's stream.  lmc_ctx_profile_read (after the caller has synchronised
  * that stream) returns the durations in ms of the last profiled call, in
  * launch order (encode: k_quantize, k_cdf_encode [which also compacts the streams into the
- * blob]; with lmc_ctx_set_fused: k_fused_encode, ~0, k_scan_finalize, k_pack_streams; decode: k_decode) and the number of entries written (<= cap). */
+ * blob]; decode: k_decode) and the number of entries written (<= cap). */
 int lmc_ctx_profile(lmc_ctx* ctx, int enable);
 int lmc_ctx_profile_read(lmc_ctx* ctx, float* ms_out, int cap);
 

@@ -18,7 +18,8 @@
 //   pass 2  tokens T-1..0: renormalise (ballot + mbcnt append of 16-bit words,
 //           ascending lane order), then x = (x/f << 16) + x%f + start
 //           computed as x + (x/f) * (2^16 - f) + start (rans_put)
-//   tail    64 states, zero pad to 16 B, exact length -> glen
+//   tail    64 states, zero pad to 16 B; then the stream is moved to its final place in the blob
+//           (compact_stream: single-pass prefix over the group lengths of the chunk)
 #pragma once
 #include "lmc_device.h"
 
@@ -34,7 +35,6 @@ struct EncodeArgs {
   u16* cdf_out;         // !ENCODE: [P][C][33]
   u8* scratch;          // [nchunks*P*G][cap] padded group streams
   u32 cap;              // bytes per scratch slot
-  u32* glen;            // [nchunks*P*G] exact stream bytes
   u32* status;
   BinsArg bins;         // ENCODE: bins and CDF row prefix per plane
   // in-kernel stream compaction (single-pass prefix over the padded group lengths of a chunk)
@@ -104,8 +104,7 @@ struct PendingTile {
 // In-kernel compaction: where does a finished stream go?  Single-pass prefix sum over the padded lengths of
 // the chunk's P*G groups (decoupled look-back): every wave publishes its length as soon as a stream is coded,
 // and later looks back over its predecessors' granules until it meets an inclusive prefix, publishes its own
-// inclusive prefix, then moves the stream from its scratch slot to its final place.  Replaces
-// k_scan_finalize + k_pack_streams behind this kernel (the cumsum + gather of collect_bytes,
+// inclusive prefix, then moves the stream from its scratch slot to its final place (the cumsum + gather of collect_bytes,
 // cachegen_encoder.py:230-238).  Predecessors have lower stream ids: they were taken by workgroups dispatched
 // no later than ours, in an earlier or the same round, and never wait on us.
 __device__ __forceinline__ void compact_stream(const EncodeArgs& a, const PendingTile& t, int lane) {
@@ -152,7 +151,7 @@ __device__ __forceinline__ void compact_stream(const EncodeArgs& a, const Pendin
   }
 }
 
-template <bool QUADSYM, bool ENCODE, bool COMPACT>
+template <bool QUADSYM, bool ENCODE>
 __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   __shared__ __attribute__((aligned(16))) u32 lds_all[4 * ENC_WAVE_DWORDS];
   const int lane = threadIdx.x & 63;
@@ -334,10 +333,6 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   const u32 padw = ((16u - (exact & 15u)) & 15u) >> 1;
   if ((u32)lane < padw) out[wcur + lane] = 0;
   if (lane == 0 && exact + 16 > a.cap) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);
-  if (!COMPACT) {
-    if (lane == 0) a.glen[gid] = exact;
-    return;
-  }
   // publish this stream's padded length, then compact it (waits for predecessors that are still coding)
   {
     const int n = a.P * a.G;
@@ -346,124 +341,4 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
     if (lane == 0 && t.pg > 0) agg_store(a.agg + (long long)chunk * n + t.pg, AGG_A, (exact + 15u) & ~15u);
     compact_stream(a, t, lane);
   }
-}
-
-// ---------------------------------------------------------------------------
-// Per chunk: exclusive scan of the 16-B padded group lengths -> gend table,
-// stream offsets for the pack kernel, header, bins, zeroed section pads, size.
-// Replaces the cumsum/roll of collect_bytes (cachegen_encoder.py:230-236) and
-// the cumsum the decoder would otherwise redo (cachegen_decoder.py:62-64).
-struct ScanArgs {
-  u8* blobs;
-  long long blob_stride;
-  const u32* glen;   // [nchunks][P*G]
-  u32* goff;         // [nchunks][P*G] start offset (relative to streams) of each group
-  u32* sizes;        // [nchunks]
-  BinsArg bins;
-  int tok_begin, tok_end, chunk_tokens;
-  int L, H, D, P, C, G, dtype;
-};
-
-__global__ __launch_bounds__(1024) void k_scan_finalize(ScanArgs a) {
-  __shared__ u32 wsum[16];
-  __shared__ u32 carry_s;
-  const int chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
-  const u32 T = (u32)min(a.chunk_tokens, a.tok_end - tok0);
-  const int n = a.P * a.G;
-  u8* blob = a.blobs + (long long)chunk * a.blob_stride;
-  const u32 cdf_rows = a.bins.rowpre[a.P];
-  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, cdf_rows);
-  u32* gend = reinterpret_cast<u32*>(blob + bo.gend);
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    const u32 len = i < n ? a.glen[(long long)chunk * n + i] : 0u;
-    const u32 padded = (len + 15u) & ~15u;
-    u32 incl = padded;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      u32 v = (u32)__shfl_up((int)incl, off);
-      if (lane >= off) incl += v;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    u32 wbase = 0;
-    for (int w = 0; w < wave; w++) wbase += wsum[w];
-    const u32 carry = carry_s;
-    const u32 excl = carry + wbase + incl - padded;
-    if (i < n) {
-      gend[i] = excl + len;
-      a.goff[(long long)chunk * n + i] = excl;
-    }
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + wbase + incl;
-    __syncthreads();
-  }
-  const u32 stream_bytes = carry_s;
-  // bins + zeroed pads (the oracle memsets the static region)
-  for (u32 i = tid; i < bo.rowpre - bo.bins; i += 1024) blob[bo.bins + i] = i < (u32)a.P ? a.bins.b[i] : (u8)0;
-  for (u32 i = tid; i < (bo.scales - bo.rowpre) / 2; i += 1024)
-    reinterpret_cast<u16*>(blob + bo.rowpre)[i] = i <= (u32)a.P ? a.bins.rowpre[i] : (u16)0;
-  for (u32 i = bo.scales + 2u * a.P * T + tid; i < bo.cdf; i += 1024) blob[i] = 0;
-  for (u32 i = bo.gend + 4u * n + tid; i < bo.streams; i += 1024) blob[i] = 0;
-  if (tid < 32) {
-    u32 v = 0;
-    switch (tid) {
-      case 0: v = LMC_BLOB_MAGIC; break;
-      case 1: v = LMC_BLOB_VERSION | (LMC_HEADER_BYTES << 16); break;
-      case 2: v = (u32)a.dtype; break;
-      case 3: v = (u32)a.L; break;
-      case 4: v = T; break;
-      case 5: v = (u32)a.H; break;
-      case 6: v = (u32)a.D; break;
-      case 7: v = (u32)a.C; break;
-      case 8: v = (u32)a.P; break;
-      case 9: v = (u32)a.G; break;
-      case 10: v = LMC_LP; break;
-      case 11: v = bo.bins; break;
-      case 12: v = bo.scales; break;
-      case 13: v = bo.cdf; break;
-      case 14: v = bo.gend; break;
-      case 15: v = bo.streams; break;
-      case 16: v = stream_bytes; break;
-      case 17: v = bo.streams + stream_bytes; break;
-      case 18: v = bo.rowpre; break;
-      case 19: v = cdf_rows; break;
-      default: v = 0;
-    }
-    reinterpret_cast<u32*>(blob)[tid] = v;
-  }
-  if (tid == 0) a.sizes[chunk] = bo.streams + stream_bytes;
-}
-
-// Copy each padded group stream from its scratch slot to its final place.
-// Replaces the fancy-index gather of collect_bytes (cachegen_encoder.py:237-238).
-struct PackArgs {
-  u8* blobs;
-  long long blob_stride;
-  const u8* scratch;
-  u32 cap;
-  const u32* glen;
-  const u32* goff;
-  int tok_begin, tok_end, chunk_tokens;
-  int P, C, G;
-  u32 cdf_rows;
-  long long ngroups_total;
-};
-
-__global__ __launch_bounds__(256) void k_pack_streams(PackArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long gid = (long long)blockIdx.x * 4 + wave;
-  if (gid >= a.ngroups_total) return;
-  const int n = a.P * a.G;
-  const int chunk = (int)(gid / n);
-  const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
-  const u32 T = (u32)min(a.chunk_tokens, a.tok_end - tok0);
-  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, a.cdf_rows);
-  const u32 n16 = ((a.glen[gid] + 15u) & ~15u) >> 4;
-  const uint4* src = reinterpret_cast<const uint4*>(a.scratch + gid * (long long)a.cap);
-  uint4* dst = reinterpret_cast<uint4*>(a.blobs + (long long)chunk * a.blob_stride + bo.streams + a.goff[gid]);
-  for (u32 i = lane; i < n16; i += 64) dst[i] = src[i];
 }

@@ -14,7 +14,6 @@
 #include "k_copy.h"
 #include "k_decode.h"
 #include "k_encode.h"
-#include "k_fused.h"
 #include "k_quantize.h"
 
 static thread_local int g_last_hip = 0;
@@ -34,15 +33,11 @@ struct lmc_ctx {
   // encode workspace
   u32* sym4 = nullptr;  size_t sym4_bytes = 0;
   u8* scratch = nullptr; size_t scratch_bytes = 0;
-  u32* glen = nullptr;  u32* goff = nullptr; size_t glen_bytes = 0;
   unsigned long long* agg = nullptr; size_t agg_bytes = 0;  // look-back granules of the in-kernel compaction
   hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
   bool ws_used = false;
   int num_cus = 256;
   u32* status_h = nullptr;  // pinned, device-accessible
-  // k_fused_encode (C = 512 / 1024, chunks <= 256 tokens) moves half the HBM bytes of the general path but is
-  // ~4 % slower standalone (1 workgroup per CU, no overlap of its memory and coder phases): opt-in.
-  bool fused = false;
   // optional per-kernel timing (lmc_ctx_profile)
   bool profile = false;
   hipEvent_t pev[8] = {};
@@ -99,20 +94,11 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   if (c->ws_used) (void)hipEventSynchronize(c->ws_free);
   if (c->sym4) (void)hipFree(c->sym4);
   if (c->scratch) (void)hipFree(c->scratch);
-  if (c->glen) (void)hipFree(c->glen);
-  if (c->goff) (void)hipFree(c->goff);
   if (c->agg) (void)hipFree(c->agg);
   if (c->ws_free) (void)hipEventDestroy(c->ws_free);
   for (int i = 0; i < 8; i++) if (c->pev[i]) (void)hipEventDestroy(c->pev[i]);
   if (c->status_h) (void)hipHostFree(c->status_h);
   delete c;
-  return LMC_OK;
-}
-
-int lmc_ctx_set_fused(lmc_ctx* c, int enable) {
-  if (!c) return LMC_ERR_INVALID;
-  std::lock_guard<std::mutex> lk(c->mu);
-  c->fused = enable != 0;
   return LMC_OK;
 }
 
@@ -228,21 +214,13 @@ static int reserve_locked(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int
   const size_t need_sym = (size_t)max_chunks * P * TQ * C * 4;
   const size_t need_scr = (size_t)max_chunks * P * G * lmc_group_cap_bytes((uint32_t)chunk_tokens);
   const size_t need_len = (size_t)max_chunks * P * G * 4;
-  if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && need_len <= c->glen_bytes &&
-      2 * need_len <= c->agg_bytes)
-    return LMC_OK;
+  if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && 2 * need_len <= c->agg_bytes) return LMC_OK;
   // growing frees memory that queued kernels may still use: wait for them (this call only)
   if (c->ws_used) HIP_TRY(hipEventSynchronize(c->ws_free));
   int rc;
   if ((rc = ws_grow((void**)&c->sym4, &c->sym4_bytes, need_sym))) return rc;
   if ((rc = ws_grow((void**)&c->scratch, &c->scratch_bytes, need_scr))) return rc;
   if ((rc = ws_grow((void**)&c->agg, &c->agg_bytes, 2 * need_len))) return rc;
-  if (need_len > c->glen_bytes) {
-    size_t h1 = c->glen_bytes, h2 = c->glen_bytes;
-    if ((rc = ws_grow((void**)&c->glen, &h1, need_len))) return rc;
-    if ((rc = ws_grow((void**)&c->goff, &h2, need_len))) return rc;
-    c->glen_bytes = h1 < h2 ? h1 : h2;
-  }
   return LMC_OK;
 }
 
@@ -286,7 +264,7 @@ int lmc_calculate_cdf(lmc_ctx* c, const int8_t* sym, int32_t P, int32_t T, int32
   a.status = c->status_h;
   HIP_TRY(hipSetDevice(c->device));
   long long n = (long long)P * a.G;
-  hipLaunchKernelGGL((k_cdf_encode<false, false, false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_cdf_encode<false, false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return LMC_OK;
 }
@@ -300,6 +278,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   const int P = 2 * L, C = H * D, G = (C + 63) / 64;
   if (C > 4096) return LMC_ERR_INVALID;
   const int nchunks = (tok_end - tok_begin + chunk_tokens - 1) / chunk_tokens;
+  if (nchunks > 65535) return LMC_ERR_INVALID;  // chunks ride on gridDim.z of k_quantize
   if (blob_stride < lmc_blob_bound((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D)) return LMC_ERR_INVALID;
   BinsArg bins;
   if (!bins_ok(bins_h, P, &bins)) return LMC_ERR_INVALID;
@@ -317,96 +296,39 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   lmc_blob_layout((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D, bins.rowpre[P], &hl);
   const long long PG = (long long)P * G;
 
-  // Launch the four kernels for chunks [c0, c0 + nc); the workspace slice starts at chunk slot `w0`.
-  auto launch_range = [&](int c0, int nc, int w0) -> int {
-    const int tb = tok_begin + c0 * chunk_tokens;
-    u8* blobs_b = (u8*)blobs + (uint64_t)c0 * blob_stride;
+  // Two launches for the whole job: k_quantize, then k_cdf_encode (CDF + coder + in-kernel compaction of the
+  // streams into the blobs).  Measured alternatives that lost are listed in DESIGN.md section 6.
+  c->pn = 0;
+  {
     QuantArgs qa;
     memset(&qa, 0, sizeof qa);
     qa.src = to_addr(src); qa.bins = bins;
-    qa.tok_begin = tb; qa.tok_end = tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = nc;
-    qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = nc * P;
-    qa.sym4 = c->sym4 + (long long)w0 * P * TQ * C;
-    qa.scale_base = blobs_b + hl.off_scales;  // off_scales does not depend on T
+    qa.tok_begin = tok_begin; qa.tok_end = tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = nchunks;
+    qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = nchunks * P;
+    qa.sym4 = c->sym4;
+    qa.scale_base = (u8*)blobs + hl.off_scales;  // off_scales does not depend on T
     qa.scale_stride = (long long)blob_stride;
-    int r;
-    const bool use_fused = c->fused && (C == 512 || C == 1024) && chunk_tokens <= 256;
-    if ((r = prof_mark(c, s))) return r;
-    if (use_fused) {
-      FusedArgs fa;
-      memset(&fa, 0, sizeof fa);
-      fa.src = qa.src; fa.bins = bins;
-      fa.tok_begin = tb; fa.tok_end = tok_end; fa.chunk_tokens = chunk_tokens; fa.nchunks = nc;
-      fa.P = P; fa.C = C; fa.G = G;
-      fa.blobs = blobs_b; fa.blob_stride = (long long)blob_stride;
-      fa.scratch = c->scratch + (long long)w0 * PG * cap; fa.cap = cap;
-      fa.glen = c->glen + (long long)w0 * PG; fa.status = c->status_h;
-      const dim3 grid((unsigned)(nc * P));
-      const bool bf = src->dtype == LMC_DTYPE_BF16;
-      if (C == 1024) {
-        if (bf) hipLaunchKernelGGL((k_fused_encode<2, LMC_DTYPE_BF16>), grid, dim3(1024), 0, s, fa);
-        else hipLaunchKernelGGL((k_fused_encode<2, LMC_DTYPE_FP16>), grid, dim3(1024), 0, s, fa);
-      } else {
-        if (bf) hipLaunchKernelGGL((k_fused_encode<1, LMC_DTYPE_BF16>), grid, dim3(512), 0, s, fa);
-        else hipLaunchKernelGGL((k_fused_encode<1, LMC_DTYPE_FP16>), grid, dim3(512), 0, s, fa);
-      }
-      HIP_TRY(hipGetLastError());
-      if ((r = prof_mark(c, s))) return r;
-    } else {
-      if ((r = launch_quant<true>(qa, s))) return r;
-      if ((r = prof_mark(c, s))) return r;
-    }
+    if ((rc = prof_mark(c, s))) return rc;
+    if ((rc = launch_quant<true>(qa, s))) return rc;
+    if ((rc = prof_mark(c, s))) return rc;
 
     EncodeArgs ea;
     memset(&ea, 0, sizeof ea);
     ea.sym4 = qa.sym4;
-    ea.tok_begin = tb; ea.tok_end = tok_end; ea.chunk_tokens = chunk_tokens; ea.nchunks = nc;
+    ea.tok_begin = tok_begin; ea.tok_end = tok_end; ea.chunk_tokens = chunk_tokens; ea.nchunks = nchunks;
     ea.P = P; ea.C = C; ea.G = G; ea.TQ = TQ;
-    ea.blobs = blobs_b; ea.blob_stride = (long long)blob_stride;
-    ea.scratch = c->scratch + (long long)w0 * PG * cap; ea.cap = cap;
-    ea.glen = c->glen + (long long)w0 * PG; ea.status = c->status_h;
+    ea.blobs = (u8*)blobs; ea.blob_stride = (long long)blob_stride;
+    ea.scratch = c->scratch; ea.cap = cap;
+    ea.status = c->status_h;
     ea.bins = bins;
-    ea.agg = c->agg + (long long)w0 * PG; ea.sizes = sizes + c0;
+    ea.agg = c->agg; ea.sizes = sizes;
     ea.L = L; ea.H = H; ea.D = D; ea.dtype = src->dtype;
-    const long long ngroups = (long long)nc * PG;
-    if (!use_fused) {
-      // the coder also compacts its streams into the blob (single-pass prefix over the group lengths):
-      // k_scan_finalize / k_pack_streams are only needed behind the fused tile kernel
-      HIP_TRY(hipMemsetAsync(ea.agg, 0, (size_t)ngroups * 8, s));
-      hipLaunchKernelGGL((k_cdf_encode<true, true, true>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, ea);
-      HIP_TRY(hipGetLastError());
-      if ((r = prof_mark(c, s))) return r;
-      return LMC_OK;
-    }
-    if ((r = prof_mark(c, s))) return r;
-
-    ScanArgs sa;
-    memset(&sa, 0, sizeof sa);
-    sa.blobs = blobs_b; sa.blob_stride = (long long)blob_stride;
-    sa.glen = ea.glen; sa.goff = c->goff + (long long)w0 * PG; sa.sizes = sizes + c0; sa.bins = bins;
-    sa.tok_begin = tb; sa.tok_end = tok_end; sa.chunk_tokens = chunk_tokens;
-    sa.L = L; sa.H = H; sa.D = D; sa.P = P; sa.C = C; sa.G = G; sa.dtype = src->dtype;
-    hipLaunchKernelGGL(k_scan_finalize, dim3((unsigned)nc), dim3(1024), 0, s, sa);
+    const long long ngroups = (long long)nchunks * PG;
+    HIP_TRY(hipMemsetAsync(ea.agg, 0, (size_t)ngroups * 8, s));
+    hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, ea);
     HIP_TRY(hipGetLastError());
-    if ((r = prof_mark(c, s))) return r;
-
-    PackArgs pa;
-    memset(&pa, 0, sizeof pa);
-    pa.blobs = blobs_b; pa.blob_stride = (long long)blob_stride;
-    pa.scratch = ea.scratch; pa.cap = cap; pa.glen = ea.glen; pa.goff = sa.goff;
-    pa.tok_begin = tb; pa.tok_end = tok_end; pa.chunk_tokens = chunk_tokens;
-    pa.P = P; pa.C = C; pa.G = G; pa.cdf_rows = bins.rowpre[P]; pa.ngroups_total = ngroups;
-    hipLaunchKernelGGL(k_pack_streams, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, pa);
-    HIP_TRY(hipGetLastError());
-    if ((r = prof_mark(c, s))) return r;
-    return LMC_OK;
-  };
-
-  // One set of launches for the whole job.  (Measured alternatives that lost: cutting the job into
-  // cache-resident sub-batches, and running quantise on a second stream ahead of the coder -- DESIGN.md 6.)
-  c->pn = 0;
-  rc = launch_range(0, nchunks, 0);
-  if (rc) return rc;
+    if ((rc = prof_mark(c, s))) return rc;
+  }
 
   HIP_TRY(hipEventRecord(c->ws_free, s));
   c->ws_used = true;

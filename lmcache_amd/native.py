@@ -70,7 +70,6 @@ SYMBOLS = {
     "lmc_ctx_destroy": (ctypes.c_int, [_vp]),
     "lmc_ctx_reserve": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "lmc_device_status": (ctypes.c_int, [_vp, ctypes.c_int]),
-    "lmc_ctx_set_fused": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmc_ctx_profile": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmc_ctx_profile_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
     "lmc_quantize": (ctypes.c_int, [_vp, _PL, _i32, _i32, _vp, _vp, _vp, _vp]),
@@ -353,9 +352,6 @@ class Context:
         st = self.status(clear=True)
         if st:
             raise NativeError(f"{what}: device status 0x{st:x} (1=stream overflow, 2=bad header, 4=bad stream)")
-
-    def set_fused(self, enable: bool) -> None:
-        check(lib().lmc_ctx_set_fused(self.handle, 1 if enable else 0), "lmc_ctx_set_fused")
 
     def profile(self, enable: bool) -> None:
         check(lib().lmc_ctx_profile(self.handle, 1 if enable else 0), "lmc_ctx_profile")

@@ -282,9 +282,9 @@ def test_long_chunks_and_denormal_scales(nat, ctx, oracle, case):
                                    (2, 100, 4, 128, torch.bfloat16), (1, 256, 4, 128, torch.float16),
                                    (2, 5, 8, 128, torch.bfloat16), (1, 129, 16, 64, torch.bfloat16),
                                    (4, 64, 8, 128, torch.bfloat16), (3, 40, 8, 64, torch.float16)])
-def test_fused_and_general_encoders_agree_with_oracle(nat, ctx, oracle, shape):
-    """k_fused_encode (C = 512 / 1024, T <= 256) and the general k_quantize + k_cdf_encode path must both
-    produce the oracle's bytes; multi-chunk with a ragged tail and edge rows included."""
+def test_multichunk_encode_shapes_agree_with_oracle(nat, ctx, oracle, shape):
+    """Multi-chunk jobs with a ragged tail and edge rows (all-zero row, inf element) over the channel counts
+    that select different k_quantize instantiations (C = 512 / 1024, bf16 / fp16) produce the oracle's bytes."""
     L, T, H, D, dt = shape
     g = torch.Generator().manual_seed(T * 7 + H)
     Ttot = 6 * T + 37 if T >= 40 else T  # several chunks + short tail for the larger cases
@@ -294,20 +294,11 @@ def test_fused_and_general_encoders_agree_with_oracle(nat, ctx, oracle, shape):
         kv[0, 1, 2, 0, 0] = float("inf")
     bins = default_bins(L)
     lay = nat.KVLayout.from_chunk(kv.to(DEV), "vllm")
-    got = {}
-    try:
-        for fused in (True, False):
-            ctx.set_fused(fused)
-            got[fused], _, _ = encode(nat, ctx, lay, 0, Ttot, T, bins)
-    finally:
-        ctx.set_fused(False)
-    for i in range(len(got[False])):
+    blobs, _, _ = encode(nat, ctx, lay, 0, Ttot, T, bins)
+    for i, b in enumerate(blobs):
         t0, t1 = i * T, min(Ttot, (i + 1) * T)
         bits, code = oracle.torch_to_bits(kv[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
-        ref = oracle.encode_blob(bits, code, H, D, np.array(bins, np.int32))
-        for fused, blobs in got.items():
-            assert len(blobs) == len(got[False])
-            assert blobs[i] == ref, f"fused={fused} chunk {i}"
+        assert b == oracle.encode_blob(bits, code, H, D, np.array(bins, np.int32)), f"chunk {i}"
 
 
 def test_encode_repeated_on_changing_paged_data(nat, ctx, oracle):
@@ -318,7 +309,7 @@ def test_encode_repeated_on_changing_paged_data(nat, ctx, oracle):
     bins = default_bins(L)
     nblocks = (ntok + bs - 1) // bs + 3
     g = torch.Generator().manual_seed(77)
-    try:
+    if True:
         for it in range(4):
             kv = torch.randn(L, 2, ntok, H, D, generator=g).to(torch.bfloat16)
             perm = torch.randperm(nblocks, generator=g)
@@ -335,8 +326,6 @@ def test_encode_repeated_on_changing_paged_data(nat, ctx, oracle):
                 t0, t1 = i * T, min(ntok, (i + 1) * T)
                 bits, code = oracle.torch_to_bits(kv[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
                 assert b == oracle.encode_blob(bits, code, H, D, np.array(bins, np.int32)), f"iter {it} chunk {i}"
-    finally:
-        pass
 
 
 def test_llama70b_tp8_rank_shape(nat, ctx, oracle):
