@@ -41,8 +41,6 @@ struct DecodeArgs {
 #define DEC_RING_BYTES (2 * (64 + DEC_RING_WORDS))
 #define DEC_WAVE_BYTES (DEC_CDF_BYTES + DEC_RING_BYTES + 128)
 
-template <bool B>
-struct BoolTag { static constexpr bool value = B; };
 
 __device__ __forceinline__ u64 uniform_ptr(const void* p) {  // a pointer every lane holds -> SGPR pair
   const u64 v = (u64)p;

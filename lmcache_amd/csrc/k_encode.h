@@ -151,6 +151,24 @@ __device__ __forceinline__ void compact_stream(const EncodeArgs& a, const Pendin
   }
 }
 
+// Symbol of token i (0..31) of a 32-token block whose workspace dwords are in w (k_quantize.h formats):
+// bytes: dword i / 4, byte i % 4;  nibbles: dword i / 8, byte (i % 8) % 4, high nibble for i % 8 >= 4.
+template <bool NIB, int I>
+__device__ __forceinline__ u32 sym_of_block(const u32* w) {
+  if (NIB) return __builtin_amdgcn_ubfe(w[I >> 3], 8 * (I & 3) + 4 * ((I >> 2) & 1), 4);
+  return __builtin_amdgcn_ubfe(w[I >> 2], 8 * (I & 3), 8);
+}
+// ... and of an arbitrary token t of the plane-chunk column symq (stride C dwords), for the ragged ends
+template <bool NIB>
+__device__ __forceinline__ u32 sym_of_token(const u32* symq, int C, int t, bool active) {
+  if (NIB) {
+    const u32 wq = active ? symq[(long long)(t >> 3) * C] : 0u;
+    return (wq >> (8 * (t & 3) + 4 * ((t >> 2) & 1))) & 0xfu;
+  }
+  const u32 wq = active ? symq[(long long)(t >> 2) * C] : 0u;
+  return (wq >> (8 * (t & 3))) & 0xffu;
+}
+
 template <bool QUADSYM, bool ENCODE>
 __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   __shared__ __attribute__((aligned(16))) u32 lds_all[4 * ENC_WAVE_DWORDS];
@@ -185,34 +203,42 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   // one shift-add); equal symbols in a pair are serialised by the LDS atomic unit.
   u32* const hrow = hist + (lane >> 1);
   const u32 one = 1u << ((lane & 1) * 16);
-  if (QUADSYM) {
-    const int nfull = Tc >> 5;  // full 32-token blocks
-    u32 w[8], wn[8];
+  // Workspace symbol format (k_quantize.h): byte planes hold 4 tokens per dword, nibble planes (bins <= 17) 8;
+  // sym_of_block<NIB, i>(w) is the symbol of token i (0..31) of a 32-token block held in w[0 .. DPB).
+  const bool nib = QUADSYM && lmc_sym_nibbles((int)a.bins.b[p]);  // wave-uniform
+  auto pass1 = [&](auto nib_tag) {
+    constexpr bool NIB = decltype(nib_tag)::value;
+    constexpr int DPB = NIB ? 4 : 8;  // dwords per 32-token block
+    const int nfull = Tc >> 5;        // full 32-token blocks
+    u32 w[DPB], wn[DPB];
     if (nfull > 0) {
 #pragma unroll
-      for (int j = 0; j < 8; j++) w[j] = active ? symq[(long long)j * a.C] : 0u;
+      for (int j = 0; j < DPB; j++) w[j] = active ? symq[(long long)j * a.C] : 0u;
     }
     for (int b = 0; b < nfull; b++) {
       if (b + 1 < nfull) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) wn[j] = active ? symq[(long long)((b + 1) * 8 + j) * a.C] : 0u;
+        for (int j = 0; j < DPB; j++) wn[j] = active ? symq[(long long)((b + 1) * DPB + j) * a.C] : 0u;
       }
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
+      for (int j = 0; j < DPB; j++) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const u32 sk = __builtin_amdgcn_ubfe(w[j], 8 * k, 8);
+        for (int k = 0; k < 32 / DPB; k++) {
+          const u32 sk = __builtin_amdgcn_ubfe(w[j], NIB ? 4 * k : 8 * k, NIB ? 4 : 8);  // any order will do here
           atomicAdd(&hrow[sk * 32], one);  // ds_add_u32 of this lane's half of the dword, bank = lane / 2
         }
       }
 #pragma unroll
-      for (int j = 0; j < 8; j++) w[j] = wn[j];
+      for (int j = 0; j < DPB; j++) w[j] = wn[j];
     }
     for (int t = nfull * 32; t < Tc; t++) {  // ragged tail (< 32 tokens)
-      const u32 wq = active ? symq[(long long)(t >> 2) * a.C] : 0u;
-      const u32 s = (wq >> (8 * (t & 3))) & 0xffu;
+      const u32 s = sym_of_token<NIB>(symq, a.C, t, active);
       atomicAdd(&hrow[s * 32], one);
     }
+  };
+  if (QUADSYM) {
+    if (nib) pass1(BoolTag<true>{});
+    else pass1(BoolTag<false>{});
   } else {
     for (int t = 0; t < Tc; t++) {
       const u32 s = active ? min((u32)(u8)symb[(long long)t * a.C], 31u) : 0u;
@@ -282,48 +308,53 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
     x = rans_put(x, f, 0x10000u - f, st);
   };
 
-  // ragged head of the descending walk: tokens Tc-1 .. 32*nfull (< 32 of them), one at a time
-  const int nfull = Tc >> 5;
-  for (int t = Tc - 1; t >= nfull * 32; t--) {
-    const u32 wq = active ? symq[(long long)(t >> 2) * a.C] : 0u;
-    const u32 s = (wq >> (8 * (t & 3))) & 0xffu;
-    const u32 lo = tab[s * 64 + lane], hi = tab[s * 64 + 64 + lane];
-    code_token(lo, (hi - lo) & 0xffffu);
-  }
-  // full 32-token blocks, descending; software pipelined twice over:
-  //   - the next block's 8 symbol dwords are loaded while this block is coded,
-  //   - the table entries of token t-1 are fetched from LDS before token t is coded.
-  if (nfull > 0) {
-    u32 w[8], wn[8];
+  auto pass2 = [&](auto nib_tag) {
+    constexpr bool NIB = decltype(nib_tag)::value;
+    constexpr int DPB = NIB ? 4 : 8;
+    // ragged head of the descending walk: tokens Tc-1 .. 32*nfull (< 32 of them), one at a time
+    const int nfull = Tc >> 5;
+    for (int t = Tc - 1; t >= nfull * 32; t--) {
+      const u32 s = sym_of_token<NIB>(symq, a.C, t, active);
+      const u32 lo = tab[s * 64 + lane], hi = tab[s * 64 + 64 + lane];
+      code_token(lo, (hi - lo) & 0xffffu);
+    }
+    // full 32-token blocks, descending; software pipelined twice over:
+    //   - the next block's symbol dwords are loaded while this block is coded,
+    //   - the table entries of token t-1 are fetched from LDS before token t is coded.
+    if (nfull > 0) {
+      u32 w[DPB], wn[DPB];
 #pragma unroll
-    for (int j = 0; j < 8; j++) w[j] = active ? symq[(long long)((nfull - 1) * 8 + j) * a.C] : 0u;
-    u32 lo_n = tab[(w[7] >> 24) * 64 + lane], hi_n = tab[(w[7] >> 24) * 64 + 64 + lane];
-    for (int b = nfull - 1; b >= 0; b--) {
-      if (b > 0) {
+      for (int j = 0; j < DPB; j++) w[j] = active ? symq[(long long)((nfull - 1) * DPB + j) * a.C] : 0u;
+      u32 sn = sym_of_block<NIB, 31>(w);
+      u32 lo_n = tab[sn * 64 + lane], hi_n = tab[sn * 64 + 64 + lane];
+      for (int b = nfull - 1; b >= 0; b--) {
+        if (b > 0) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) wn[j] = active ? symq[(long long)((b - 1) * 8 + j) * a.C] : 0u;
-      }
-#pragma unroll
-      for (int j = 7; j >= 0; j--) {
-#pragma unroll
-        for (int k = 3; k >= 0; k--) {
+          for (int j = 0; j < DPB; j++) wn[j] = active ? symq[(long long)((b - 1) * DPB + j) * a.C] : 0u;
+        }
+        static_for<32>([&](auto itag) {
+          constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
           const u32 st = lo_n, f = (hi_n - lo_n) & 0xffffu;
-          if (j > 0 || k > 0) {  // entries of the next token of this block
-            const u32 sn = k > 0 ? (w[j] >> (8 * (k - 1))) & 0xffu : (w[j > 0 ? j - 1 : 0] >> 24) & 0xffu;
+          if constexpr (i > 0) {  // entries of the next token of this block
+            sn = sym_of_block<NIB, i - 1>(w);
             lo_n = tab[sn * 64 + lane];
             hi_n = tab[sn * 64 + 64 + lane];
-          } else if (b > 0) {     // ... or of the first token of the next block
-            const u32 sn = wn[7] >> 24;
-            lo_n = tab[sn * 64 + lane];
-            hi_n = tab[sn * 64 + 64 + lane];
+          } else {
+            if (b > 0) {          // ... or of the first token of the next block
+              sn = sym_of_block<NIB, 31>(wn);
+              lo_n = tab[sn * 64 + lane];
+              hi_n = tab[sn * 64 + 64 + lane];
+            }
           }
           code_token(st, f);
-        }
-      }
+        });
 #pragma unroll
-      for (int j = 0; j < 8; j++) w[j] = wn[j];
+        for (int j = 0; j < DPB; j++) w[j] = wn[j];
+      }
     }
-  }
+  };
+  if (nib) pass2(BoolTag<true>{});
+  else pass2(BoolTag<false>{});
   x = active ? x : LMC_RANS_L;  // idle lanes (channel >= C) carry the initial state
   // tail: states, pad, length
   out[wcur + 2 * lane] = (u16)x;

@@ -59,16 +59,22 @@ __device__ __forceinline__ u32 quant_special(float x, float factor, float maxf) 
   return (__builtin_fabsf(r) < 2147483648.0f) ? ((u32)(int)r & 0xffu) : 0u;
 }
 
-// One row quad (4 consecutive tokens q*4 .. q*4+3 of plane p of one chunk) by the G lanes sl = 0..G-1.
-//   sym4_quad   QUAD: &sym4[chunk][p][q][0]          sym8_plane  !QUAD: &sym8[p][0][0]
-//   scale_quad  &scales[chunk][p][q*4]
+// One task = 4 (row quad) or, NIB, 8 consecutive tokens starting at token t_first of plane p of one chunk,
+// by the G lanes sl = 0..G-1.
+//   sym_out     QUAD: the task's dwords, [channel]      sym8_plane  !QUAD: &sym8[p][0][0]
+//   scale_out   &scales[chunk][p][t_first]
+// QUAD output dword of channel c: byte k = symbol of token t_first + k.  NIB (planes whose symbols fit four
+// bits: bins <= 17): byte k = symbol of token t_first + k | symbol of token t_first + 4 + k << 4, so the
+// workspace round trip of most planes is half a byte per element.
 // ROWS (4 or 2): rows loaded and reduced together -- 4 keeps 4*NITER 16-byte loads in flight per lane,
 // 2 halves the registers.
-template <int G, int NITER, int DT, bool QUAD, int ROWS = 4>
-__device__ __forceinline__ void quantize_quad(const KvAddr& src, int p, int tok0, int Tc, int q, bool qvalid, int C,
-                                              float maxf, u32* sym4_quad, int8_t* sym8_plane, u16* scale_quad,
+template <int G, int NITER, int DT, bool QUAD, bool NIB, int ROWS = 4>
+__device__ __forceinline__ void quantize_task(const KvAddr& src, int p, int tok0, int Tc, int t_first, bool qvalid,
+                                              int C, float maxf, u32* sym_out, int8_t* sym8_plane, u16* scale_out,
                                               int sl) {
-  static_assert(ROWS == 2 || ROWS == 4, "row quads are processed in one or two passes");
+  static_assert(ROWS == 2 || ROWS == 4 || (ROWS == 8 && NIB), "rows in flight: a power of two within the task");
+  static_assert(QUAD || !NIB, "nibble packing is a workspace format");
+  constexpr int NQ = NIB ? 2 : 1;  // row quads in the task
   // per-lane channel runs (row independent)
   long long coff[NITER];
   int c0[NITER];
@@ -82,21 +88,23 @@ __device__ __forceinline__ void quantize_quad(const KvAddr& src, int p, int tok0
   }
   const u16* pbase = lmc_plane_base(src, p);
   const f32x2_t maxf2 = {maxf, maxf};
-  // QUAD: o[it][e] byte r = symbol of (token 4q + r, channel c0[it] + e); bytes of tokens past the end of a
-  // ragged chunk are never read by the coder, so they need no masking
-  u32 o[NITER][8];
+  // QUAD: o[hq][it][e] byte r = symbol of (token t_first + 4 hq + r, channel c0[it] + e); bytes of tokens past
+  // the end of a ragged chunk are never read by the coder, so they need no masking
+  u32 o[NQ][NITER][8];
 #pragma unroll
-  for (int it = 0; it < NITER; it++)
+  for (int hq = 0; hq < NQ; hq++)
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[it][e] = 0;
+    for (int it = 0; it < NITER; it++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[hq][it][e] = 0;
 
 #pragma unroll
-  for (int r0 = 0; r0 < 4; r0 += ROWS) {
+  for (int r0 = 0; r0 < 4 * NQ; r0 += ROWS) {
     uint4 v[ROWS][NITER];
     bool tv[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
-      int t = q * 4 + r0 + r;
+      int t = t_first + r0 + r;
       tv[r] = qvalid && t < Tc;
       const u16* rowp = pbase + (tv[r] ? lmc_tok_off(src, tok0 + t) : 0);
 #pragma unroll
@@ -133,7 +141,7 @@ __device__ __forceinline__ void quantize_quad(const KvAddr& src, int p, int tok0
     if (sl == 0) {
 #pragma unroll
       for (int r = 0; r < ROWS; r++)
-        if (tv[r]) scale_quad[r0 + r] = (u16)mrow[r];
+        if (tv[r]) scale_out[r0 + r] = (u16)mrow[r];
     }
 
     float factor[ROWS];
@@ -164,14 +172,14 @@ __device__ __forceinline__ void quantize_quad(const KvAddr& src, int p, int tok0
 #pragma unroll
             for (int k = 0; k < 4; k++) {
               const f32x2_t z = quant_z2(h_lo<DT>(w[k]), h_hi<DT>(w[k]), f2, maxf2);
-              o[it][2 * k] = __builtin_amdgcn_cvt_pk_u8_f32(z.x, r0 + r, o[it][2 * k]);
-              o[it][2 * k + 1] = __builtin_amdgcn_cvt_pk_u8_f32(z.y, r0 + r, o[it][2 * k + 1]);
+              o[(r0 + r) >> 2][it][2 * k] = __builtin_amdgcn_cvt_pk_u8_f32(z.x, (r0 + r) & 3, o[(r0 + r) >> 2][it][2 * k]);
+              o[(r0 + r) >> 2][it][2 * k + 1] = __builtin_amdgcn_cvt_pk_u8_f32(z.y, (r0 + r) & 3, o[(r0 + r) >> 2][it][2 * k + 1]);
             }
           } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-              o[it][2 * k] |= sym_of(r, h_lo<DT>(w[k])) << (8 * (r0 + r));
-              o[it][2 * k + 1] |= sym_of(r, h_hi<DT>(w[k])) << (8 * (r0 + r));
+              o[(r0 + r) >> 2][it][2 * k] |= sym_of(r, h_lo<DT>(w[k])) << (8 * ((r0 + r) & 3));
+              o[(r0 + r) >> 2][it][2 * k + 1] |= sym_of(r, h_hi<DT>(w[k])) << (8 * ((r0 + r) & 3));
             }
           }
         }
@@ -186,7 +194,7 @@ __device__ __forceinline__ void quantize_quad(const KvAddr& src, int p, int tok0
             lo |= (sym_of(r, h_lo<DT>(w[k])) << (16 * k)) | (sym_of(r, h_hi<DT>(w[k])) << (16 * k + 8));
             hi |= (sym_of(r, h_lo<DT>(w[k + 2])) << (16 * k)) | (sym_of(r, h_hi<DT>(w[k + 2])) << (16 * k + 8));
           }
-          int8_t* dst = sym8_plane + ((long long)(q * 4 + r0 + r)) * C + c0[it];
+          int8_t* dst = sym8_plane + ((long long)(t_first + r0 + r)) * C + c0[it];
           *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
         }
       }
@@ -196,33 +204,48 @@ __device__ __forceinline__ void quantize_quad(const KvAddr& src, int p, int tok0
 #pragma unroll
     for (int it = 0; it < NITER; it++) {
       if (!cval[it]) continue;
-      u32* dst = sym4_quad + c0[it];
-      const uint4 a0 = make_uint4(o[it][0], o[it][1], o[it][2], o[it][3]);
-      const uint4 a1 = make_uint4(o[it][4], o[it][5], o[it][6], o[it][7]);
-      *reinterpret_cast<uint4*>(dst) = a0;  // kernel-arg pointers: global already
-      *reinterpret_cast<uint4*>(dst + 4) = a1;
+      u32 w[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) w[e] = NIB ? (o[0][it][e] | (o[NQ - 1][it][e] << 4)) : o[0][it][e];
+      u32* dst = sym_out + c0[it];
+      *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);  // kernel-arg pointers: global already
+      *reinterpret_cast<uint4*>(dst + 4) = make_uint4(w[4], w[5], w[6], w[7]);
     }
   }
 }
 
-// grid = (ceil(TQ / (4 * RPW)), P, chunks): plane and chunk come straight from the block index, and with
-// G = 64 (one row quad per wave) everything but the channel offset is wave-uniform and lives in SGPRs.
+// A wave (G = 64) or a G-lane group takes one row OCT: tokens 8*oct .. 8*oct + 7.  Planes with bins <= 17
+// get the nibble-packed workspace format (one dword per channel for the oct), the others two row quads.
+// grid = (ceil(TO / (4 * RPW)), P, chunks), TO = ceil(TQ / 2): plane and chunk come straight from the block
+// index, and with G = 64 everything but the channel offset is wave-uniform and lives in SGPRs.
 template <int G, int NITER, int DT, bool QUAD>
 __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
-  constexpr int RPW = LMC_WAVE / G;  // row quads per wave
+  constexpr int RPW = LMC_WAVE / G;  // tasks per wave
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int sub = lane / G, sl = lane % G;
   const int p = (int)blockIdx.y, chunk = (int)blockIdx.z;
-  int q = ((int)blockIdx.x * 4 + wave) * RPW + sub;
-  const bool qvalid = q < a.TQ && chunk * a.P + p < a.pc_limit;
-  if (!qvalid) q = 0;
+  const int TO = (a.TQ + 1) >> 1;
+  int oct = ((int)blockIdx.x * 4 + wave) * RPW + sub;
+  const bool ovalid = oct < TO && chunk * a.P + p < a.pc_limit;
+  if (!ovalid) oct = 0;
   const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
   const int Tc = min(a.chunk_tokens, a.tok_end - tok0);
-  const float maxf = (float)((int)a.bins.b[p] / 2 - 1);
-  u16* scale_quad =
-      reinterpret_cast<u16*>(a.scale_base + (long long)chunk * a.scale_stride) + ((long long)p * Tc + q * 4);
-  u32* sym4_quad = QUAD ? a.sym4 + (((long long)chunk * a.P + p) * a.TQ + q) * a.C : nullptr;
+  const int bins = (int)a.bins.b[p];
+  const float maxf = (float)(bins / 2 - 1);
+  u16* scale_out = reinterpret_cast<u16*>(a.scale_base + (long long)chunk * a.scale_stride) + ((long long)p * Tc + oct * 8);
+  u32* sym_pc = QUAD ? a.sym4 + ((long long)chunk * a.P + p) * a.TQ * a.C : nullptr;  // this plane-chunk's workspace
   int8_t* sym8_plane = QUAD ? nullptr : a.sym8 + (long long)p * Tc * a.C;
-  quantize_quad<G, NITER, DT, QUAD>(a.src, p, tok0, Tc, q, qvalid, a.C, maxf, sym4_quad, sym8_plane, scale_quad, sl);
+  if (QUAD && lmc_sym_nibbles(bins)) {
+    quantize_task<G, NITER, DT, QUAD, QUAD, (QUAD && NITER <= 2) ? 8 : 4>(a.src, p, tok0, Tc, oct * 8, ovalid, a.C, maxf, sym_pc + (long long)oct * a.C,
+                                            nullptr, scale_out, sl);
+  } else {
+#pragma unroll 1
+    for (int hq = 0; hq < 2; hq++) {
+      const int q = 2 * oct + hq;
+      quantize_task<G, NITER, DT, QUAD, false>(a.src, p, tok0, Tc, q * 4, ovalid && q < a.TQ, a.C, maxf,
+                                               QUAD ? sym_pc + (long long)q * a.C : nullptr, sym8_plane,
+                                               scale_out + 4 * hq, sl);
+    }
+  }
 }

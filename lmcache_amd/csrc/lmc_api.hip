@@ -176,8 +176,8 @@ static int launch_quant_dt(const QuantArgs& a, hipStream_t s) {
   const unsigned nz = (unsigned)((a.pc_limit + a.P - 1) / a.P);  // chunks that hold the plane-chunks to do
 #define LQ(G, N)                                                                                   \
   do {                                                                                             \
-    const int per_wg = 4 * (64 / (G));                                                             \
-    dim3 grid((unsigned)((a.TQ + per_wg - 1) / per_wg), (unsigned)a.P, nz);                        \
+    const int per_wg = 4 * (64 / (G)), TO = (a.TQ + 1) / 2; /* row octs per plane-chunk */         \
+    dim3 grid((unsigned)((TO + per_wg - 1) / per_wg), (unsigned)a.P, nz);                          \
     hipLaunchKernelGGL((k_quantize<G, N, DT, QUAD>), grid, dim3(256), 0, s, a);                    \
   } while (0)
   if (C <= 128) LQ(16, 1);

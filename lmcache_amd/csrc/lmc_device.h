@@ -52,6 +52,10 @@ __device__ __forceinline__ long long lmc_tok_off(const KvAddr& a, int t) {
   return (long long)t * a.stride_token;
 }
 
+// Workspace symbol format of a plane: symbols are 0 .. bins - 2, so planes with bins <= 17 pack two per byte
+// (k_quantize.h writes, k_encode.h reads).
+__device__ __forceinline__ bool lmc_sym_nibbles(int bins) { return bins <= 17; }
+
 // Section offsets of a chunk blob with T tokens (mirror of lmc_blob_layout).
 struct BlobOff {
   u32 bins, rowpre, scales, cdf, gend, streams;
@@ -185,6 +189,16 @@ __device__ __forceinline__ u32 rans_put(u32 x, u32 f, u32 c, u32 st) {
 
 template <int I>
 struct IntTag { static constexpr int value = I; };  // compile-time integer passed as a value
+template <bool B>
+struct BoolTag { static constexpr bool value = B; };
+// Compile-time loop: f(IntTag<0>{}), f(IntTag<1>{}), ...
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IntTag<I>{});
+    static_for<N, I + 1>(f);
+  }
+}
 
 // e / 33 for e < 8192 (CDF rows are 33 entries)
 __device__ __forceinline__ u32 div33(u32 e) { return (e * 1986u) >> 16; }

@@ -97,6 +97,9 @@ class CacheGenDeviceCodec:
         self.device = torch.device("cuda", self.device_index)
         self.ctx = native.get_context(self.device_index)
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        # a second DMA queue for the device -> host leg: two hipMemcpyAsync streams keep two SDMA engines busy
+        self.copy_stream2 = torch.cuda.Stream(device=self.device)
+        self.d2h_streams = 2
         self._lock = threading.RLock()
         self._enc_arena: Optional[torch.Tensor] = None
         self._dec_arena: Optional[torch.Tensor] = None
@@ -150,11 +153,19 @@ class CacheGenDeviceCodec:
         blobs = []
         with self._lock:
             self.copy_stream.wait_event(job.done)
-            cs = self.copy_stream.cuda_stream
+            streams = [self.copy_stream]
+            if self.d2h_streams > 1 and len(sizes) > 1:
+                self.copy_stream2.wait_event(job.done)
+                streams.append(self.copy_stream2)
             for i, nb in enumerate(sizes):
                 hb = arena.alloc(nb)
-                native.memcpy_async(hb.ptr, job.arena.data_ptr() + i * job.stride, nb, "d2h", cs)
+                native.memcpy_async(hb.ptr, job.arena.data_ptr() + i * job.stride, nb, "d2h",
+                                    streams[i % len(streams)].cuda_stream)
                 blobs.append(hb)
+            if len(streams) > 1:  # fold the second queue into the first: one event covers both
+                ev2 = torch.cuda.Event()
+                ev2.record(self.copy_stream2)
+                self.copy_stream.wait_event(ev2)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
             self._arena_free = ev
