@@ -68,13 +68,13 @@ __device__ __forceinline__ u32 quant_special(float x, float factor, float maxf) 
 // workspace round trip of most planes is half a byte per element.
 // ROWS (4 or 2): rows loaded and reduced together -- 4 keeps 4*NITER 16-byte loads in flight per lane,
 // 2 halves the registers.
-template <int G, int NITER, int DT, bool QUAD, bool NIB, int ROWS = 4>
+template <int G, int NITER, int DT, bool QUAD, bool NIB, int ROWS = 4, int NQ = NIB ? 2 : 1>
 __device__ __forceinline__ void quantize_task(const KvAddr& src, int p, int tok0, int Tc, int t_first, bool qvalid,
-                                              int C, float maxf, u32* sym_out, int8_t* sym8_plane, u16* scale_out,
-                                              int sl) {
-  static_assert(ROWS == 2 || ROWS == 4 || (ROWS == 8 && NIB), "rows in flight: a power of two within the task");
-  static_assert(QUAD || !NIB, "nibble packing is a workspace format");
-  constexpr int NQ = NIB ? 2 : 1;  // row quads in the task
+                                              bool q1valid, int C, float maxf, u32* sym_out, int8_t* sym8_plane,
+                                              u16* scale_out, int sl) {
+  static_assert(ROWS == 2 || ROWS == 4 || (ROWS == 8 && NQ == 2), "rows in flight: a power of two within the task");
+  static_assert(QUAD || (!NIB && NQ == 1), "nibble packing and two-quad tasks are workspace formats");
+  static_assert(!NIB || NQ == 2, "a nibble dword holds two row quads");
   // per-lane channel runs (row independent)
   long long coff[NITER];
   int c0[NITER];
@@ -204,12 +204,22 @@ __device__ __forceinline__ void quantize_task(const KvAddr& src, int p, int tok0
 #pragma unroll
     for (int it = 0; it < NITER; it++) {
       if (!cval[it]) continue;
-      u32 w[8];
+      u32* dst = sym_out + c0[it];  // kernel-arg pointers: global already
+      if (NIB) {
+        u32 w[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) w[e] = NIB ? (o[0][it][e] | (o[NQ - 1][it][e] << 4)) : o[0][it][e];
-      u32* dst = sym_out + c0[it];
-      *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);  // kernel-arg pointers: global already
-      *reinterpret_cast<uint4*>(dst + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+        for (int e = 0; e < 8; e++) w[e] = o[0][it][e] | (o[NQ - 1][it][e] << 4);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(dst + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+      } else {
+#pragma unroll
+        for (int hq = 0; hq < NQ; hq++) {  // byte format: the task's row quads are adjacent [quad][channel] rows
+          if (hq == 1 && !q1valid) continue;
+          u32* d2 = dst + (long long)hq * C;
+          *reinterpret_cast<uint4*>(d2) = make_uint4(o[hq][it][0], o[hq][it][1], o[hq][it][2], o[hq][it][3]);
+          *reinterpret_cast<uint4*>(d2 + 4) = make_uint4(o[hq][it][4], o[hq][it][5], o[hq][it][6], o[hq][it][7]);
+        }
+      }
     }
   }
 }
@@ -236,16 +246,22 @@ __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
   u16* scale_out = reinterpret_cast<u16*>(a.scale_base + (long long)chunk * a.scale_stride) + ((long long)p * Tc + oct * 8);
   u32* sym_pc = QUAD ? a.sym4 + ((long long)chunk * a.P + p) * a.TQ * a.C : nullptr;  // this plane-chunk's workspace
   int8_t* sym8_plane = QUAD ? nullptr : a.sym8 + (long long)p * Tc * a.C;
-  if (QUAD && lmc_sym_nibbles(bins)) {
-    quantize_task<G, NITER, DT, QUAD, QUAD, (QUAD && NITER <= 2) ? 8 : 4>(a.src, p, tok0, Tc, oct * 8, ovalid, a.C, maxf, sym_pc + (long long)oct * a.C,
-                                            nullptr, scale_out, sl);
+  if constexpr (QUAD) {
+    constexpr int ROWS = NITER <= 2 ? 8 : 4;  // 16-byte loads in flight per lane: ROWS * NITER
+    u32* const sym_out = sym_pc + (long long)oct * (lmc_sym_nibbles(bins) ? 1 : 2) * a.C;
+    const bool q1valid = 2 * oct + 1 < a.TQ;
+    if (lmc_sym_nibbles(bins))
+      quantize_task<G, NITER, DT, true, true, ROWS, 2>(a.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out,
+                                                       nullptr, scale_out, sl);
+    else
+      quantize_task<G, NITER, DT, true, false, ROWS, 2>(a.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out,
+                                                        nullptr, scale_out, sl);
   } else {
 #pragma unroll 1
     for (int hq = 0; hq < 2; hq++) {
       const int q = 2 * oct + hq;
-      quantize_task<G, NITER, DT, QUAD, false>(a.src, p, tok0, Tc, q * 4, ovalid && q < a.TQ, a.C, maxf,
-                                               QUAD ? sym_pc + (long long)q * a.C : nullptr, sym8_plane,
-                                               scale_out + 4 * hq, sl);
+      quantize_task<G, NITER, DT, false, false>(a.src, p, tok0, Tc, q * 4, ovalid && q < a.TQ, false, a.C, maxf, nullptr,
+                                                sym8_plane, scale_out + 4 * hq, sl);
     }
   }
 }
