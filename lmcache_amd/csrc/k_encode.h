@@ -254,10 +254,23 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   const u32 T = (u32)Tc;
   const u32 magic = (T == 1u) ? 0xffffffffu : (u32)(0x100000000ull / T);
   {
+    // Symbols are 0 .. R (R = bins - 2), so entries above R are 65504 + i whatever the data (n = T there):
+    // only entries 1 .. R are divided.  T a power of two (the usual 256-token chunk) divides by a shift.
+    const u32 R = (u32)a.bins.b[p] - 2u;                 // wave-uniform; !ENCODE (lmc_calculate_cdf) passes 32 bins
+    const bool pow2 = (T & (T - 1u)) == 0u;
+    const u32 sh = 31u - (u32)__builtin_clz(T);          // log2(T) when pow2
+    const u32 half_m1 = sh ? (1u << (sh - 1u)) - 1u : 0u;
     u32 n = 0;
 #pragma unroll
     for (int i = 0; i <= 32; i++) {
-      const u32 ci = rne_div_u32(n * LMC_CDF_SCALE, T, magic) + (u32)i;
+      u32 ci = LMC_CDF_SCALE + (u32)i;
+      if (i == 0) {
+        ci = 0;
+      } else if ((u32)i <= R) {
+        const u32 v = n * LMC_CDF_SCALE;
+        if (pow2) ci = (sh ? (v + half_m1 + ((v >> sh) & 1u)) >> sh : v) + (u32)i;  // round half to even
+        else ci = rne_div_u32(v, T, magic) + (u32)i;
+      }
       tab[i * 64 + lane] = (u16)ci;  // entry 32 is 65536 stored as 0
       if (i < 32) n += (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
     }
