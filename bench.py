@@ -39,7 +39,7 @@ CTX, CHUNK = 16384, 256
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per step from the PMC passes committed under profiles/ (see profiles/r01_*_pmc.md): updated by hand
 # whenever the kernels' data flow changes; None until measured.
-TRAFFIC_BYTES_PER_STEP = 5_526_000_000  # profiles/r01_c_pmc.md
+TRAFFIC_BYTES_PER_STEP = 4_642_000_000  # profiles/r01_d_pmc.md
 
 
 def cachegen_bins_llama8b():
