@@ -40,6 +40,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per step from the PMC passes committed under profiles/ (see profiles/r01_*_pmc.md): updated by hand
 # whenever the kernels' data flow changes; None until measured.
 TRAFFIC_BYTES_PER_STEP = 4_642_000_000  # profiles/r01_d_pmc.md
+VALU_BUSY_DOMINANT = 0.946               # k_cdf_encode: SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles), profiles/r01_d_pmc.md
 
 
 def cachegen_bins_llama8b():
@@ -221,6 +222,9 @@ def main():
                 "kernels_ms_serial": {n: round(float(v), 4) for n, v in zip(knames, kms)},
                 "achieved_serial": round(serial, 1),
                 "algorithmic_bytes_per_step": int(algo_bytes),
+                # from the SQ PMC pass committed under profiles/ (not measured live): the dominant kernel is an
+                # integer entropy coder and sits under the VALU-issue roof, not the HBM one
+                "valu_busy_dominant_kernel": VALU_BUSY_DOMINANT,
                 "note": "achieved = (raw KV read once + blob written once) per step / HIP-event time of one step "
                         "(the whole encode job: k_quantize + k_cdf_encode) on the launch stream over the timed region; "
                         "kernels_ms_serial = per-kernel HIP events of one job (lmc_ctx_profile); traffic = HBM bytes per "
