@@ -244,8 +244,7 @@ def main():
             def store_once():
                 arena.reset()
                 job = codec.encode(layout, 0, CTX, CHUNK, bins)
-                sizes_h = codec.sizes_of(job)
-                hblobs, done = codec.offload(job, sizes_h, arena)
+                hblobs, done = codec.offload(job, None, arena)
                 done.synchronize()
                 return hblobs
 

@@ -141,8 +141,7 @@ class LMCLocalBackend(LMCBackendInterface):
 
     def _finish_encoded(self, keys: Sequence[CacheEngineKey], job, shapes, dtype) -> None:
         codec = self._codec()
-        sizes = codec.sizes_of(job)
-        blobs, done = codec.offload(job, sizes, self.host_arena)
+        blobs, done = codec.offload(job, None, self.host_arena)  # range by range, overlapping the rest of the encode
         done.synchronize()
         for key, hb, shp in zip(keys, blobs, shapes):
             self._publish(key, _HostChunk(hb, None, shp, dtype, True))

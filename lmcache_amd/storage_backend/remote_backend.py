@@ -189,11 +189,10 @@ class LMCPipelinedRemoteBackend(LMCRemoteBackend):
         with torch.cuda.device(src.device):
             job = codec.encode(src, tok_begin, tok_end, chunk_tokens, self.cachegen_config.plane_bins(src.L))
         # drain the device arena now (the next encode reuses it); only the connector writes may be deferred
-        sizes = codec.sizes_of(job)
         if self._host_arena is None:
-            self._host_arena = PinnedArena(slab_bytes=max(64 << 20, sum(sizes) + (1 << 20)))
+            self._host_arena = PinnedArena(slab_bytes=64 << 20)
         self._host_arena.reset()
-        blobs, done = codec.offload(job, sizes, self._host_arena)
+        blobs, done = codec.offload(job, None, self._host_arena)  # range by range, overlapping the rest of the encode
         done.synchronize()
         payload = _DeferredSets([(k, hb.tobytes()) for k, hb in zip(keys, blobs)])
         if blocking:

@@ -87,6 +87,9 @@ class EncodeJob:
     done: torch.cuda.Event     # recorded after the last encode kernel
     geometry: tuple            # (L, H, D, chunk_tokens)
     size_list: Optional[List[int]] = None  # filled by sizes_of (the pinned words are reused by the next job)
+    # a long job is launched as a few consecutive ranges of chunks, each with its own event, so that the
+    # host-DRAM offload of range r can start while range r+1 is still being encoded: (chunk0, chunk1, event)
+    parts: Optional[list] = None
 
 
 class CacheGenDeviceCodec:
@@ -100,6 +103,7 @@ class CacheGenDeviceCodec:
         # a second DMA queue for the device -> host leg: two hipMemcpyAsync streams keep two SDMA engines busy
         self.copy_stream2 = torch.cuda.Stream(device=self.device)
         self.d2h_streams = 2
+        self.encode_parts = 4                                # ranges a long encode job is launched in
         self._lock = threading.RLock()
         self._enc_arena: Optional[torch.Tensor] = None
         self._dec_arena: Optional[torch.Tensor] = None
@@ -129,11 +133,19 @@ class CacheGenDeviceCodec:
                 cur = torch.cuda.current_stream(self.device)
                 if self._arena_free is not None:
                     cur.wait_event(self._arena_free)  # previous job's D2H has read the arena
-                self.ctx.encode_chunks(src, tok_begin, tok_end, chunk_tokens, bins, self._enc_arena.data_ptr(),
-                                       stride, self._sizes.ptr, stream=cur.cuda_stream)
-                done = torch.cuda.Event()
-                done.record(cur)
-            job = EncodeJob(n, stride, self._enc_arena, self._sizes, done, (L, H, D, chunk_tokens))
+                nparts = self.encode_parts if n >= 4 * self.encode_parts else 1
+                per = (n + nparts - 1) // nparts
+                parts = []
+                for c0 in range(0, n, per):
+                    c1 = min(n, c0 + per)
+                    self.ctx.encode_chunks(src, tok_begin + c0 * chunk_tokens, min(tok_end, tok_begin + c1 * chunk_tokens),
+                                           chunk_tokens, bins, self._enc_arena.data_ptr() + c0 * stride, stride,
+                                           self._sizes.ptr + 4 * c0, stream=cur.cuda_stream)
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    parts.append((c0, c1, ev))
+                done = parts[-1][2]
+            job = EncodeJob(n, stride, self._enc_arena, self._sizes, done, (L, H, D, chunk_tokens), None, parts)
             self._pending = job
             return job
 
@@ -148,20 +160,38 @@ class CacheGenDeviceCodec:
                     self._pending = None
             return job.size_list
 
-    def offload(self, job: EncodeJob, sizes: Sequence[int], arena: PinnedArena) -> (List[HostBlob], torch.cuda.Event):
-        """hipMemcpyAsync every blob to pinned host DRAM on the side stream."""
+    def offload(self, job: EncodeJob, sizes: Optional[Sequence[int]], arena: PinnedArena) -> (List[HostBlob], torch.cuda.Event):
+        """hipMemcpyAsync every blob to pinned host DRAM on the side streams, exact sizes.  With sizes=None the
+        sizes are read range by range as the job's ranges complete, so the copies of one range overlap the
+        encode of the next (job.size_list is filled on the way)."""
         blobs = []
         with self._lock:
-            self.copy_stream.wait_event(job.done)
             streams = [self.copy_stream]
-            if self.d2h_streams > 1 and len(sizes) > 1:
-                self.copy_stream2.wait_event(job.done)
+            if self.d2h_streams > 1 and job.nchunks > 1:
                 streams.append(self.copy_stream2)
-            for i, nb in enumerate(sizes):
-                hb = arena.alloc(nb)
-                native.memcpy_async(hb.ptr, job.arena.data_ptr() + i * job.stride, nb, "d2h",
-                                    streams[i % len(streams)].cuda_stream)
-                blobs.append(hb)
+            progressive = sizes is None and job.size_list is None and job.parts is not None
+            if progressive:
+                sizes = []
+            elif sizes is None:
+                sizes = self.sizes_of(job)
+            for c0, c1, ev in (job.parts if progressive else [(0, job.nchunks, job.done)]):
+                if progressive:
+                    ev.synchronize()  # this range only
+                    if c0 == 0:
+                        self.ctx.raise_on_status("CacheGen encode")
+                    sizes.extend(job.sizes.tensor[4 * c0:4 * c1].view(torch.int32).tolist())
+                for st in streams:
+                    st.wait_event(ev)
+                for i in range(c0, c1):
+                    hb = arena.alloc(sizes[i])
+                    native.memcpy_async(hb.ptr, job.arena.data_ptr() + i * job.stride, sizes[i], "d2h",
+                                        streams[i % len(streams)].cuda_stream)
+                    blobs.append(hb)
+            if progressive:
+                self.ctx.raise_on_status("CacheGen encode")
+                job.size_list = list(sizes)
+                if self._pending is job:
+                    self._pending = None
             if len(streams) > 1:  # fold the second queue into the first: one event covers both
                 ev2 = torch.cuda.Event()
                 ev2.record(self.copy_stream2)
