@@ -19,18 +19,23 @@
  *
  *   header   128 B          struct lmc_blob_header
  *   bins     u8  [P]        quantisation bins of each plane (32 or 16 ...)
- *   rowpre   u16 [P+1]      rowpre[p] = sum over planes before p of R, R = bins - 2
+ *   rowpre   u16 [P+1]      rowpre[p] = sum over planes before p of R, R = bins - 1
  *   scales   u16 [P][T]     per-(plane,token) absmax, raw bits of the KV dtype
  *                           (= max_tensors_key ++ max_tensors_value)
- *   cdf      per plane p: u16 [C][R_p], the entries cdf[1 .. R_p] of each channel's
- *                           16-bit CDF (plane p starts C * rowpre[p] entries in).
- *                           The values are exactly those of the reference's `cdf`
- *                           tensor [2L, C, 33]; the entries left out are implied by
- *                           the quantiser's symbol range 0 .. bins-2:
- *                             cdf[0] = 0,  cdf[i] = 65504 + i (mod 2^16) for i > R_p
- *                           (n_i = T there, and RNE(T*65504/T) = 65504).  Storing
- *                           30 / 14 entries instead of 33 shrinks a Llama-3-8B chunk
- *                           blob from 11.1 MB to 9.0 MB (3.0x -> 3.7x).
+ *   cdf      the per-channel symbol statistics the 16-bit CDF is a function of.  Per plane p:
+ *                           [C][R_p] counts of the symbols 0 .. R_p - 1, R_p = bins - 1 being
+ *                           the number of symbols the quantiser can emit (plane p starts
+ *                           C * rowpre[p] entries in).  header.count_bytes = 1 when T <= 256:
+ *                           one byte per count, a count of 256 stored as 255 (the counts of
+ *                           a channel sum to T, so a reader adds T - sum to the entry that
+ *                           reads 255); otherwise 2 (u16).  The CDF of a channel is
+ *                             cdf[i] = RNE(N_i * 65504 / T) + i  (mod 2^16),
+ *                             N_i = number of its symbols < i,  i = 0 .. 32
+ *                           -- exactly the values of the reference's `cdf` tensor
+ *                           [2L, C, 33] (cachegen_encoder.py:95-126, 175-222; entries above
+ *                           R_p come out as 65504 + i because N_i = T there).  Counts
+ *                           instead of the 33 (v1) or bins - 2 (v2) u16 entries take a
+ *                           Llama-3-8B chunk blob from 11.1 MB (v1) over 9.0 MB to 7.9 MB.
  *   gend     u32 [P][G]     EXACT end offset (bytes, relative to the streams
  *                           section) of group stream (p,g); G = ceil(C/64).
  *                           Stream (p,g) starts at roundup16(gend[prev]) (0 for
@@ -59,7 +64,7 @@ extern "C" {
 #endif
 
 #define LMC_BLOB_MAGIC 0x31434D4Cu /* "LMC1" */
-#define LMC_BLOB_VERSION 2u
+#define LMC_BLOB_VERSION 3u
 #define LMC_HEADER_BYTES 128u
 
 #define LMC_DTYPE_BF16 0
@@ -94,16 +99,19 @@ typedef struct lmc_blob_header {
   uint32_t total_bytes;  /* off_streams + stream_bytes */
   uint32_t off_rowpre;
   uint32_t cdf_rows;     /* rowpre[P] = sum of R over all planes */
-  uint32_t reserved[12];
+  uint32_t count_bytes;  /* bytes per stored count: 1 (T <= 256) or 2 */
+  uint32_t reserved[11];
 } lmc_blob_header;
 
 static inline uint32_t lmc_r16(uint32_t x) { return (x + 15u) & ~15u; }
 
-/* CDF entries stored per channel of a plane quantised with `bins` bins. */
-static inline uint32_t lmc_cdf_row(uint32_t bins) { return bins - 2u; }
+/* Counts stored per channel of a plane quantised with `bins` bins: one per symbol 0 .. bins-2. */
+static inline uint32_t lmc_cdf_row(uint32_t bins) { return bins - 1u; }
+/* Bytes per stored count for a chunk of T tokens. */
+static inline uint32_t lmc_count_bytes(uint32_t T) { return T <= 256u ? 1u : 2u; }
 
 /* Section offsets for a chunk geometry.  cdf_rows = sum over planes of lmc_cdf_row(bins[p]);
- * pass 30 * P (all planes at 32 bins) for an upper bound. */
+ * pass 31 * P (all planes at 32 bins) for an upper bound. */
 static inline void lmc_blob_layout(uint32_t L, uint32_t T, uint32_t H, uint32_t D, uint32_t cdf_rows,
                                    lmc_blob_header* h) {
   uint32_t C = H * D, P = 2u * L, G = (C + LMC_LANES - 1u) / LMC_LANES;
@@ -113,11 +121,12 @@ static inline void lmc_blob_layout(uint32_t L, uint32_t T, uint32_t H, uint32_t 
   h->num_layers = L; h->ntokens = T; h->num_heads = H; h->head_size = D;
   h->nchannels = C; h->nplanes = P; h->ngroups = G; h->lp = LMC_LP;
   h->cdf_rows = cdf_rows;
+  h->count_bytes = lmc_count_bytes(T);
   h->off_bins = LMC_HEADER_BYTES;
   h->off_rowpre = h->off_bins + lmc_r16(P);
   h->off_scales = h->off_rowpre + lmc_r16(2u * (P + 1u));
   h->off_cdf = h->off_scales + lmc_r16(2u * P * T);
-  h->off_gend = h->off_cdf + lmc_r16(2u * C * cdf_rows);
+  h->off_gend = h->off_cdf + lmc_r16(h->count_bytes * C * cdf_rows);
   h->off_streams = h->off_gend + lmc_r16(4u * P * G);
 }
 
@@ -131,7 +140,7 @@ static inline uint32_t lmc_group_cap_bytes(uint32_t T) {
 /* Worst-case blob size for a chunk geometry (every plane at 32 bins). */
 static inline uint64_t lmc_blob_bound(uint32_t L, uint32_t T, uint32_t H, uint32_t D) {
   lmc_blob_header h;
-  lmc_blob_layout(L, T, H, D, 30u * 2u * L, &h);
+  lmc_blob_layout(L, T, H, D, 31u * 2u * L, &h);
   return (uint64_t)h.off_streams + (uint64_t)h.nplanes * h.ngroups * lmc_group_cap_bytes(T);
 }
 

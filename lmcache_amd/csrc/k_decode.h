@@ -74,40 +74,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   const u32 cdf_rows = hdw(19);
   const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, cdf_rows);
   if (hdw(0) != LMC_BLOB_MAGIC || (hdw(1) & 0xffffu) != LMC_BLOB_VERSION || hdw(7) != (u32)a.C ||
-      hdw(8) != (u32)a.P || hdw(15) != bo.streams || cdf_rows > 30u * (u32)a.P) {
+      hdw(8) != (u32)a.P || hdw(15) != bo.streams || cdf_rows > 31u * (u32)a.P || hdw(20) != dev_count_bytes(T)) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_HEADER);
     return;
   }
   const int c = g * 64 + lane;
   const bool active = c < a.C;
 
-  // ---- CDF rows of this group -> LDS [entry][lane] (coalesced 2-byte loads, transposed LDS writes) ----
-  // The blob stores entries 1..R of each row (R = bins - 2); entry 0 is 0 and entries above R are
-  // 65504 + i (lmc_format.h).
-  const u32 R = min(30u, max(2u, (u32)__builtin_amdgcn_readfirstlane((int)blob[bo.bins + p]) - 2u));
+  // ---- symbol counts of this group -> the CDF table in LDS, [entry][lane] u16 ----------------------------
+  // The blob stores the counts of every channel's symbols 0 .. nsym-1 (nsym = bins - 1), one byte each for
+  // T <= 256 (lmc_format.h).  They are fetched coalesced, staged transposed in the table's own LDS, and
+  // every lane then turns its column into the CDF with the encoder's integer arithmetic.
+  const u32 nsym = min(31u, max(3u, (u32)__builtin_amdgcn_readfirstlane((int)blob[bo.bins + p]) - 1u));
   {
     const u32 rp = (u32)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const u16*>(blob + bo.rowpre)[p]);
-    const float rcpR = 1.0f / (float)R;
-    const u32 total = (u32)min(64, a.C - g * 64) * R;
-    const u16* src = reinterpret_cast<const u16*>(blob + bo.cdf) + (long long)a.C * rp + (long long)g * 64 * R;
+    const float rcpR = 1.0f / (float)nsym;
+    const u32 total = (u32)min(64, a.C - g * 64) * nsym;
+    const long long e00 = (long long)a.C * rp + (long long)g * 64 * nsym;
+    const bool bytes1 = dev_count_bytes(T) == 1u;  // wave-uniform
+    const u8* src8 = blob + bo.cdf + e00;
+    const u16* src16 = reinterpret_cast<const u16*>(blob + bo.cdf) + e00;
 #pragma unroll 1
-    for (u32 e0 = 0; e0 < total; e0 += 64 * 10) {  // <= 30 sweeps of 64, 10 loads in flight
-      u16 v[10];
+    for (u32 e0 = 0; e0 < total; e0 += 64 * 10) {  // <= 31 sweeps of 64, 10 loads in flight
+      u32 v[10];
 #pragma unroll
       for (int i = 0; i < 10; i++) {
         const u32 e = e0 + i * 64 + lane;
-        v[i] = e < total ? src[e] : (u16)0;
+        v[i] = e < total ? (bytes1 ? (u32)src8[e] : (u32)src16[e]) : 0u;
       }
 #pragma unroll
       for (int i = 0; i < 10; i++) {
         const u32 e = e0 + i * 64 + lane;
-        u32 cl, s;
-        divmod_small(e, R, rcpR, cl, s);
-        if (e < total) cdfT[(s + 1u) * 64 + cl] = v[i];
+        u32 cl, sidx;
+        divmod_small(e, nsym, rcpR, cl, sidx);
+        if (e < total) cdfT[sidx * 64 + cl] = (u16)v[i];
       }
     }
-    cdfT[lane] = 0;
-    for (u32 i = R + 1u; i < (u32)LMC_LP; i++) cdfT[i * 64 + lane] = (u16)(LMC_CDF_SCALE + i);
+    for (u32 i = nsym; i < 32u; i++) cdfT[i * 64 + lane] = 0;  // symbols that cannot occur
+    wave_lds_fence();  // the staging was written transposed
+    u32 hreg[16];  // this lane's 32 counts, two per register
+#pragma unroll
+    for (int i = 0; i < 16; i++) hreg[i] = (u32)cdfT[(2 * i) * 64 + lane] | ((u32)cdfT[(2 * i + 1) * 64 + lane] << 16);
+    if (bytes1) {  // a count of 256 was stored as 255: the counts of a channel sum to T
+      u32 sum = 0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) sum += (hreg[i] & 0xffffu) + (hreg[i] >> 16);
+      const u32 deficit = T - sum;  // 0 or 1 in a well-formed blob
+      if (__ballot(deficit != 0u)) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          if ((hreg[i] & 0xffffu) == 255u) hreg[i] += deficit & 0xffffu;
+          else if ((hreg[i] >> 16) == 255u) hreg[i] += (deficit & 0xffffu) << 16;
+        }
+      }
+    }
+    cdf_column_to_lds(hreg, T, nsym, cdfT, lane);
     if (!active) {  // idle lanes: any strictly increasing column keeps the search in range
 #pragma unroll
       for (int i = 0; i < 33; i++) cdfT[i * 64 + lane] = (u16)i;
@@ -161,12 +182,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   u32 pending = 0;      // loads for [filled, filled + 256) are in flight
   wave_lds_fence();
 
-  // The symbol search is a binary search over the lane's CDF column.  Symbols are 0 .. R-1 (R = bins - 2),
-  // so planes with R <= 15 (16 bins: most of them) search entries 0..15 only (TOP = 4), the others 0..31
+  // The symbol search is a binary search over the lane's CDF column.  Symbols are 0 .. nsym-1 (nsym = bins - 1),
+  // so planes with nsym <= 16 (16 bins: most of them) search entries 0..15 only (TOP = 4), the others 0..31
   // (TOP = 8).  Its first two levels run on three pivots held in registers.
   typedef const __attribute__((address_space(3))) u16* lds_u16p;  // 32-bit LDS pointers: no generic-pointer math
   const lds_u16p col = (lds_u16p)cdfT + lane;
-  const u32 top = R <= 15u ? 4u : 8u;  // wave-uniform
+  const u32 top = nsym <= 16u ? 4u : 8u;  // wave-uniform
   const lds_u16p colB = col + 2u * top * 64u;
   const u32 pA = col[top * 64u], pB = colB[0], pC = col[3u * top * 64u];
   typedef const __attribute__((address_space(3))) float* lds_f32p;

@@ -63,6 +63,7 @@ __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, c
   for (u32 i = lane; i < (bo.scales - bo.rowpre) / 2; i += 64)
     reinterpret_cast<u16*>(blob + bo.rowpre)[i] = i <= P ? a.bins.rowpre[i] : (u16)0;
   for (u32 i = bo.scales + 2u * P * T + lane; i < bo.cdf; i += 64) blob[i] = 0;
+  for (u32 i = bo.cdf + dev_count_bytes(T) * (u32)a.C * cdf_rows + lane; i < bo.gend; i += 64) blob[i] = 0;
   for (u32 i = bo.gend + 4u * n + lane; i < bo.streams; i += 64) blob[i] = 0;
   if (lane < 32) {
     u32 v = 0;
@@ -87,6 +88,7 @@ __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, c
       case 17: v = bo.streams + stream_bytes; break;
       case 18: v = bo.rowpre; break;
       case 19: v = cdf_rows; break;
+      case 20: v = dev_count_bytes(T); break;
       default: v = 0;
     }
     reinterpret_cast<u32*>(blob)[lane] = v;
@@ -245,6 +247,33 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
       atomicAdd(&hrow[s * 32], one);
     }
   }
+  if (ENCODE) {
+    // The blob stores the COUNTS of every channel's symbols 0 .. R-1 (R = bins - 1; lmc_format.h): this
+    // group's [channel][R] block is contiguous, written with consecutive lanes on consecutive entries,
+    // reading the histogram transposed.  One byte per count for T <= 256 (256 saturates to 255).
+    wave_lds_fence();  // every lane's ds_add has landed
+    const u32 T = (u32)Tc;
+    const u32 R = (u32)a.bins.b[p] - 1u;
+    const float rcpR = 1.0f / (float)R;
+    const u32 total = (u32)min(64, a.C - g * 64) * R;
+    const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
+    u8* sec = a.blobs + (long long)chunk * a.blob_stride + bo.cdf;
+    const long long e0 = (long long)a.C * a.bins.rowpre[p] + (long long)g * 64 * R;
+    if (dev_count_bytes(T) == 1u) {
+      for (u32 e = lane; e < total; e += 64) {
+        u32 cl, sidx;
+        divmod_small(e, R, rcpR, cl, sidx);
+        sec[e0 + e] = (u8)min((u32)tab[sidx * 64 + cl], 255u);
+      }
+    } else {
+      u16* dst = reinterpret_cast<u16*>(sec) + e0;
+      for (u32 e = lane; e < total; e += 64) {
+        u32 cl, sidx;
+        divmod_small(e, R, rcpR, cl, sidx);
+        dst[e] = tab[sidx * 64 + cl];
+      }
+    }
+  }
   u32 hreg[16];  // this lane's 32 counts, two per register
 #pragma unroll
   for (int i = 0; i < 16; i++) hreg[i] = (u32)tab[(2 * i) * 64 + lane] | ((u32)tab[(2 * i + 1) * 64 + lane] << 16);
@@ -252,45 +281,11 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
 
   // ---- CDF ------------------------------------------------------------------
   const u32 T = (u32)Tc;
-  const u32 magic = (T == 1u) ? 0xffffffffu : (u32)(0x100000000ull / T);
-  {
-    // Symbols are 0 .. R (R = bins - 2), so entries above R are 65504 + i whatever the data (n = T there):
-    // only entries 1 .. R are divided.  T a power of two (the usual 256-token chunk) divides by a shift.
-    const u32 R = (u32)a.bins.b[p] - 2u;                 // wave-uniform; !ENCODE (lmc_calculate_cdf) passes 32 bins
-    const bool pow2 = (T & (T - 1u)) == 0u;
-    const u32 sh = 31u - (u32)__builtin_clz(T);          // log2(T) when pow2
-    const u32 half_m1 = sh ? (1u << (sh - 1u)) - 1u : 0u;
-    u32 n = 0;
-#pragma unroll
-    for (int i = 0; i <= 32; i++) {
-      u32 ci = LMC_CDF_SCALE + (u32)i;
-      if (i == 0) {
-        ci = 0;
-      } else if ((u32)i <= R) {
-        const u32 v = n * LMC_CDF_SCALE;
-        if (pow2) ci = (sh ? (v + half_m1 + ((v >> sh) & 1u)) >> sh : v) + (u32)i;  // round half to even
-        else ci = rne_div_u32(v, T, magic) + (u32)i;
-      }
-      tab[i * 64 + lane] = (u16)ci;  // entry 32 is 65536 stored as 0
-      if (i < 32) n += (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-    }
-  }
+  // !ENCODE (lmc_calculate_cdf) has no bins: every entry is computed
+  cdf_column_to_lds(hreg, T, ENCODE ? (u32)a.bins.b[p] - 1u : 33u, tab, lane);
   wave_lds_fence();  // columns are read by other lanes below
   if (ENCODE) {
-    // The blob keeps entries 1..R of every channel row (R = bins - 2; the rest is implied, lmc_format.h).
-    // This group's rows are contiguous: write them with consecutive lanes on consecutive u16 (128 B per
-    // store), reading LDS transposed.
-    const u32 R = (u32)a.bins.b[p] - 2u;
-    const float rcpR = 1.0f / (float)R;
-    const u32 total = (u32)min(64, a.C - g * 64) * R;
-    const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
-    u16* dst = reinterpret_cast<u16*>(a.blobs + (long long)chunk * a.blob_stride + bo.cdf) +
-               (long long)a.C * a.bins.rowpre[p] + (long long)g * 64 * R;
-    for (u32 e = lane; e < total; e += 64) {
-      u32 cl, s;
-      divmod_small(e, R, rcpR, cl, s);
-      dst[e] = tab[(s + 1u) * 64 + cl];
-    }
+    // nothing to write: the blob carries the counts (written above), the CDF is a function of them
   } else {
     // lmc_calculate_cdf: the reference's full [P][C][33] layout
     const u32 total = (u32)min(64, a.C - g * 64) * LMC_LP;

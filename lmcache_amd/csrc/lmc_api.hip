@@ -464,7 +464,7 @@ int lmc_blob_info(const void* blob_h, size_t nbytes, lmc_blob_header* out) {
   memcpy(&h, blob_h, sizeof h);
   if (h.magic != LMC_BLOB_MAGIC || h.version != LMC_BLOB_VERSION || h.header_bytes != LMC_HEADER_BYTES) return LMC_ERR_INVALID;
   if (h.num_layers == 0 || h.ntokens == 0 || h.num_heads == 0 || h.head_size == 0) return LMC_ERR_INVALID;
-  if (h.num_layers > LMC_MAX_PLANES / 2 || h.cdf_rows > 30u * 2u * h.num_layers) return LMC_ERR_INVALID;
+  if (h.num_layers > LMC_MAX_PLANES / 2 || h.cdf_rows > 31u * 2u * h.num_layers || h.count_bytes != lmc_count_bytes(h.ntokens)) return LMC_ERR_INVALID;
   lmc_blob_header ref;
   memset(&ref, 0, sizeof ref);
   lmc_blob_layout(h.num_layers, h.ntokens, h.num_heads, h.head_size, h.cdf_rows, &ref);

@@ -56,6 +56,9 @@ __device__ __forceinline__ long long lmc_tok_off(const KvAddr& a, int t) {
 // (k_quantize.h writes, k_encode.h reads).
 __device__ __forceinline__ bool lmc_sym_nibbles(int bins) { return bins <= 17; }
 
+// device twin of lmc_count_bytes (lmc_format.h): bytes per stored symbol count
+__device__ __forceinline__ u32 dev_count_bytes(u32 T) { return T <= 256u ? 1u : 2u; }
+
 // Section offsets of a chunk blob with T tokens (mirror of lmc_blob_layout).
 struct BlobOff {
   u32 bins, rowpre, scales, cdf, gend, streams;
@@ -66,7 +69,7 @@ __device__ __forceinline__ BlobOff lmc_blob_off(u32 P, u32 T, u32 C, u32 G, u32 
   o.rowpre = o.bins + ((P + 15u) & ~15u);
   o.scales = o.rowpre + ((2u * (P + 1u) + 15u) & ~15u);
   o.cdf = o.scales + ((2u * P * T + 15u) & ~15u);
-  o.gend = o.cdf + ((2u * C * cdf_rows + 15u) & ~15u);
+  o.gend = o.cdf + ((dev_count_bytes(T) * C * cdf_rows + 15u) & ~15u);
   o.streams = o.gend + ((4u * P * G + 15u) & ~15u);
   return o;
 }
@@ -170,6 +173,34 @@ __device__ __forceinline__ void divmod_est(u32 x, u32 f, u32& q, u32& r) {
   const bool fix = re >= f;
   q = qe + (fix ? 1u : 0u);
   r = fix ? re - f : re;
+}
+
+// The 33-entry CDF column of this lane's channel from its symbol counts (hreg[k] = count of symbol 2k |
+// count of symbol 2k+1 << 16), written to LDS as tab[entry][lane] u16 (entry 32 is 65536 stored as 0):
+//   cdf[i] = RNE(N_i * 65504 / T) + i,  N_i = number of symbols < i   (cachegen_encoder.py:95-126)
+// in exact integer arithmetic.  Symbols are 0 .. nsym - 1, so N_i = T and cdf[i] = 65504 + i from entry nsym
+// on whatever the data: only entries 1 .. nsym - 1 are divided, by a shift when T is a power of two (the
+// usual 256-token chunk).  Shared by the encoder (counts from its histogram) and the decoder (counts from
+// the blob).
+__device__ __forceinline__ void cdf_column_to_lds(const u32 (&hreg)[16], u32 T, u32 nsym, u16* tab, int lane) {
+  const u32 magic = (T == 1u) ? 0xffffffffu : (u32)(0x100000000ull / T);
+  const bool pow2 = (T & (T - 1u)) == 0u;
+  const u32 sh = 31u - (u32)__builtin_clz(T);  // log2(T) when pow2
+  const u32 half_m1 = sh ? (1u << (sh - 1u)) - 1u : 0u;
+  u32 n = 0;
+#pragma unroll
+  for (int i = 0; i <= 32; i++) {
+    u32 ci = LMC_CDF_SCALE + (u32)i;
+    if (i == 0) {
+      ci = 0;
+    } else if ((u32)i < nsym) {
+      const u32 v = n * LMC_CDF_SCALE;
+      if (pow2) ci = (sh ? (v + half_m1 + ((v >> sh) & 1u)) >> sh : v) + (u32)i;  // round half to even
+      else ci = rne_div_u32(v, T, magic) + (u32)i;
+    }
+    tab[i * 64 + lane] = (u16)ci;
+    if (i < 32) n += (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+  }
 }
 
 // One rANS state update x' = ((x / f) << 16) + (x % f) + st for x < f * 2^16, 1 <= f < 2^16,

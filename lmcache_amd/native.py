@@ -56,7 +56,7 @@ class BlobHeader(ctypes.Structure):
                 ("off_bins", ctypes.c_uint32), ("off_scales", ctypes.c_uint32), ("off_cdf", ctypes.c_uint32),
                 ("off_gend", ctypes.c_uint32), ("off_streams", ctypes.c_uint32), ("stream_bytes", ctypes.c_uint32),
                 ("total_bytes", ctypes.c_uint32), ("off_rowpre", ctypes.c_uint32), ("cdf_rows", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32 * 12)]
+                ("count_bytes", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 11)]
 
 
 # name -> (restype, argtypes); every symbol include/lmc_hip.h declares
@@ -149,15 +149,16 @@ def group_cap_bytes(T: int) -> int:
 
 
 def blob_static_bytes(L: int, T: int, H: int, D: int, bins: Optional[Sequence[int]] = None) -> int:
-    """Bytes in front of the streams section (lmc_blob_layout): header, bins, rowpre, scales, the tight CDF
-    rows (bins - 2 entries per channel; every plane at 32 bins when `bins` is None) and gend."""
+    """Bytes in front of the streams section (lmc_blob_layout): header, bins, rowpre, scales, the symbol
+    counts (bins - 1 per channel, one byte each for T <= 256 else two; every plane at 32 bins when `bins` is
+    None) and gend."""
     C, P = H * D, 2 * L
     G = (C + LANES - 1) // LANES
-    rows = 30 * P if bins is None else sum(int(b) - 2 for b in bins)
+    rows = 31 * P if bins is None else sum(int(b) - 1 for b in bins)
     off = HEADER_BYTES + r16(P)
     off += r16(2 * (P + 1))
     off += r16(2 * P * T)
-    off += r16(2 * C * rows)
+    off += r16((1 if T <= 256 else 2) * C * rows)
     off += r16(4 * P * G)
     return off
 

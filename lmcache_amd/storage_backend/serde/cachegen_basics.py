@@ -113,18 +113,30 @@ class CacheGenGPUEncoderOutput:
 
     @property
     def cdf(self) -> torch.Tensor:
-        """int16 [2L, C, 33] -- the reference's `cdf` tensor, rebuilt from the blob's tight rows: the blob
-        stores entries 1..bins-2 of every channel; entry 0 is 0 and the entries above are 65504 + i."""
+        """int16 [2L, C, 33] -- the reference's `cdf` tensor, rebuilt from the blob: the container stores the
+        symbol counts of every channel, and cdf[i] = RNE(N_i * 65504 / T) + i with N_i the number of symbols
+        < i (cachegen_encoder.py:95-126; include/lmc_format.h)."""
         h = self.header
-        P, C, LP = int(h.nplanes), int(h.nchannels), int(h.lp)
+        P, C, LP, T = int(h.nplanes), int(h.nchannels), int(h.lp), int(h.ntokens)
         rowpre = self._section(h.off_rowpre, P + 1, np.uint16).astype(np.int64)
-        rows = self._section(h.off_cdf, C * int(rowpre[P]), np.uint16)
+        dt = np.uint8 if int(h.count_bytes) == 1 else np.uint16
+        stored = self._section(h.off_cdf, C * int(rowpre[P]), dt).astype(np.int64)
         full = np.empty((P, C, LP), np.uint16)
-        full[:, :, 0] = 0
+        i = np.arange(LP, dtype=np.int64)
         for p, b in enumerate(self.bins):
-            R = b - 2
-            full[p, :, 1:R + 1] = rows[C * rowpre[p]:C * rowpre[p + 1]].reshape(C, R)
-            full[p, :, R + 1:] = (65504 + np.arange(R + 1, LP)).astype(np.uint16)
+            R = b - 1
+            cnt = stored[C * rowpre[p]:C * rowpre[p + 1]].reshape(C, R).copy()
+            if dt is np.uint8:  # a count of 256 reads 255: the counts of a channel sum to T
+                short = T - cnt.sum(axis=1)
+                rows, cols = np.nonzero((cnt == 255) & (short[:, None] > 0))
+                cnt[rows, cols] += short[rows]
+            N = np.zeros((C, LP), np.int64)
+            N[:, 1:R + 1] = np.cumsum(cnt, axis=1)
+            N[:, R + 1:] = N[:, R:R + 1]
+            v = N * 65504
+            q, r = v // T, v % T
+            q = q + ((2 * r > T) | ((2 * r == T) & (q % 2 == 1)))  # round half to even
+            full[p] = ((q + i) & 0xffff).astype(np.uint16)
         return torch.from_numpy(full.view(np.int16))
 
     def _scales(self) -> torch.Tensor:

@@ -232,3 +232,41 @@ def test_pipelined_remote_backend_keeps_one_result_per_key():
     finally:
         be.close()
     assert be._fetcher is None
+
+
+@pytest.mark.parametrize("T", [256, 255, 300, 1])
+def test_blob_counts_section_rebuilds_the_reference_cdf(oracle, T):
+    """Format v3 stores symbol COUNTS (one byte for T <= 256, a count of 256 saturating to 255) and the CDF is a
+    function of them: the numpy rebuild of CacheGenEncoderOutput.cdf and the oracle's C rebuild must both give the
+    CDF computed from the symbols, including channels whose every token carries the same symbol."""
+    from lmcache_amd import native
+    from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenEncoderOutput
+    torch.manual_seed(T)
+    L, H, D = 2, 2, 64
+    kv = torch.randn(L, 2, T, H * D).to(torch.bfloat16)
+    kv[:, :, :, 5] = 0          # constant channel: count == T on one symbol (the middle one)
+    kv[0, 0, :, 7] = kv[0, 0, :, :].abs().amax(dim=-1)  # always the row max: top symbol every token
+    bits, code = oracle.torch_to_bits(kv)
+    bins = np.array([32, 16, 32, 16], np.int32)
+    blob = oracle.encode_blob(bits, code, H, D, bins)
+    h = native.blob_info(blob)
+    assert h.version == 3 and h.count_bytes == (1 if T <= 256 else 2)
+    assert h.off_gend - h.off_cdf == native.r16(h.count_bytes * H * D * sum(int(b) - 1 for b in bins))
+    assert native.blob_static_bytes(L, T, H, D, bins) == h.off_streams
+    sym, _ = oracle.quantize(bits, code, bins)
+    want = oracle.cdf(sym)
+    assert np.array_equal(CacheGenEncoderOutput.from_bytes(blob).cdf.numpy().view(np.uint16), want)
+    assert np.array_equal(oracle.blob_cdf(blob), want)
+    assert np.array_equal(oracle.decode_blob_symbols(blob), sym)
+    if T == 256:  # the saturated count is really there
+        sec = np.frombuffer(blob, np.uint8, count=H * D * 31, offset=h.off_cdf).reshape(H * D, 31)
+        assert sec[5].max() == 255 and sec[5].sum() == 255
+
+
+def test_divmod_small_is_exact_for_every_row_length():
+    """The kernels split e into (e / R, e % R) with one float multiply (lmc_device.h divmod_small); R is the
+    number of counts per channel, 3 .. 31, e < 64 * R."""
+    for R in range(2, 32):
+        e = np.arange(64 * R, dtype=np.uint32)
+        q = ((e.astype(np.float32) + np.float32(0.5)) * (np.float32(1.0) / np.float32(R))).astype(np.uint32)
+        assert np.array_equal(q, e // R), R
