@@ -95,7 +95,9 @@ __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, c
   }
 }
 
-#define ENC_WAVE_DWORDS 1056  // 4224 B per wave: histogram [32][64] u16, then (aliased) CDF table [33][64] u16
+#define ENC_TAB_DWORDS 1056   // 4224 B per wave: histogram [32][64] u16, then (aliased) CDF table [33][64] u16
+#define ENC_RING_WORDS 256    // + a 512-B staging ring for the renormalisation words (flushed 256 B at a time)
+#define ENC_WAVE_DWORDS (ENC_TAB_DWORDS + ENC_RING_WORDS / 2)
 
 struct PendingTile {
   int chunk, pg;
@@ -305,14 +307,23 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   u32 wcur = 0;  // wave-uniform word cursor
 
   // one token: renormalise (append this step's words in ascending lane order), then encode
-  LMC_GLOBAL u8* const outb = (LMC_GLOBAL u8*)out;  // uniform base; per-lane 32-bit byte offsets
+  // The words of a step (a few dozen bytes) go to a wave-private LDS ring; whenever 128 words have gathered
+  // they leave with one coalesced 256-byte store.
+  u16* const ring = reinterpret_cast<u16*>(hist + ENC_TAB_DWORDS);
+  LMC_GLOBAL u32* const out32 = (LMC_GLOBAL u32*)out;
+  u32 flushed = 0;  // words already in global memory (a multiple of 128), wave-uniform
   auto code_token = [&](u32 st, u32 f) {
     const u32 xh = x >> 16;
     const bool emit = xh >= f;  // <=> x >= f << 16
     const u64 mask = __ballot(emit);
-    if (emit) *(LMC_GLOBAL u16*)(outb + ((wcur + lane_rank(mask)) << 1)) = (u16)x;
+    if (emit) ring[(wcur + lane_rank(mask)) & (ENC_RING_WORDS - 1)] = (u16)x;
     x = emit ? xh : x;
     wcur += (u32)__popcll(mask);
+    if (wcur - flushed >= 128u) {
+      wave_lds_fence();
+      out32[(flushed >> 1) + lane] = reinterpret_cast<const u32*>(ring)[((flushed & (ENC_RING_WORDS - 1)) >> 1) + lane];
+      flushed += 128u;
+    }
     x = rans_put(x, f, 0x10000u - f, st);
   };
 
@@ -364,6 +375,9 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   if (nib) pass2(BoolTag<true>{});
   else pass2(BoolTag<false>{});
   x = active ? x : LMC_RANS_L;  // idle lanes (channel >= C) carry the initial state
+  // the words still in the ring (< 128 + 64)
+  wave_lds_fence();
+  for (u32 k = flushed + lane; k < wcur; k += 64) out[k] = ring[k & (ENC_RING_WORDS - 1)];
   // tail: states, pad, length
   out[wcur + 2 * lane] = (u16)x;
   out[wcur + 2 * lane + 1] = (u16)(x >> 16);
