@@ -175,12 +175,13 @@ __device__ __forceinline__ u32 sym_of_token(const u32* symq, int C, int t, bool 
 
 template <bool QUADSYM, bool ENCODE>
 __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
-  __shared__ __attribute__((aligned(16))) u32 lds_all[4 * ENC_WAVE_DWORDS];
+  // the four staging rings come first so that each is 512-byte aligned (the word index wraps with one and-or)
+  __shared__ __attribute__((aligned(512))) u32 lds_all[4 * ENC_WAVE_DWORDS];
   const int lane = threadIdx.x & 63;
   // everything derived from the wave id is wave-uniform: keep it in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long ngroups_total = (long long)a.nchunks * a.P * a.G;
-  u32* hist = lds_all + wave * ENC_WAVE_DWORDS;    // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
+  u32* hist = lds_all + 4 * (ENC_RING_WORDS / 2) + wave * ENC_TAB_DWORDS;  // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
   u16* tab = reinterpret_cast<u16*>(hist);          // [33][64] u16 CDF, written after hist is in registers
 
   const long long gid = (long long)blockIdx.x * 4 + wave;
@@ -309,14 +310,17 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   // one token: renormalise (append this step's words in ascending lane order), then encode
   // The words of a step (a few dozen bytes) go to a wave-private LDS ring; whenever 128 words have gathered
   // they leave with one coalesced 256-byte store.
-  u16* const ring = reinterpret_cast<u16*>(hist + ENC_TAB_DWORDS);
+  u16* const ring = reinterpret_cast<u16*>(lds_all + wave * (ENC_RING_WORDS / 2));
+  typedef __attribute__((address_space(3))) u16* lds_u16w;
+  u32 ring_addr = (u32)(size_t)(lds_u16w)ring;  // 512-byte aligned LDS address
+  asm volatile("" : "+v"(ring_addr));           // in a VGPR, so that (x & 0x1fe) | ring_addr is one v_and_or_b32
   LMC_GLOBAL u32* const out32 = (LMC_GLOBAL u32*)out;
   u32 flushed = 0;  // words already in global memory (a multiple of 128), wave-uniform
   auto code_token = [&](u32 st, u32 f) {
     const u32 xh = x >> 16;
     const bool emit = xh >= f;  // <=> x >= f << 16
     const u64 mask = __ballot(emit);
-    if (emit) ring[(wcur + lane_rank(mask)) & (ENC_RING_WORDS - 1)] = (u16)x;
+    if (emit) *(lds_u16w)(size_t)(ring_addr | (((wcur + lane_rank(mask)) << 1) & (2 * ENC_RING_WORDS - 1))) = (u16)x;
     x = emit ? xh : x;
     wcur += (u32)__popcll(mask);
     if (wcur - flushed >= 128u) {
