@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
             else bits = (u16)f2fp16(val);
             LMC_GLOBAL u8* const row = PAGED ? (LMC_GLOBAL u8*)ubase + lmc_tok_off(a.dst, tdst0 + (int)t) * 2 : rowp;
             asm volatile("" : "+v"(off));  // keeps the zero-extension next to the store: SGPR base + 32-bit VGPR offset
-            *(LMC_GLOBAL u16*)(row + off) = bits;
+            __builtin_nontemporal_store(bits, (LMC_GLOBAL u16*)(row + off));  // written once, read by someone else later
           }
           rowp += row_step;
         }
