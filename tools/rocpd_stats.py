@@ -34,6 +34,15 @@ def main(argv):
     for name, n, tot, avg, mn, mx in rows:
         print(f"| `{name[:110]}` | {n} | {tot / 1e6:.3f} | {avg / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | "
               f"{100.0 * tot / total:.1f} |")
+    if min_grid:
+        rows = db.execute(
+            "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+            "where grid_x * grid_y * grid_z >= ? group by name order by sum(duration) desc", (min_grid,)).fetchall()
+        print(f"\n## Kernel dispatches of >= {min_grid} work-items only\n")
+        print("| kernel | calls | total ms | avg us | min us | max us |")
+        print("|---|---|---|---|---|---|")
+        for name, n, tot, avg, mn, mx in rows:
+            print(f"| `{name[:110]}` | {n} | {tot / 1e6:.3f} | {avg / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} |")
     try:
         pmc = db.execute("select kernel_name, counter_name, avg(value), avg(duration), count(*) "
                          "from counters_collection where grid_size >= ? group by kernel_name, counter_name "
