@@ -10,22 +10,25 @@
 // this kernel; 4 waves share a workgroup only to share the CU.
 //
 //   pass 1  per-lane histogram in LDS, u16 counters [symbol][lane]; lanes 2i and
-//           2i+1 share a dword and add 1 / 1 << 16 with ds_add_u32 (bank = lane / 2)
-//   CDF     cdf[i] = RNE(n_i * 65504 / T) + i, exact integer arithmetic, kept in
-//           LDS as tab[entry][lane] u16 (aliases the dead histogram: 4.2 KiB per
-//           wave -> 8 waves per SIMD) and written to the blob's cdf section with
-//           coalesced 2-byte stores read transposed from LDS
+//           2i+1 share a dword and add 1 / 1 << 16 with ds_add_u32 (bank = lane / 2).
+//           The counts go to the blob (its "cdf" section holds counts: lmc_format.h)
+//           with coalesced stores read transposed from LDS.
+//   CDF     cdf[i] = RNE(n_i * 65504 / T) + i, exact integer arithmetic
+//           (cdf_column_to_lds, shared with the decoder), kept in LDS as
+//           tab[entry][lane] u16 (aliases the dead histogram: 4.2 KiB per wave)
 //   pass 2  tokens T-1..0: renormalise (ballot + mbcnt append of 16-bit words,
-//           ascending lane order), then x = (x/f << 16) + x%f + start
-//           computed as x + (x/f) * (2^16 - f) + start (rans_put)
+//           ascending lane order, into a 512-byte LDS ring that is flushed 256 B at
+//           a time), then x = (x/f << 16) + x%f + start, computed as
+//           x + (x/f) * (2^16 - f) + start (rans_put)
 //   tail    64 states, zero pad to 16 B; then the stream is moved to its final place in the blob
 //           (compact_stream: single-pass prefix over the group lengths of the chunk)
+// 4.7 KiB of LDS per wave -> 8 waves per SIMD.
 #pragma once
 #include "lmc_device.h"
 
 struct EncodeArgs {
   // symbols
-  const u32* sym4;      // QUADSYM: [nchunks][P][TQ][C]
+  const u32* sym4;      // QUADSYM: symbol workspace, TQ*C dwords per (chunk, plane), format per plane (k_quantize.h)
   const int8_t* sym8;   // !QUADSYM: [P][T][C]
   int tok_begin, tok_end, chunk_tokens, nchunks;
   int P, C, G, TQ;

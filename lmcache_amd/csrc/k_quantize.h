@@ -7,17 +7,17 @@
 // in fp32 with separately rounded mul and add (-ffp-contract=off), IEEE
 // division, round-half-even.
 //
-// Mapping: a "row quad" = 4 consecutive tokens of one plane.  G lanes of a
-// wave own one row quad (G = 16/32/64 by channel count), each lane owns NITER
-// runs of 8 consecutive channels (one 16-byte load per row per run), so the
-// four rows of a quad give 4*NITER independent 16-byte loads in flight per
-// lane.  The row max is a packed-u16 integer max on |x| bit patterns
-// (NaN > inf > finite, which is torch.amax's NaN propagation) reduced with
-// xor-shuffles inside the G-lane group.
+// Mapping: a task = one "row oct", 8 consecutive tokens of one plane, taken by the G lanes of a wave
+// (G = 16/32/64 by channel count); each lane owns NITER runs of 8 consecutive channels (one 16-byte load
+// per row per run), so a task keeps 8*NITER independent 16-byte loads in flight per lane (NITER <= 2).
+// The row max is a packed-u16 integer max on |x| bit patterns (NaN > inf > finite, which is torch.amax's
+// NaN propagation) reduced with xor-shuffles inside the G-lane group.
 //
-// Output, QUAD=true (pipeline): sym4[chunk][plane][quad][channel] u32 whose
-// byte k is the symbol of token 4*quad+k -- a lane-local byte transpose, so
-// the encoder later reads 4 tokens of its channel with one coalesced dword.
+// Output, QUAD=true (pipeline): the symbol workspace of the coder, one region of TQ*C dwords per
+// (chunk, plane), written with a lane-local transpose so that the coder later reads several tokens of its
+// channel with one coalesced dword:
+//   planes with > 17 bins  [quad][channel] u32, byte k = symbol of token 4*quad + k
+//   planes with <= 17 bins [oct][channel] u32,  byte k = token 8*oct + k | token 8*oct + 4 + k << 4
 // Output, QUAD=false (lmc_quantize parity entry): int8 [P][T][C].
 #pragma once
 #include "lmc_device.h"
@@ -28,7 +28,7 @@ struct QuantArgs {
   int tok_begin, tok_end, chunk_tokens, nchunks;
   int P, C, TQ;          // TQ = ceil(chunk_tokens / 4)
   int pc_limit;          // plane-chunks (chunk * P + plane) to quantise: nchunks * P
-  u32* sym4;             // QUAD: [nchunks][P][TQ][C]
+  u32* sym4;             // QUAD: symbol workspace, TQ*C dwords per (chunk, plane)
   int8_t* sym8;          // !QUAD: [P][T][C]
   u8* scale_base;        // scale of (chunk, p, t) at scale_base + chunk*scale_stride + 2*(p*Tc + t)
   long long scale_stride;

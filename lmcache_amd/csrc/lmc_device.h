@@ -33,7 +33,7 @@ struct KvAddr {
 
 struct BinsArg {
   u8 b[LMC_MAX_PLANES];
-  u16 rowpre[LMC_MAX_PLANES + 1];  // rowpre[p] = sum over planes before p of (bins - 2): CDF rows stored per channel
+  u16 rowpre[LMC_MAX_PLANES + 1];  // rowpre[p] = sum over planes before p of (bins - 1): symbol counts stored per channel
 };
 
 __device__ __forceinline__ const u16* lmc_plane_base(const KvAddr& a, int p) {
