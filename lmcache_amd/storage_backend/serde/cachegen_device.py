@@ -90,6 +90,7 @@ class EncodeJob:
     # a long job is launched as a few consecutive ranges of chunks, each with its own event, so that the
     # host-DRAM offload of range r can start while range r+1 is still being encoded: (chunk0, chunk1, event)
     parts: Optional[list] = None
+    offload_issued: bool = False  # its device -> host copies are on the copy streams (the arena may be reused after them)
 
 
 class CacheGenDeviceCodec:
@@ -112,6 +113,7 @@ class CacheGenDeviceCodec:
         self._dec_free: Optional[torch.cuda.Event] = None    # previous decode kernel done
         self._stage: Optional[native.PinnedBuffer] = None    # staging for pageable `bytes` inputs
         self._pending: Optional[EncodeJob] = None            # last job whose sizes were not read yet
+        self._last_job: Optional[EncodeJob] = None           # last job launched (has its offload been issued?)
         self.decode_batch_chunks = 8                         # chunks per H2D/decode pipeline stage
 
     # ---- encode ------------------------------------------------------------------
@@ -126,12 +128,20 @@ class CacheGenDeviceCodec:
             if self._pending is not None:
                 self.sizes_of(self._pending)  # the pinned size words are about to be overwritten
             with torch.cuda.device(self.device):
-                if self._enc_arena is None or self._enc_arena.numel() < n * stride:
-                    self._enc_arena = torch.empty(n * stride, dtype=torch.uint8, device=self.device)
+                # The shared arena may be rewritten only after the previous job's copies have been ISSUED (then
+                # `_arena_free` orders us behind them).  A non-blocking store defers its offload to the
+                # backend's worker thread: if that has not happened yet, this job gets an arena of its own.
+                prev = self._last_job
+                if prev is None or prev.offload_issued:
+                    if self._enc_arena is None or self._enc_arena.numel() < n * stride:
+                        self._enc_arena = torch.empty(n * stride, dtype=torch.uint8, device=self.device)
+                    arena = self._enc_arena
+                else:
+                    arena = torch.empty(n * stride, dtype=torch.uint8, device=self.device)
                 if self._sizes is None or self._sizes.nbytes < 4 * n:
                     self._sizes = native.PinnedBuffer(4 * max(n, 256))
                 cur = torch.cuda.current_stream(self.device)
-                if self._arena_free is not None:
+                if arena is self._enc_arena and self._arena_free is not None:
                     cur.wait_event(self._arena_free)  # previous job's D2H has read the arena
                 nparts = self.encode_parts if n >= 4 * self.encode_parts else 1
                 per = (n + nparts - 1) // nparts
@@ -139,14 +149,15 @@ class CacheGenDeviceCodec:
                 for c0 in range(0, n, per):
                     c1 = min(n, c0 + per)
                     self.ctx.encode_chunks(src, tok_begin + c0 * chunk_tokens, min(tok_end, tok_begin + c1 * chunk_tokens),
-                                           chunk_tokens, bins, self._enc_arena.data_ptr() + c0 * stride, stride,
+                                           chunk_tokens, bins, arena.data_ptr() + c0 * stride, stride,
                                            self._sizes.ptr + 4 * c0, stream=cur.cuda_stream)
                     ev = torch.cuda.Event()
                     ev.record(cur)
                     parts.append((c0, c1, ev))
                 done = parts[-1][2]
-            job = EncodeJob(n, stride, self._enc_arena, self._sizes, done, (L, H, D, chunk_tokens), None, parts)
+            job = EncodeJob(n, stride, arena, self._sizes, done, (L, H, D, chunk_tokens), None, parts)
             self._pending = job
+            self._last_job = job
             return job
 
     def sizes_of(self, job: EncodeJob) -> List[int]:
@@ -198,7 +209,9 @@ class CacheGenDeviceCodec:
                 self.copy_stream.wait_event(ev2)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
-            self._arena_free = ev
+            job.offload_issued = True
+            if job.arena is self._enc_arena:
+                self._arena_free = ev
         return blobs, ev
 
     # ---- decode ------------------------------------------------------------------

@@ -378,3 +378,37 @@ def test_pipelined_remote_backend_range_protocol_and_misses(oracle):
     finally:
         plain.close()
         piped.close()
+
+
+def test_back_to_back_nonblocking_stores_keep_their_own_bytes(oracle):
+    """Two non-blocking cachegen stores issued back to back: the second encode must not rewrite the device
+    arena the first one's deferred offload still has to read (the worker thread is held back to force the
+    order encode A, encode B, offload A, offload B)."""
+    import threading
+    import time
+    fmt, cs, nl = "vllm", 128, 4
+    engine = LMCacheEngine(make_cfg("cachegen-host", cs), dumb_metadata(fmt, MODEL))
+    try:
+        gate = threading.Event()
+        engine.engine_.put_queue.put(lambda: gate.wait(10))   # the worker blocks here first
+        toks_a, toks_b = generate_tokens(256, "cuda"), generate_tokens(256, "cuda")
+        kv_a = generate_kv_cache(256, fmt, "cuda", num_layers=nl)
+        kv_b = tuple((k + 0.5, v - 0.25) for k, v in generate_kv_cache(256, fmt, "cuda", num_layers=nl))
+        engine.store(toks_a, kv_a, blocking=False)
+        engine.store(toks_b, kv_b, blocking=False)
+        torch.cuda.synchronize()
+        gate.set()
+        for _ in range(500):
+            if int(engine.retrieve(toks_b)[1].sum()) == 256 and int(engine.retrieve(toks_a)[1].sum()) == 256:
+                break
+            time.sleep(0.01)
+        for toks, kv in ((toks_a, kv_a), (toks_b, kv_b)):
+            got, mask = engine.retrieve(toks)
+            assert int(mask.sum()) == 256
+            for t0 in range(0, 256, cs):
+                part = tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in kv)
+                want = oracle_roundtrip(oracle, part, fmt, MODEL, torch.bfloat16)
+                have = to_blob(tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in got)).cpu()
+                assert torch.equal(have, want)
+    finally:
+        engine.close()
