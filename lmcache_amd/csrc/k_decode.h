@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   const u32 cdf_rows = hdw(19);
   const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, cdf_rows);
   if (hdw(0) != LMC_BLOB_MAGIC || (hdw(1) & 0xffffu) != LMC_BLOB_VERSION || hdw(7) != (u32)a.C ||
-      hdw(8) != (u32)a.P || hdw(15) != bo.streams || cdf_rows > 31u * (u32)a.P || hdw(20) != dev_count_bytes(T)) {
+      hdw(8) != (u32)a.P || hdw(15) != bo.streams || cdf_rows > 31u * (u32)a.P || hdw(20) != dev_count_bytes(T) ||
+      // every section offset is a function of the fields checked above; the blob must also fit its slot
+      (!SYMOUT && (T > (u32)a.chunk_tokens || (unsigned long long)hdw(17) > (unsigned long long)a.blob_stride))) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_HEADER);
     return;
   }
@@ -145,9 +147,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   // ---- stream ----------------------------------------------------------------
   const u32* gend = reinterpret_cast<const u32*>(blob + bo.gend);
   const u32 end = (u32)__builtin_amdgcn_readfirstlane((int)gend[pg]);
-  const u32 start = pg == 0 ? 0u : (((u32)__builtin_amdgcn_readfirstlane((int)gend[pg - 1]) + 15u) & ~15u);
+  const u32 prev_end = pg == 0 ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)gend[pg - 1]);
+  const u32 start = (prev_end + 15u) & ~15u;
   const u16* words = reinterpret_cast<const u16*>(blob + bo.streams + start);
-  if (end < start + 256u || bo.streams + end > hdw(17)) {
+  // 64-bit comparisons: a corrupt directory entry must not wrap its way past the bounds
+  if (prev_end > 0xfffffff0u || (unsigned long long)end < (unsigned long long)start + 256ull ||
+      (unsigned long long)bo.streams + (unsigned long long)end > (unsigned long long)hdw(17)) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_STREAM);
     return;
   }

@@ -465,6 +465,34 @@ def test_corrupt_blob_is_flagged(nat, ctx):
     ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
     torch.cuda.synchronize()
     assert ctx.status(clear=True) & 4
+    # a header that claims more bytes than its slot holds, or more tokens than the chunk spacing: refused
+    # before any section is read (every section offset is a function of validated header fields)
+    import struct
+    bad = blob_dev.clone()
+    bad[68:72] = torch.tensor(list(struct.pack("<I", stride + 16)), dtype=torch.uint8, device=DEV)  # total_bytes
+    ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+    torch.cuda.synchronize()
+    assert ctx.status(clear=True) & 2
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T - 1)
+    torch.cuda.synchronize()
+    assert ctx.status(clear=True) & 2
+    # garbage in the count section or in the stream directory: flagged, nothing hangs or faults
+    g = torch.Generator().manual_seed(3)
+    bad = blob_dev.clone()
+    n = hdr.off_gend - hdr.off_cdf
+    bad[hdr.off_cdf:hdr.off_gend] = torch.randint(0, 256, (n,), generator=g, dtype=torch.uint8).to(DEV)
+    ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+    torch.cuda.synchronize()
+    assert ctx.status(clear=True) & 4
+    bad = blob_dev.clone()
+    bad[hdr.off_gend:hdr.off_gend + 8] = torch.tensor([0xff] * 8, dtype=torch.uint8, device=DEV)
+    ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+    torch.cuda.synchronize()
+    assert ctx.status(clear=True) & 4
+    # and the intact blob still decodes
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+    torch.cuda.synchronize()
+    assert ctx.status(clear=True) == 0
 
 
 def test_full_size_llama8b_chunk_vs_oracle(nat, ctx, oracle):
