@@ -188,6 +188,7 @@ def main():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
+            torch.cuda.synchronize()
             dist.destroy_process_group()
         return
 
@@ -317,6 +318,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
