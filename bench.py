@@ -99,9 +99,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # LMC_BENCH_FORCE_DIST=1 runs the process-group code path with a single rank too (a 1-GPU box can then
+    # exercise init / barrier / all_reduce / teardown exactly as the multi-GPU launch does)
+    use_dist = world > 1 or os.environ.get("LMC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     torch.cuda.set_device(local_rank)
@@ -126,7 +132,7 @@ def main():
         ctx.encode_chunks(layout, 0, CTX, CHUNK, bins, blobs.data_ptr(), stride, sizes.data_ptr(), stream=sp)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
 
@@ -149,7 +155,7 @@ def main():
     gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
     barrier()
     ctx.raise_on_status("bench")
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -159,7 +165,7 @@ def main():
 
     # ---- optional: one exchange step of the encoded chunks over RCCL/xGMI (row f1; outside the timed region) ----
     exchange = None
-    if args.exchange and world > 1:
+    if args.exchange and use_dist:
         import torch.distributed as dist
         from lmcache_amd.storage_backend.connector.xgmi_exchange import XgmiShardStore
         szs = sizes.cpu().tolist()
@@ -185,7 +191,7 @@ def main():
                     "note": "one batch_isend_irecv per call; includes the all_gather_object control round trips"}
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
@@ -315,7 +321,7 @@ def main():
         n = args.cpu_chunks or 32
         res["cpu_baseline"] = cpu_baseline(n)
     print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         torch.cuda.synchronize()
