@@ -146,7 +146,8 @@ class LMCPipelinedRemoteBackend(LMCRemoteBackend):
         out_q.put(RemoteBackendEndSignal())
 
     def _arrivals(self, keys):
-        """Yield (idx, bytes-or-None) in key order while the fetch thread runs ahead."""
+        """Yield (idx, bytes-or-None, backlog) in key order while the fetch thread runs ahead; `backlog` tells
+        whether more fetched items are already waiting (so a consumer can batch what has arrived)."""
         q: "queue.Queue" = queue.Queue()
         self._fetcher.submit(self._fetch_into, list(keys), q)
         while True:
@@ -155,13 +156,13 @@ class LMCPipelinedRemoteBackend(LMCRemoteBackend):
                 return
             if isinstance(item, Exception):
                 raise item
-            yield item
+            yield item[0], item[1], not q.empty()
 
     # ---- reference API ---------------------------------------------------------------------------------
     @_lmcache_nvtx_annotate
     def batched_get(self, keys):
         results: List[Optional[torch.Tensor]] = []
-        for _, bs in self._arrivals(keys):
+        for _, bs, _ in self._arrivals(keys):
             results.append(None if bs is None else self.deserializer.from_bytes(bs).to(self.dst_device))
         return results
 
@@ -216,20 +217,12 @@ class LMCPipelinedRemoteBackend(LMCRemoteBackend):
                 first += len(batch)
                 batch = []
 
-        q: "queue.Queue" = queue.Queue()
-        self._fetcher.submit(self._fetch_into, list(keys), q)
-        while True:
-            item = q.get()
-            if isinstance(item, RemoteBackendEndSignal):
-                break
-            if isinstance(item, Exception):
-                raise item
-            idx, bs = item
+        for idx, bs, backlog in self._arrivals(keys):
             if bs is None:
                 raise KeyError(f"chunk {idx} of the requested range is not in the remote store")
             batch.append(bs)
             # decode what has arrived as soon as the fetch thread falls behind, or a full batch is there
-            if len(batch) >= self.fetch_batch or q.empty():
+            if len(batch) >= self.fetch_batch or not backlog:
                 flush()
         flush()
 
