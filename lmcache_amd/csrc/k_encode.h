@@ -21,7 +21,7 @@
 //           a time), then x = (x/f << 16) + x%f + start, computed as
 //           x + (x/f) * (2^16 - f) + start (rans_put)
 //   tail    64 states, zero pad to 16 B; then the stream is moved to its final place in the blob
-//           (compact_stream: single-pass prefix over the group lengths of the chunk)
+//           (single-pass prefix over the group lengths of the chunk, one look-back per workgroup)
 // 4.7 KiB of LDS per wave -> 8 waves per SIMD.
 #pragma once
 #include "lmc_device.h"
@@ -109,29 +109,28 @@ struct PendingTile {
 };
 
 // In-kernel compaction: where does a finished stream go?  Single-pass prefix sum over the padded lengths of
-// the chunk's P*G groups (decoupled look-back): every wave publishes its length as soon as a stream is coded,
-// and later looks back over its predecessors' granules until it meets an inclusive prefix, publishes its own
-// inclusive prefix, then moves the stream from its scratch slot to its final place (the cumsum + gather of collect_bytes,
-// cachegen_encoder.py:230-238).  Predecessors have lower stream ids: they were taken by workgroups dispatched
-// no later than ours, in an earlier or the same round, and never wait on us.
-__device__ __forceinline__ void compact_stream(const EncodeArgs& a, const PendingTile& t, int lane) {
-  const int n = a.P * a.G;
-  const u32 padded = (t.exact + 15u) & ~15u;
-  unsigned long long* agg = a.agg + (long long)t.chunk * n;
+// the chunk's P*G groups (decoupled look-back): lengths are published as soon as streams are coded, a wave
+// looks back over its predecessors' granules until it meets an inclusive prefix, publishes its own inclusive
+// prefix, and the streams move from their scratch slots to their final places (the cumsum + gather of
+// collect_bytes, cachegen_encoder.py:230-238).  Predecessors have lower stream ids: they were taken by
+// workgroups dispatched no later than ours, in an earlier or the same round, and never wait on us.
+// Exclusive prefix of granule `idx` over the granule array `agg` (decoupled look-back, one wave): walks back 64
+// granules at a time until it meets an inclusive prefix; waits while a granule it needs is unpublished.
+__device__ __forceinline__ u32 lookback_exclusive(unsigned long long* agg, int idx0, int lane, u32* status) {
   u32 excl = 0;
-  if (t.pg > 0) {
-    int base = t.pg - 1;
+  if (idx0 > 0) {
+    int base = idx0 - 1;
     u32 spins = 0;
     for (;;) {
       const int idx = base - lane;
-      const unsigned long long v = idx >= 0 ? agg_load(agg + idx) : ((AGG_P << 62) | 0ull);  // virtual group -1
+      const unsigned long long v = idx >= 0 ? agg_load(agg + idx) : ((AGG_P << 62) | 0ull);  // virtual granule -1
       const u32 flag = (u32)(v >> 62);
       const u64 mP = __ballot(flag == (u32)AGG_P), mX = __ballot(flag == (u32)AGG_X);
       const int first = mP ? __builtin_ctzll(mP) : 64;  // nearest predecessor with a full prefix
       const u64 below = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
       if (mX & below) {  // someone we need has not published yet
         if (++spins > (1u << 24)) {
-          if (lane == 0) atomicOr(a.status, LMC_ST_LOOKBACK_TIMEOUT);
+          if (lane == 0) atomicOr(status, LMC_ST_LOOKBACK_TIMEOUT);
           break;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -142,7 +141,14 @@ __device__ __forceinline__ void compact_stream(const EncodeArgs& a, const Pendin
       base -= 64;
     }
   }
-  if (lane == 0) agg_store(agg + t.pg, AGG_P, excl + padded);
+  return excl;
+}
+
+// Move a finished stream from its scratch slot to offset `excl` of the chunk's streams section, record its
+// end in the directory; the chunk's last group also writes header, bins, rowpre, pads and the size word.
+__device__ __forceinline__ void place_stream(const EncodeArgs& a, const PendingTile& t, u32 excl, int lane) {
+  const int n = a.P * a.G;
+  const u32 padded = (t.exact + 15u) & ~15u;
   const BlobOff bo = lmc_blob_off((u32)a.P, t.T, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
   u8* blob = a.blobs + (long long)t.chunk * a.blob_stride;
   if (lane == 0) reinterpret_cast<u32*>(blob + bo.gend)[t.pg] = excl + t.exact;
@@ -393,12 +399,38 @@ __global__ __launch_bounds__(256) void k_cdf_encode(EncodeArgs a) {
   const u32 padw = ((16u - (exact & 15u)) & 15u) >> 1;
   if ((u32)lane < padw) out[wcur + lane] = 0;
   if (lane == 0 && exact + 16 > a.cap) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);
-  // publish this stream's padded length, then compact it (waits for predecessors that are still coding)
-  {
-    const int n = a.P * a.G;
-    PendingTile t;
-    t.chunk = chunk; t.pg = p * a.G + g; t.exact = exact; t.T = T; t.out = out;
-    if (lane == 0 && t.pg > 0) agg_store(a.agg + (long long)chunk * n + t.pg, AGG_A, (exact + 15u) & ~15u);
-    compact_stream(a, t, lane);
+  // ---- compaction: where does this stream go? ------------------------------------------------------------
+  const int n = a.P * a.G;
+  PendingTile t;
+  t.chunk = chunk; t.pg = p * a.G + g; t.exact = exact; t.T = T; t.out = out;
+  const u32 padded = (exact + 15u) & ~15u;
+  unsigned long long* agg = a.agg + (long long)chunk * n;
+  if ((n & 3) == 0) {
+    // The four waves of a workgroup hold four consecutive streams of one chunk: they add their lengths up in
+    // LDS and ONE wave runs the look-back over workgroup-level granules -- a quarter of the granules, and a
+    // quarter of the walk when a whole chunk finishes at once and nobody has an inclusive prefix yet.
+    __shared__ u32 wg_len[4];
+    __shared__ u32 wg_excl;
+    if (lane == 0) wg_len[wave] = padded;
+    __syncthreads();
+    const u32 l0 = wg_len[0], l1 = wg_len[1], l2 = wg_len[2], l3 = wg_len[3];
+    const u32 intra = (wave > 0 ? l0 : 0u) + (wave > 1 ? l1 : 0u) + (wave > 2 ? l2 : 0u);
+    if (wave == 0) {
+      const int wgi = t.pg >> 2;
+      if (lane == 0 && wgi > 0) agg_store(agg + wgi, AGG_A, l0 + l1 + l2 + l3);
+      const u32 e = lookback_exclusive(agg, wgi, lane, a.status);
+      if (lane == 0) {
+        agg_store(agg + wgi, AGG_P, e + l0 + l1 + l2 + l3);
+        wg_excl = e;
+      }
+    }
+    __syncthreads();
+    place_stream(a, t, wg_excl + intra, lane);
+  } else {
+    // streams of a chunk do not fill whole workgroups: every wave publishes and looks back for itself
+    if (lane == 0 && t.pg > 0) agg_store(agg + t.pg, AGG_A, padded);
+    const u32 excl = lookback_exclusive(agg, t.pg, lane, a.status);
+    if (lane == 0) agg_store(agg + t.pg, AGG_P, excl + padded);
+    place_stream(a, t, excl, lane);
   }
 }
