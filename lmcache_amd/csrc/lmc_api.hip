@@ -264,7 +264,7 @@ int lmc_calculate_cdf(lmc_ctx* c, const int8_t* sym, int32_t P, int32_t T, int32
   a.status = c->status_h;
   HIP_TRY(hipSetDevice(c->device));
   long long n = (long long)P * a.G;
-  hipLaunchKernelGGL((k_cdf_encode<false, false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_cdf_encode<false, false>), dim3((unsigned)((n + ENC_WAVES - 1) / ENC_WAVES)), dim3(64 * ENC_WAVES), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return LMC_OK;
 }
@@ -325,7 +325,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     ea.L = L; ea.H = H; ea.D = D; ea.dtype = src->dtype;
     const long long ngroups = (long long)nchunks * PG;
     HIP_TRY(hipMemsetAsync(ea.agg, 0, (size_t)ngroups * 8, s));
-    hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, ea);
+    hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + ENC_WAVES - 1) / ENC_WAVES)), dim3(64 * ENC_WAVES), 0, s, ea);
     HIP_TRY(hipGetLastError());
     if ((rc = prof_mark(c, s))) return rc;
   }
