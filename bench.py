@@ -39,8 +39,8 @@ CTX, CHUNK = 16384, 256
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per step from the PMC passes committed under profiles/ (see profiles/r01_*_pmc.md): updated by hand
 # whenever the kernels' data flow changes; None until measured.
-TRAFFIC_BYTES_PER_STEP = 4_574_000_000  # profiles/r01_e_pmc.md
-VALU_BUSY_DOMINANT = 1.0                 # k_cdf_encode: SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles), profiles/r01_e_pmc.md
+TRAFFIC_BYTES_PER_STEP = 4_561_000_000  # profiles/r01_f_pmc.md
+VALU_BUSY_DOMINANT = 1.0                 # k_cdf_encode: SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles), profiles/r01_f_pmc.md
 
 
 def cachegen_bins_llama8b():
