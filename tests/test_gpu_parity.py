@@ -535,3 +535,25 @@ def test_saturated_and_wide_symbol_counts(nat, ctx, oracle, T):
     torch.cuda.synchronize()
     ctx.raise_on_status("decode")
     assert np.array_equal(bits_np(out).reshape(L, 2, T, H * D), oracle.decode_blob(ref, oracle.BF16))
+
+
+def test_unusual_bins_and_ragged_channel_counts(nat, ctx, oracle):
+    """Bins other than the CacheGen tables' 16 / 32 (4 .. 32, odd ones too: both workspace formats, both decoder
+    search depths, count rows of every length) on channel counts that leave idle lanes in the last group, chunk
+    lengths on both sides of the one-byte / two-byte count boundary; blob and decode bit-exact against the oracle."""
+    rng = np.random.default_rng(11)
+    cases = [(1, 64, 3, 40, [4, 32]), (2, 255, 1, 72, [6, 17, 18, 30]), (1, 257, 2, 64, [20, 8]),
+             (2, 300, 5, 24, [31, 5, 16, 28]), (1, 256, 1, 8, [32, 4])]
+    for L, T, H, D, bins in cases:
+        x = rng.standard_normal((L, 2, T, H, D)).astype(np.float32)
+        x[:, :, :, :, ::5] = np.round(x[:, :, :, :, ::5])   # peaky channels
+        kv = torch.from_numpy(x).to(torch.bfloat16)
+        blobs, blob_dev, stride = encode(nat, ctx, nat.KVLayout.from_chunk(kv.to(DEV), "vllm"), 0, T, T, bins)
+        b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
+        ref = oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+        assert blobs[0] == ref, (L, T, H, D, bins)
+        out = torch.zeros(L, 2, T, H, D, dtype=torch.bfloat16, device=DEV)
+        ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+        torch.cuda.synchronize()
+        ctx.raise_on_status("decode")
+        assert np.array_equal(bits_np(out).reshape(L, 2, T, H * D), oracle.decode_blob(ref, oracle.BF16)), (L, T, H, D, bins)

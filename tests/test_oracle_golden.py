@@ -116,3 +116,31 @@ def test_blob_roundtrip_equals_quant_dequant(oracle, dtype):
     M = torch.tensor(bins.reshape(2, L).T // 2 - 1).float()[:, :, None, None]
     tol = mx / (2 * M) + mx * (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10)
     assert ((dec - kv.float()).abs() <= tol).all()
+
+
+def test_blob_roundtrip_random_geometries(oracle):
+    """Format v3 end to end in the oracle over random geometries: ragged channel counts (idle lanes in the last
+    group), bins anywhere in 4..32, chunk lengths on both sides of the one-byte / two-byte count boundary, and
+    peaky data (few symbols per channel, counts that saturate)."""
+    rng = np.random.default_rng(7)
+    for it in range(14):
+        L = int(rng.integers(1, 3))
+        T = int(rng.choice([1, 2, 7, 31, 64, 255, 256, 257, 300]))
+        H = int(rng.integers(1, 4))
+        D = int(rng.choice([8, 16, 40, 64, 72]))
+        bins = rng.choice(np.arange(4, 33, 2), size=2 * L).astype(np.int32)
+        x = rng.standard_normal((L, 2, T, H * D)).astype(np.float32)
+        if it % 3 == 0:
+            x = np.round(x)            # few distinct values -> few symbols, saturating counts
+        if it % 4 == 1:
+            x[:, :, :, ::3] = 0.0      # constant channels
+        import torch
+        kv = torch.from_numpy(x).to(torch.bfloat16)
+        bits, code = oracle.torch_to_bits(kv)
+        blob = oracle.encode_blob(bits, code, H, D, bins)
+        sym, scale = oracle.quantize(bits, code, bins)
+        assert np.array_equal(oracle.decode_blob_symbols(blob), sym), (it, L, T, H, D)
+        assert np.array_equal(oracle.blob_cdf(blob), oracle.cdf(sym)), (it, L, T, H, D)
+        assert np.array_equal(oracle.decode_blob(blob, oracle.BF16),
+                              oracle.dequantize(sym, scale, code, bins, oracle.BF16)), (it, L, T, H, D)
+        assert len(blob) <= oracle.blob_bound(L, T, H, D)
