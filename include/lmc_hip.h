@@ -45,7 +45,7 @@ const char* lmc_strerror(int code);
 int lmc_last_hip_error(void);
 /* ABI version of this header. */
 int lmc_abi_version(void);
-#define LMC_ABI_VERSION 1
+#define LMC_ABI_VERSION 2
 
 /* ------------------------------------------------------------------ */
 /* KV addressing                                                       */
@@ -97,10 +97,22 @@ int lmc_ctx_destroy(lmc_ctx* ctx);
  * max_chunks chunks of chunk_tokens tokens.  Optional: lmc_encode_chunks grows
  * it on demand (growth allocates, i.e. may stall that one call). */
 int lmc_ctx_reserve(lmc_ctx* ctx, int L, int H, int D, int chunk_tokens, int max_chunks);
-/* Sticky status word written by kernels (0 = ok): stream overflow, bad blob
- * header, inconsistent stream.  Valid once the work has completed (after an
- * event / stream sync by the caller).  `clear` resets it. */
+/* Status bits a kernel can raise (0 = ok).  A call that is given a `job_status` word reports into THAT
+ * word (device-accessible uint32, e.g. pinned host memory, zeroed by the caller; valid once the call's
+ * work has completed: after an event / stream sync by the caller), so that concurrent jobs never see each
+ * other's failures; with job_status == NULL the bits go to the context's sticky word below. */
+#define LMC_STATUS_STREAM_OVERFLOW 1u /* encode: a group stream outgrew its scratch slot (cannot happen) */
+#define LMC_STATUS_BAD_HEADER 2u      /* decode: header / geometry / section offsets inconsistent */
+#define LMC_STATUS_BAD_STREAM 4u      /* decode: directory out of bounds, words left over, final state wrong */
+#define LMC_STATUS_LOOKBACK_TIMEOUT 8u
+/* The context's sticky status word.  `clear` resets it. */
 int lmc_device_status(lmc_ctx* ctx, int clear);
+
+/* Geometry limits of this build: 2L <= LMC_MAX_PLANES planes, C = H*D <= LMC_MAX_CHANNELS channels per
+ * plane (4096 = a 32-head x 128 MHA model; every BASELINE.json config fits), head_size a multiple of 8,
+ * chunks of 1 .. 65535 tokens.  Outside them the entry points return LMC_ERR_INVALID. */
+#define LMC_MAX_PLANES 256
+#define LMC_MAX_CHANNELS 4096
 
 /* Per-kernel timing of the NEXT lmc_encode_chunks / lmc_decode_chunks calls:
  * when enabled the call brackets each of its kernels with hipEvents on the
@@ -148,10 +160,11 @@ int lmc_calculate_cdf(lmc_ctx* ctx, const int8_t* sym, int32_t P, int32_t T, int
  *            blob_stride >= lmc_blob_bound(L, chunk_tokens, H, D), multiple of 16
  *   sizes    device-accessible uint32 [nchunks] (device or pinned host memory):
  *            receives total_bytes of each blob
+ *   job_status  see LMC_STATUS_* above (may be NULL)
  */
 int lmc_encode_chunks(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end,
                       int32_t chunk_tokens, const int32_t* bins_h, void* blobs, uint64_t blob_stride,
-                      uint32_t* sizes, lmc_stream_t stream);
+                      uint32_t* sizes, uint32_t* job_status, lmc_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* decode side                                                         */
@@ -171,7 +184,8 @@ int lmc_encode_chunks(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin,
  *   "huggingface": cachegen_decoder.py:190-200)
  */
 int lmc_decode_chunks(lmc_ctx* ctx, const void* blobs, uint64_t blob_stride, int32_t nchunks,
-                      const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, lmc_stream_t stream);
+                      const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, uint32_t* job_status,
+                      lmc_stream_t stream);
 
 /* Entropy-decode only (debug / parity): blob -> sym_out int8 [P][T][C].
  * Stands where torchac_cuda.decode_fast_prefsum stands (cachegen_decoder.py:65-66). */

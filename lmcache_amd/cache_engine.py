@@ -179,13 +179,30 @@ class LMCacheEngine:
             if hits == 0 or nret <= 0:
                 ret_mask[:] = False
                 return (), ret_mask
-            shape0, dtype = self.engine_.chunk_meta(keys[0])
+            try:
+                shape0, dtype = self.engine_.chunk_meta(keys[0])
+            except KeyError:  # gone since `contains`: a miss
+                ret_mask[:] = False
+                return (), ret_mask
             L = shape0[0]
             H, D = (shape0[3], shape0[4]) if fmt == "vllm" else (shape0[2], shape0[4])
             dev = torch.device("cuda", torch.cuda.current_device())
             shape = (L, 2, nret, H, D) if fmt == "vllm" else (L, 2, H, nret, D)
             blob = torch.empty(shape, dtype=dtype, device=dev)
-            self.engine_.get_kv_range(keys[:hits], native.KVLayout.from_chunk(blob, fmt), fmt, -extra, cs)
+            try:
+                got = self.engine_.get_kv_range(keys[:hits], native.KVLayout.from_chunk(blob, fmt), fmt, -extra, cs)
+            except native.NativeError:
+                # a stored blob that does not decode must never reach the model as KV: the whole lookup is a miss
+                logger.exception("retrieve: a cached chunk failed to decode; treated as a miss")
+                got = 0
+            got = hits if got is None else got
+            if got < hits:  # some chunks went missing after `contains`: keep the prefix that arrived
+                hits = got
+                _, extra, nret2 = self.plan_retrieve(len(tokens), cs, num_skip_tok, hits)
+                if hits == 0 or nret2 <= 0:
+                    ret_mask[:] = False
+                    return (), ret_mask
+                blob = blob.narrow(2 if fmt == "vllm" else 3, 0, nret2)
         else:
             chunks = []
             for chunk in self.engine_.batched_get(iter(keys)):

@@ -90,6 +90,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   const u32 nsym = min(31u, max(3u, (u32)__builtin_amdgcn_readfirstlane((int)blob[bo.bins + p]) - 1u));
   {
     const u32 rp = (u32)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const u16*>(blob + bo.rowpre)[p]);
+    if (rp + nsym > cdf_rows) {  // a corrupt row prefix must not send the count loads outside the section
+      if (lane == 0) atomicOr(a.status, LMC_ST_BAD_HEADER);
+      return;
+    }
     const float rcpR = 1.0f / (float)nsym;
     const u32 total = (u32)min(64, a.C - g * 64) * nsym;
     const long long e00 = (long long)a.C * rp + (long long)g * 64 * nsym;

@@ -270,13 +270,14 @@ int lmc_calculate_cdf(lmc_ctx* c, const int8_t* sym, int32_t P, int32_t T, int32
 }
 
 int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
-                      const int32_t* bins_h, void* blobs, uint64_t blob_stride, uint32_t* sizes, lmc_stream_t stream) {
+                      const int32_t* bins_h, void* blobs, uint64_t blob_stride, uint32_t* sizes, uint32_t* job_status,
+                      lmc_stream_t stream) {
   if (!c || !layout_ok(src) || tok_begin < 0 || tok_end <= tok_begin || chunk_tokens < 1 || chunk_tokens > 65535 ||
       !blobs || !sizes || ((uintptr_t)blobs & 15) || (blob_stride & 15))
     return LMC_ERR_INVALID;
   const int L = src->num_layers, H = src->num_heads, D = src->head_size;
   const int P = 2 * L, C = H * D, G = (C + 63) / 64;
-  if (C > 4096) return LMC_ERR_INVALID;
+  if (C > LMC_MAX_CHANNELS) return LMC_ERR_INVALID;
   const int nchunks = (tok_end - tok_begin + chunk_tokens - 1) / chunk_tokens;
   if (nchunks > 65535) return LMC_ERR_INVALID;  // chunks ride on gridDim.z of k_quantize
   if (blob_stride < lmc_blob_bound((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D)) return LMC_ERR_INVALID;
@@ -319,7 +320,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     ea.P = P; ea.C = C; ea.G = G; ea.TQ = TQ;
     ea.blobs = (u8*)blobs; ea.blob_stride = (long long)blob_stride;
     ea.scratch = c->scratch; ea.cap = cap;
-    ea.status = c->status_h;
+    ea.status = job_status ? job_status : c->status_h;
     ea.bins = bins;
     ea.agg = c->agg; ea.sizes = sizes;
     ea.L = L; ea.H = H; ea.D = D; ea.dtype = src->dtype;
@@ -336,20 +337,20 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
 }
 
 static int decode_common(lmc_ctx* c, const void* blobs, uint64_t blob_stride, int nchunks, int L, int H, int D,
-                         DecodeArgs& a) {
+                         uint32_t* job_status, DecodeArgs& a) {
   if (!c || !blobs || nchunks < 1 || ((uintptr_t)blobs & 15) || (blob_stride & 15)) return LMC_ERR_INVALID;
   a.blobs = (const u8*)blobs; a.blob_stride = (long long)blob_stride; a.nchunks = nchunks;
   a.P = 2 * L; a.C = H * D; a.G = (a.C + 63) / 64;
-  a.status = c->status_h;
+  a.status = job_status ? job_status : c->status_h;
   return LMC_OK;
 }
 
 int lmc_decode_chunks(lmc_ctx* c, const void* blobs, uint64_t blob_stride, int32_t nchunks, const lmc_kv_layout* dst,
-                      int32_t dst_tok0, int32_t chunk_tokens, lmc_stream_t stream) {
+                      int32_t dst_tok0, int32_t chunk_tokens, uint32_t* job_status, lmc_stream_t stream) {
   if (!layout_ok(dst) || chunk_tokens < 1) return LMC_ERR_INVALID;
   DecodeArgs a;
   memset(&a, 0, sizeof a);
-  int rc = decode_common(c, blobs, blob_stride, nchunks, dst->num_layers, dst->num_heads, dst->head_size, a);
+  int rc = decode_common(c, blobs, blob_stride, nchunks, dst->num_layers, dst->num_heads, dst->head_size, job_status, a);
   if (rc) return rc;
   a.dst = to_addr(dst); a.dst_tok0 = dst_tok0; a.chunk_tokens = chunk_tokens;
   HIP_TRY(hipSetDevice(c->device));
@@ -377,7 +378,7 @@ int lmc_decode_symbols(lmc_ctx* c, const void* blob, int32_t L, int32_t H, int32
   if (!sym_out || L < 1 || H < 1 || D < 8) return LMC_ERR_INVALID;
   DecodeArgs a;
   memset(&a, 0, sizeof a);
-  int rc = decode_common(c, blob, 0, 1, L, H, D, a);
+  int rc = decode_common(c, blob, 0, 1, L, H, D, nullptr, a);
   if (rc) return rc;
   a.sym_out = sym_out;
   HIP_TRY(hipSetDevice(c->device));

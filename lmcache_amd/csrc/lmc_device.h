@@ -12,14 +12,15 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-#define LMC_WAVE 64
-#define LMC_MAX_PLANES 256
+#include "../../include/lmc_hip.h"
 
-// Device status bits (lmc_device_status).
-#define LMC_ST_STREAM_OVERFLOW 1u
-#define LMC_ST_BAD_HEADER 2u
-#define LMC_ST_BAD_STREAM 4u
-#define LMC_ST_LOOKBACK_TIMEOUT 8u
+#define LMC_WAVE 64
+
+// Device status bits (include/lmc_hip.h).
+#define LMC_ST_STREAM_OVERFLOW LMC_STATUS_STREAM_OVERFLOW
+#define LMC_ST_BAD_HEADER LMC_STATUS_BAD_HEADER
+#define LMC_ST_BAD_STREAM LMC_STATUS_BAD_STREAM
+#define LMC_ST_LOOKBACK_TIMEOUT LMC_STATUS_LOOKBACK_TIMEOUT
 
 // Device copy of lmc_kv_layout (include/lmc_hip.h), strides in elements.
 struct KvAddr {

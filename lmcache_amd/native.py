@@ -9,6 +9,7 @@ cross the C ABI -- tensors are passed as raw device pointers.
 import ctypes
 import os
 import subprocess
+import sys
 import threading
 from typing import Optional, Sequence, Tuple
 
@@ -16,7 +17,8 @@ import torch  # must be imported before the .so so that a single libamdhip64 (to
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "liblmc_hip.so")
+# LMCACHE_AMD_SO: an alternative build of the same library (A/B timing of experimental kernels: tools/probes)
+SO_PATH = os.environ.get("LMCACHE_AMD_SO") or os.path.join(CSRC, "liblmc_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 BF16, FP16 = 0, 1
@@ -74,8 +76,8 @@ SYMBOLS = {
     "lmc_ctx_profile_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
     "lmc_quantize": (ctypes.c_int, [_vp, _PL, _i32, _i32, _vp, _vp, _vp, _vp]),
     "lmc_calculate_cdf": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "lmc_encode_chunks": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp]),
-    "lmc_decode_chunks": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _vp]),
+    "lmc_encode_chunks": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp, _vp]),
+    "lmc_decode_chunks": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _vp, _vp]),
     "lmc_decode_symbols": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "lmc_copy_kv": (ctypes.c_int, [_vp, _PL, _i32, _i32, _PL, _i32, _vp]),
     "lmc_pinned_alloc": (ctypes.c_int, [_sz, ctypes.POINTER(_vp)]),
@@ -115,7 +117,7 @@ def lib() -> ctypes.CDLL:
             for name, (res, args) in SYMBOLS.items():
                 fn = getattr(L, name)  # AttributeError if the ABI and this binding drift apart
                 fn.restype, fn.argtypes = res, args
-            if L.lmc_abi_version() != 1:
+            if L.lmc_abi_version() != 2:
                 raise NativeError("liblmc_hip.so ABI version mismatch; rebuild")
             _lib = L
     return _lib
@@ -172,6 +174,58 @@ def blob_bound(L: int, T: int, H: int, D: int) -> int:
 
 def current_stream_ptr(device=None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _PointerTables:
+    """Device copies of plane-pointer tables (lmc_kv_layout.plane_ptrs), keyed by the pointers themselves.
+
+    A serving engine hands the same per-layer KV tensors to every store()/retrieve(), so the table of a call
+    is almost always one uploaded before: no copy, no host wait.  A new table goes through a pinned staging
+    slot with an asynchronous copy on the caller's current stream (the kernels that read it are queued behind
+    it on that stream); the host never waits for the device here (the reference's own note on this path:
+    "synchronize is harmful", local_backend.py:83-90)."""
+    SLOTS = 16          # pinned staging slots, reused round-robin (a slot is free once its copy's event fired)
+    MAX_CACHED = 64
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._cache = {}     # (device index, ptrs tuple) -> device int64 tensor
+        self._order = []
+        self._stage = None   # PinnedBuffer, SLOTS x 2 KiB
+        self._events = [None] * self.SLOTS
+        self._next = 0
+
+    def get(self, ptrs: Sequence[int], device: torch.device) -> torch.Tensor:
+        key = (device.index, tuple(ptrs))
+        with self._lock:
+            t = self._cache.get(key)
+            if t is not None:
+                return t
+            n = len(ptrs)
+            assert n <= 256, "at most 256 planes"
+            if self._stage is None:
+                self._stage = PinnedBuffer(self.SLOTS * 2048)
+            k = self._next
+            self._next = (k + 1) % self.SLOTS
+            if self._events[k] is not None:
+                self._events[k].synchronize()   # 16 uploads ago: long done
+            view = self._stage.tensor[k * 2048:k * 2048 + 8 * n].view(torch.int64)
+            view.copy_(torch.tensor(ptrs, dtype=torch.int64))
+            with torch.cuda.device(device):
+                t = torch.empty(n, dtype=torch.int64, device=device)
+                cur = torch.cuda.current_stream(device)
+                memcpy_async(t.data_ptr(), self._stage.ptr + k * 2048, 8 * n, "h2d", cur.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+            self._events[k] = ev
+            self._cache[key] = t
+            self._order.append(key)
+            if len(self._order) > self.MAX_CACHED:
+                self._cache.pop(self._order.pop(0), None)
+            return t
+
+
+_pointer_tables = _PointerTables()
 
 
 class KVLayout:
@@ -244,7 +298,7 @@ class KVLayout:
                     raise ValueError("all K/V tensors must share shape, strides, dtype and device")
                 ptrs.append(x.data_ptr())
                 keep.append(x)
-        table = torch.tensor(ptrs, dtype=torch.int64).to(k0.device, non_blocking=False)
+        table = _pointer_tables.get(ptrs, k0.device)
         s = KvLayoutStruct()
         if fmt == "vllm":
             T, H, D = k0.shape
@@ -277,7 +331,7 @@ class KVLayout:
                 raise ValueError("all layer caches must share shape, strides and dtype")
             ptrs += [c[0].data_ptr(), c[1].data_ptr()]
             keep.append(c)
-        table = torch.tensor(ptrs, dtype=torch.int64).to(c0.device)
+        table = _pointer_tables.get(ptrs, c0.device)
         sm = slot_mapping.to(device=c0.device, dtype=torch.int64).contiguous()
         s = KvLayoutStruct()
         if layout == "NBHD":
@@ -318,8 +372,10 @@ class PinnedBuffer:
             self.ptr = 0
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: leave the pages to the OS then
         try:
-            self.free()
+            if not sys.is_finalizing():
+                self.free()
         except Exception:
             pass
 
@@ -342,7 +398,8 @@ class Context:
 
     def __del__(self):
         try:
-            self.close()
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 
@@ -352,7 +409,7 @@ class Context:
     def raise_on_status(self, what: str):
         st = self.status(clear=True)
         if st:
-            raise NativeError(f"{what}: device status 0x{st:x} (1=stream overflow, 2=bad header, 4=bad stream)")
+            raise NativeError(f"{what}: {describe_status(st)}")
 
     def profile(self, enable: bool) -> None:
         check(lib().lmc_ctx_profile(self.handle, 1 if enable else 0), "lmc_ctx_profile")
@@ -394,18 +451,21 @@ class Context:
         return out
 
     def encode_chunks(self, src: KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int, bins,
-                      blobs_ptr: int, blob_stride: int, sizes_ptr: int, stream: Optional[int] = None) -> int:
+                      blobs_ptr: int, blob_stride: int, sizes_ptr: int, stream: Optional[int] = None,
+                      status_ptr: Optional[int] = None) -> int:
+        """status_ptr: device-accessible uint32 (pinned host) that receives THIS job's LMC_STATUS_* bits
+        (None: the context's sticky word)."""
         b = self._bins(bins)
         st = current_stream_ptr(src.device) if stream is None else stream
         check(lib().lmc_encode_chunks(self.handle, ctypes.byref(src.struct), tok_begin, tok_end, chunk_tokens, b,
-                                      blobs_ptr, blob_stride, sizes_ptr, st), "lmc_encode_chunks")
+                                      blobs_ptr, blob_stride, sizes_ptr, status_ptr, st), "lmc_encode_chunks")
         return (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
 
     def decode_chunks(self, blobs_ptr: int, blob_stride: int, nchunks: int, dst: KVLayout, dst_tok0: int,
-                      chunk_tokens: int, stream: Optional[int] = None) -> None:
+                      chunk_tokens: int, stream: Optional[int] = None, status_ptr: Optional[int] = None) -> None:
         st = current_stream_ptr(dst.device) if stream is None else stream
         check(lib().lmc_decode_chunks(self.handle, blobs_ptr, blob_stride, nchunks, ctypes.byref(dst.struct),
-                                      dst_tok0, chunk_tokens, st), "lmc_decode_chunks")
+                                      dst_tok0, chunk_tokens, status_ptr, st), "lmc_decode_chunks")
 
     def decode_symbols(self, blob: torch.Tensor, L: int, H: int, D: int, T: int, stream: Optional[int] = None
                        ) -> torch.Tensor:
@@ -420,6 +480,40 @@ class Context:
         st = current_stream_ptr(src.device) if stream is None else stream
         check(lib().lmc_copy_kv(self.handle, ctypes.byref(src.struct), tok_begin, ntok, ctypes.byref(dst.struct),
                                 dst_tok0, st), "lmc_copy_kv")
+
+
+def describe_status(st: int) -> str:
+    names = [(1, "stream overflow"), (2, "bad blob header"), (4, "bad stream"), (8, "look-back timeout")]
+    return f"device status 0x{st:x} (" + ", ".join(n for b, n in names if st & b) + ")"
+
+
+class StatusWords:
+    """Pool of pinned uint32 words a job's kernels report their LMC_STATUS_* bits into (one word per job, so
+    concurrent jobs never see each other's failures)."""
+
+    def __init__(self, n: int = 256):
+        self._buf = PinnedBuffer(4 * n)
+        self._view = self._buf.tensor.view(torch.int32)
+        self._free = list(range(n))
+        self._lock = threading.Lock()
+
+    def acquire(self) -> int:
+        with self._lock:
+            if not self._free:
+                raise NativeError("more than 256 jobs in flight with unread status words")
+            i = self._free.pop()
+        self._view[i] = 0
+        return i
+
+    def ptr(self, i: int) -> int:
+        return self._buf.ptr + 4 * i
+
+    def read_release(self, i: int) -> int:
+        """Value of word i (the job's work must have completed) and return it to the pool."""
+        v = int(self._view[i]) & 0xffffffff
+        with self._lock:
+            self._free.append(i)
+        return v
 
 
 def memcpy_async(dst_ptr: int, src_ptr: int, nbytes: int, kind: str, stream: int) -> None:

@@ -6,8 +6,10 @@ Two OPTIONAL methods extend it for backends that can consume KV where it lies
 (no blob materialisation) -- the engine uses them when present and falls back
 to the reference's chunk-tensor protocol otherwise:
 
-  put_kv_range(keys, src_layout, tok_begin, tok_end, chunk_tokens, blocking) -> int
-  get_kv_range(keys, dst_layout, dst_tok0, chunk_tokens) -> None
+  put_kv_range(keys, src_layout, fmt, tok_begin, tok_end, chunk_tokens, blocking) -> int   chunks stored
+  get_kv_range(keys, dst_layout, fmt, dst_tok0, chunk_tokens) -> int   leading chunks written (a key that has
+      gone since `contains` ends the run: "None on a miss", never an exception); raises NativeError when a
+      stored blob does not decode -- the engine then reports a miss instead of handing garbage to the model
 """
 import abc
 from typing import Iterable, Optional, Tuple

@@ -193,7 +193,12 @@ class LMCLocalBackend(LMCBackendInterface):
         fmt = self.fmt or "vllm"
         if entry.encoded:
             T = entry.shape[2] if fmt == "vllm" else entry.shape[3]
-            self._codec().decode([entry.blob], native.KVLayout.from_chunk(out, fmt), 0, T)
+            codec = self._codec()
+            try:
+                codec.finish_decode(codec.decode([entry.blob], native.KVLayout.from_chunk(out, fmt), 0, T))
+            except native.NativeError:
+                logger.exception("stored chunk does not decode: treated as a miss")
+                return None
         else:
             cur = torch.cuda.current_stream(dev)
             native.memcpy_async(out.data_ptr(), entry.blob.ptr, entry.blob.nbytes, "h2d", cur.cuda_stream)
@@ -280,18 +285,27 @@ class LMCLocalBackend(LMCBackendInterface):
         return n
 
     def get_kv_range(self, keys: Sequence[CacheEngineKey], dst: native.KVLayout, fmt: str, dst_tok0: int,
-                     chunk_tokens: int) -> None:
+                     chunk_tokens: int) -> int:
         """Write chunk i (stored under keys[i]) to dst tokens dst_tok0 + i*chunk_tokens ...; tokens that land
-        below 0 are dropped (retrieve()'s first-chunk trim, cache_engine.py:360-365).  All keys must be present."""
-        entries = [self.dict[k] for k in keys]
+        below 0 are dropped (retrieve()'s first-chunk trim, cache_engine.py:360-365).  Returns the number of
+        leading chunks written (a key that has gone since `contains` ends the run, like the reference's break on
+        the first None chunk, cache_engine.py:339-345); raises NativeError if a stored blob does not decode."""
+        entries = []
+        for k in keys:
+            e = self.dict.get(k)
+            if e is None:
+                break
+            entries.append(e)
         if not entries:
-            return
+            return 0
         ctx = native.get_context(self._cuda_device)
         dev = dst.device
         if self.mode == "cachegen":
+            codec = self._codec()
             with torch.cuda.device(dev):
-                self._codec().decode([e.blob for e in entries], dst, dst_tok0, chunk_tokens)
-            return
+                job = codec.decode([e.blob for e in entries], dst, dst_tok0, chunk_tokens)
+            codec.finish_decode(job)  # this decode's event, then its own status word
+            return len(entries)
         cur = torch.cuda.current_stream(dev)
         stage = None
         if self.mode == "raw":
@@ -317,3 +331,4 @@ class LMCLocalBackend(LMCBackendInterface):
             ev = torch.cuda.Event()
             ev.record(cur)
             self._stage_free = ev
+        return len(entries)

@@ -174,6 +174,7 @@ class LMCPipelinedRemoteBackend(LMCRemoteBackend):
         if bs is None:
             bs = self.connection.get(key.to_string())
             if not bs:
+                self.existing_keys.discard(key)  # gone since `contains`: a miss, not an error
                 raise KeyError(key)
             self._prefetched[key] = bs
         h = native.blob_info(bs)
@@ -202,29 +203,49 @@ class LMCPipelinedRemoteBackend(LMCRemoteBackend):
             self.put_queue.put(payload)
         return n
 
-    def get_kv_range(self, keys, dst, fmt: str, dst_tok0: int, chunk_tokens: int) -> None:
-        """Decode chunk i (stored under keys[i]) into dst tokens dst_tok0 + i*chunk_tokens ...; every key
-        must be present (the engine probes `contains` first)."""
+    def get_kv_range(self, keys, dst, fmt: str, dst_tok0: int, chunk_tokens: int) -> int:
+        """Decode chunk i (stored under keys[i]) into dst tokens dst_tok0 + i*chunk_tokens ...  Returns the
+        number of leading chunks written: a blob that has gone from the store since `contains` ends the run
+        (the reference breaks on the first None chunk, cache_engine.py:339-345) and drops the key from the
+        existing-keys cache.  Every fetched blob is checked on the host (header, geometry against `dst`, length)
+        before it goes to the GPU; a blob whose streams do not check out there raises NativeError."""
+        from lmcache_amd import native
         from lmcache_amd.storage_backend.serde.cachegen_device import get_codec
         codec = get_codec(dst.device.index)
-        batch, first = [], 0
+        batch, first, jobs = [], 0, []
+        keys = list(keys)
 
         def flush():
             nonlocal batch, first
             if batch:
                 with torch.cuda.device(dst.device):
-                    codec.decode(batch, dst, dst_tok0 + first * chunk_tokens, chunk_tokens)
+                    jobs.append(codec.decode(batch, dst, dst_tok0 + first * chunk_tokens, chunk_tokens))
                 first += len(batch)
                 batch = []
 
-        for idx, bs, backlog in self._arrivals(keys):
-            if bs is None:
-                raise KeyError(f"chunk {idx} of the requested range is not in the remote store")
-            batch.append(bs)
-            # decode what has arrived as soon as the fetch thread falls behind, or a full batch is there
-            if len(batch) >= self.fetch_batch or not backlog:
-                flush()
-        flush()
+        try:
+            for idx, bs, backlog in self._arrivals(keys):
+                if bs is None:
+                    self.existing_keys.discard(keys[idx])
+                    break
+                h = native.blob_info(bs)  # raises NativeError on a bad header / truncated blob
+                if (h.num_layers, h.num_heads, h.head_size) != (dst.L, dst.H, dst.D) or h.ntokens > chunk_tokens:
+                    raise native.NativeError(f"chunk {idx}: blob geometry does not match the destination")
+                batch.append(bs)
+                # decode what has arrived as soon as the fetch thread falls behind, or a full batch is there
+                if len(batch) >= self.fetch_batch or not backlog:
+                    flush()
+            flush()
+        finally:
+            err = None
+            for j in jobs:  # wait for every decode that was launched, keep the first failure
+                try:
+                    codec.finish_decode(j)
+                except native.NativeError as e:
+                    err = err or e
+            if err is not None:
+                raise err
+        return first
 
     def _apply_sets(self, item: "_DeferredSets") -> None:
         for key, bs in item.payload:

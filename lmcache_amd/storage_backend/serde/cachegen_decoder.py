@@ -52,8 +52,8 @@ class CacheGenDeserializer(Deserializer):
             dev = torch.cuda.current_device()
             out = torch.empty(shape, dtype=dtype, device=torch.device("cuda", dev))
             codec = get_codec(dev)
-            codec.decode([bs], native.KVLayout.from_chunk(out, self.fmt), 0, int(h.ntokens))
-            # the caller owns `out` and may use it on any stream: finish before returning
-            torch.cuda.current_stream(dev).synchronize()
-            codec.ctx.raise_on_status("CacheGen decode")
+            job = codec.decode([bs], native.KVLayout.from_chunk(out, self.fmt), 0, int(h.ntokens))
+            # the caller owns `out` and may use it on any stream: finish (this decode only) before returning;
+            # a blob whose streams do not check out raises instead of returning garbage
+            codec.finish_decode(job)
             return out

@@ -83,14 +83,22 @@ class EncodeJob:
     nchunks: int
     stride: int
     arena: torch.Tensor        # device uint8, blob i at i*stride
-    sizes: native.PinnedBuffer  # uint32 [nchunks], written by the GPU
+    sizes: Optional[native.PinnedBuffer]  # this job's own uint32 [nchunks], written by the GPU; back in the pool once read
     done: torch.cuda.Event     # recorded after the last encode kernel
     geometry: tuple            # (L, H, D, chunk_tokens)
-    size_list: Optional[List[int]] = None  # filled by sizes_of (the pinned words are reused by the next job)
+    status_idx: int = -1       # this job's status word (native.StatusWords); -1 once read
+    size_list: Optional[List[int]] = None  # filled by sizes_of / offload
     # a long job is launched as a few consecutive ranges of chunks, each with its own event, so that the
     # host-DRAM offload of range r can start while range r+1 is still being encoded: (chunk0, chunk1, event)
     parts: Optional[list] = None
     offload_issued: bool = False  # its device -> host copies are on the copy streams (the arena may be reused after them)
+
+
+@dataclass
+class DecodeJob:
+    """One decode() call in flight: `done` fires after its last kernel, `status_idx` is its own status word."""
+    done: torch.cuda.Event
+    status_idx: int
 
 
 class CacheGenDeviceCodec:
@@ -108,12 +116,12 @@ class CacheGenDeviceCodec:
         self._lock = threading.RLock()
         self._enc_arena: Optional[torch.Tensor] = None
         self._dec_arena: Optional[torch.Tensor] = None
-        self._sizes: Optional[native.PinnedBuffer] = None
-        self._arena_free: Optional[torch.cuda.Event] = None  # D2H of the previous job done
+        self._size_pool: List[native.PinnedBuffer] = []      # pinned size words, one buffer per job in flight
+        self._status = native.StatusWords()                  # one status word per job in flight
+        self._arena_free: Optional[torch.cuda.Event] = None  # D2H of the last job that used the shared arena done
         self._dec_free: Optional[torch.cuda.Event] = None    # previous decode kernel done
         self._stage: Optional[native.PinnedBuffer] = None    # staging for pageable `bytes` inputs
-        self._pending: Optional[EncodeJob] = None            # last job whose sizes were not read yet
-        self._last_job: Optional[EncodeJob] = None           # last job launched (has its offload been issued?)
+        self._shared_job: Optional[EncodeJob] = None         # last job that encoded into the shared arena
         self.decode_batch_chunks = 8                         # chunks per H2D/decode pipeline stage
 
     # ---- encode ------------------------------------------------------------------
@@ -125,21 +133,28 @@ class CacheGenDeviceCodec:
         n = (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
         stride = native.r16(native.blob_bound(L, chunk_tokens, H, D))
         with self._lock:
-            if self._pending is not None:
-                self.sizes_of(self._pending)  # the pinned size words are about to be overwritten
             with torch.cuda.device(self.device):
-                # The shared arena may be rewritten only after the previous job's copies have been ISSUED (then
-                # `_arena_free` orders us behind them).  A non-blocking store defers its offload to the
-                # backend's worker thread: if that has not happened yet, this job gets an arena of its own.
-                prev = self._last_job
+                # The shared arena may be rewritten only after the copies of the last job that used it have been
+                # ISSUED (then `_arena_free` orders us behind them).  A non-blocking store defers its offload to the
+                # backend's worker thread: while that has not happened, a new job gets an arena of its own.
+                prev = self._shared_job
                 if prev is None or prev.offload_issued:
                     if self._enc_arena is None or self._enc_arena.numel() < n * stride:
                         self._enc_arena = torch.empty(n * stride, dtype=torch.uint8, device=self.device)
                     arena = self._enc_arena
                 else:
                     arena = torch.empty(n * stride, dtype=torch.uint8, device=self.device)
-                if self._sizes is None or self._sizes.nbytes < 4 * n:
-                    self._sizes = native.PinnedBuffer(4 * max(n, 256))
+                # every job owns its size words and its status word: a second store never waits for the first
+                # one's sizes to be read (the reference's own note on this path: "synchronize is harmful",
+                # local_backend.py:83-90), and never sees its failures
+                sizes = None
+                for k, b in enumerate(self._size_pool):
+                    if b.nbytes >= 4 * n:
+                        sizes = self._size_pool.pop(k)
+                        break
+                if sizes is None:
+                    sizes = native.PinnedBuffer(4 * max(n, 256))
+                st = self._status.acquire()
                 cur = torch.cuda.current_stream(self.device)
                 if arena is self._enc_arena and self._arena_free is not None:
                     cur.wait_event(self._arena_free)  # previous job's D2H has read the arena
@@ -150,25 +165,37 @@ class CacheGenDeviceCodec:
                     c1 = min(n, c0 + per)
                     self.ctx.encode_chunks(src, tok_begin + c0 * chunk_tokens, min(tok_end, tok_begin + c1 * chunk_tokens),
                                            chunk_tokens, bins, arena.data_ptr() + c0 * stride, stride,
-                                           self._sizes.ptr + 4 * c0, stream=cur.cuda_stream)
+                                           sizes.ptr + 4 * c0, stream=cur.cuda_stream, status_ptr=self._status.ptr(st))
                     ev = torch.cuda.Event()
                     ev.record(cur)
                     parts.append((c0, c1, ev))
                 done = parts[-1][2]
-            job = EncodeJob(n, stride, arena, self._sizes, done, (L, H, D, chunk_tokens), None, parts)
-            self._pending = job
-            self._last_job = job
+            job = EncodeJob(n, stride, arena, sizes, done, (L, H, D, chunk_tokens), st, None, parts)
+            if arena is self._enc_arena:
+                self._shared_job = job
             return job
+
+    def _check_job(self, job: EncodeJob) -> None:
+        """The job's kernels have completed: read its status word (once) and raise on a device error."""
+        if job.status_idx >= 0:
+            st = self._status.read_release(job.status_idx)
+            job.status_idx = -1
+            if st:
+                raise native.NativeError("CacheGen encode: " + native.describe_status(st))
+
+    def _release_sizes(self, job: EncodeJob) -> None:
+        if job.sizes is not None:
+            self._size_pool.append(job.sizes)
+            job.sizes = None
 
     def sizes_of(self, job: EncodeJob) -> List[int]:
         """Wait for THIS job only (event, not device) and read the blob sizes the GPU wrote to pinned memory."""
         with self._lock:
             if job.size_list is None:
                 job.done.synchronize()
-                self.ctx.raise_on_status("CacheGen encode")
                 job.size_list = job.sizes.tensor[:4 * job.nchunks].view(torch.int32).tolist()
-                if self._pending is job:
-                    self._pending = None
+                self._release_sizes(job)
+                self._check_job(job)
             return job.size_list
 
     def offload(self, job: EncodeJob, sizes: Optional[Sequence[int]], arena: PinnedArena) -> (List[HostBlob], torch.cuda.Event):
@@ -188,8 +215,6 @@ class CacheGenDeviceCodec:
             for c0, c1, ev in (job.parts if progressive else [(0, job.nchunks, job.done)]):
                 if progressive:
                     ev.synchronize()  # this range only
-                    if c0 == 0:
-                        self.ctx.raise_on_status("CacheGen encode")
                     sizes.extend(job.sizes.tensor[4 * c0:4 * c1].view(torch.int32).tolist())
                 for st in streams:
                     st.wait_event(ev)
@@ -199,10 +224,9 @@ class CacheGenDeviceCodec:
                                         streams[i % len(streams)].cuda_stream)
                     blobs.append(hb)
             if progressive:
-                self.ctx.raise_on_status("CacheGen encode")
                 job.size_list = list(sizes)
-                if self._pending is job:
-                    self._pending = None
+                self._release_sizes(job)
+                self._check_job(job)  # every range's event has fired
             if len(streams) > 1:  # fold the second queue into the first: one event covers both
                 ev2 = torch.cuda.Event()
                 ev2.record(self.copy_stream2)
@@ -215,24 +239,30 @@ class CacheGenDeviceCodec:
         return blobs, ev
 
     # ---- decode ------------------------------------------------------------------
-    def _dec_slots(self, n: int, stride: int) -> torch.Tensor:
+    def _dec_slots(self, n: int, stride: int, cur) -> torch.Tensor:
         if self._dec_arena is None or self._dec_arena.numel() < n * stride:
             self._dec_arena = torch.empty(n * stride, dtype=torch.uint8, device=self.device)
+            # the caching allocator may hand out a block whose previous owner still has kernels queued on the
+            # current stream: the side-stream copies into it must not start before those
+            self.copy_stream.wait_stream(cur)
         return self._dec_arena
 
-    def decode(self, host_blobs: Sequence, dst: native.KVLayout, dst_tok0: int, chunk_tokens: int) -> None:
+    def decode(self, host_blobs: Sequence, dst: native.KVLayout, dst_tok0: int, chunk_tokens: int,
+               batch_chunks: Optional[int] = None) -> Optional[DecodeJob]:
         """H2D the blobs on the side stream and decode them on the current stream straight into `dst`,
         pipelined in batches of `decode_batch_chunks` (copy of batch b+1 overlaps the decode of batch b).
-        host_blobs: HostBlob (pinned) or bytes-like (staged through pinned memory)."""
+        host_blobs: HostBlob (pinned) or bytes-like (staged through pinned memory).
+        Asynchronous: returns a DecodeJob; finish_decode(job) waits for it and raises on a corrupt blob."""
         n = len(host_blobs)
         if n == 0:
-            return
+            return None
         sizes = [hb.nbytes if isinstance(hb, HostBlob) else len(hb) for hb in host_blobs]
         stride = native.r16(max(sizes))
         with self._lock:
             with torch.cuda.device(self.device):
                 cur = torch.cuda.current_stream(self.device)
-                arena = self._dec_slots(n, stride)
+                arena = self._dec_slots(n, stride, cur)
+                st = self._status.acquire()
                 if self._dec_free is not None:
                     self.copy_stream.wait_event(self._dec_free)  # previous decode has read the slots
                 cs = self.copy_stream.cuda_stream
@@ -247,7 +277,7 @@ class CacheGenDeviceCodec:
                         self.copy_stream.synchronize()  # staging buffer is reused: earlier H2D must be done
                 # H2D and decode are pipelined in batches: the copy stream runs ahead, the compute stream
                 # decodes batch b as soon as its blobs have landed (one event per batch)
-                B = self.decode_batch_chunks
+                B = batch_chunks or self.decode_batch_chunks
                 last = None
                 for b0 in range(0, n, B):
                     b1 = min(n, b0 + B)
@@ -265,17 +295,30 @@ class CacheGenDeviceCodec:
                     ready.record(self.copy_stream)
                     cur.wait_event(ready)
                     self.ctx.decode_chunks(arena.data_ptr() + b0 * stride, stride, b1 - b0, dst,
-                                           dst_tok0 + b0 * chunk_tokens, chunk_tokens, stream=cur.cuda_stream)
+                                           dst_tok0 + b0 * chunk_tokens, chunk_tokens, stream=cur.cuda_stream,
+                                           status_ptr=self._status.ptr(st))
                     last = torch.cuda.Event()
                     last.record(cur)
                 self._dec_free = last
+                return DecodeJob(last, st)
+
+    def finish_decode(self, job: Optional[DecodeJob], what: str = "CacheGen decode") -> None:
+        """Wait for THIS decode (its event, not the device) and raise NativeError if a kernel flagged its blobs
+        (bad header / directory / stream): the destination then holds garbage and must not be used."""
+        if job is None:
+            return
+        job.done.synchronize()
+        st = self._status.read_release(job.status_idx)
+        if st:
+            raise native.NativeError(f"{what}: " + native.describe_status(st))
 
     def close(self):
         with self._lock:
-            for b in (self._sizes, self._stage):
+            for b in self._size_pool + [self._stage]:
                 if b is not None:
                     b.free()
-            self._sizes = self._stage = None
+            self._size_pool = []
+            self._stage = None
             self._enc_arena = self._dec_arena = None
 
 

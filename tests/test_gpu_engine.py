@@ -371,10 +371,33 @@ def test_pipelined_remote_backend_range_protocol_and_misses(oracle):
         got = piped.engine_.batched_get(iter([keys[0], bogus, keys[2]]))
         assert len(got) == 3 and got[1] is None and got[0] is not None and got[2] is not None
         assert torch.equal(got[2][:, 0], torch.stack([k[2 * cs:3 * cs] for k, _ in b]))
-        with pytest.raises(KeyError):
-            out = torch.empty((nl, 2, cs, 8, 128), dtype=torch.bfloat16, device="cuda")
-            from lmcache_amd import native
-            piped.engine_.get_kv_range([bogus], native.KVLayout.from_chunk(out, fmt), fmt, 0, cs)
+        # a key that is not there ends the run: nothing written, no exception (abstract_backend.py: "None on a miss")
+        out = torch.empty((nl, 2, cs, 8, 128), dtype=torch.bfloat16, device="cuda")
+        from lmcache_amd import native
+        assert piped.engine_.get_kv_range([bogus], native.KVLayout.from_chunk(out, fmt), fmt, 0, cs) == 0
+        # a blob that disappears from the store after `contains` said yes (eviction, restart): retrieve degrades
+        # to the prefix that is still there, like the reference's break on the first None chunk
+        # (cache_engine.py:339-345), and the stale key leaves the existing-keys cache
+        store = piped.engine_.connection._store
+        gone = keys[3].to_string()
+        saved = store.pop(gone)
+        d, md = piped.retrieve(tokens)
+        assert int(md.sum()) == 3 * cs and md[:3 * cs].all()
+        for (kb, vb), (kd, vd) in zip(b, d):
+            assert torch.equal(kb[:3 * cs], kd) and torch.equal(vb[:3 * cs], vd)
+        assert keys[3] not in piped.engine_.existing_keys
+        store[gone] = saved
+        e, me = piped.retrieve(tokens)
+        assert int(me.sum()) == num_tokens
+        # a blob that arrives damaged never becomes KV: the lookup is a miss
+        bad = bytearray(saved)
+        bad[len(bad) // 2] ^= 0x5a
+        store[gone] = bytes(bad)
+        f, mf = piped.retrieve(tokens)
+        assert f == () and not mf.any()
+        store[gone] = saved
+        g2, mg = piped.retrieve(tokens)
+        assert int(mg.sum()) == num_tokens
     finally:
         plain.close()
         piped.close()
@@ -407,6 +430,89 @@ def test_back_to_back_nonblocking_stores_keep_their_own_bytes(oracle):
             assert int(mask.sum()) == 256
             for t0 in range(0, 256, cs):
                 part = tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in kv)
+                want = oracle_roundtrip(oracle, part, fmt, MODEL, torch.bfloat16)
+                have = to_blob(tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in got)).cpu()
+                assert torch.equal(have, want)
+    finally:
+        engine.close()
+
+
+def test_corrupt_pinned_blob_is_a_miss_never_garbage(oracle):
+    """A CacheGen chunk damaged in pinned host DRAM (header, counts or streams) must not come back as KV:
+    retrieve() reports a miss and get() returns None -- each decode reports into its own status word, so the
+    failure neither disappears nor shows up later as somebody else's "encode" error."""
+    import ctypes
+    fmt, cs, nl = "vllm", 128, 4
+    engine = LMCacheEngine(make_cfg("cachegen-host", cs), dumb_metadata(fmt, MODEL))
+    try:
+        toks = generate_tokens(384, "cuda")
+        kv = generate_kv_cache(384, fmt, "cuda", num_layers=nl)
+        engine.store(toks, kv)
+        good, m = engine.retrieve(toks)
+        assert int(m.sum()) == 384
+        keys = [engine._make_key(h, fmt) for h in engine._prefix_hash(engine._chunk_tokens(toks))]
+        entry = engine.engine_.dict[keys[1]]
+        raw = (ctypes.c_uint8 * entry.blob.nbytes).from_address(entry.blob.ptr)
+        for where in (entry.blob.nbytes - 40, 146, entry.blob.nbytes // 2):  # final states, a row prefix, a stream
+            old = raw[where]
+            raw[where] = old ^ 0x3c
+            ret, mask = engine.retrieve(toks)
+            assert ret == () and not mask.any(), where
+            assert engine.engine_.get(keys[1]) is None
+            assert engine.engine_.get(keys[0]) is not None  # the neighbours still decode
+            raw[where] = old
+            ret, mask = engine.retrieve(toks)
+            assert int(mask.sum()) == 384
+            for (k, v), (k0, v0) in zip(ret, good):
+                assert torch.equal(k, k0) and torch.equal(v, v0)
+        # a later store is not blamed for the earlier decode failures
+        engine.store(generate_tokens(128, "cuda"), generate_kv_cache(128, fmt, "cuda", num_layers=nl))
+    finally:
+        engine.close()
+
+
+def test_jobs_own_their_size_and_status_words(oracle):
+    """Two encodes in flight: the second one neither waits for the first one's sizes to be read nor shares
+    its pinned size / status words (cachegen_device.py); and the order A non-blocking, B blocking, C must not
+    let C rewrite the shared arena A's deferred offload still has to read."""
+    import threading
+    import time
+    from lmcache_amd import native
+    from lmcache_amd.storage_backend.serde.cachegen_device import get_codec
+    fmt, cs, nl = "vllm", 128, 4
+    codec = get_codec()
+    kv = generate_kv_cache(256, fmt, "cuda", num_layers=nl)
+    lay = native.KVLayout.from_kv_tuple(kv, fmt)
+    assert native.KVLayout.from_kv_tuple(kv, fmt).struct.plane_ptrs == lay.struct.plane_ptrs  # pointer table cached
+    from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
+    bins = CacheGenConfig.from_model_name(MODEL).plane_bins(nl)
+    j1 = codec.encode(lay, 0, 256, cs, bins)
+    j2 = codec.encode(lay, 0, 128, cs, bins)
+    assert j1.size_list is None and j1.sizes is not j2.sizes and j1.status_idx != j2.status_idx
+    s2, s1 = codec.sizes_of(j2), codec.sizes_of(j1)
+    assert len(s1) == 2 and len(s2) == 1 and s1[0] == s2[0] and j1.status_idx == -1
+    j1.offload_issued = j2.offload_issued = True  # nothing else will read these arenas
+
+    engine = LMCacheEngine(make_cfg("cachegen-host", cs), dumb_metadata(fmt, MODEL))
+    try:
+        gate = threading.Event()
+        engine.engine_.put_queue.put(lambda: gate.wait(10))   # the worker blocks here first
+        seqs = [(generate_tokens(256, "cuda"), tuple((k + 0.125 * i, v - 0.25 * i) for k, v in
+                                                     generate_kv_cache(256, fmt, "cuda", num_layers=nl))) for i in range(3)]
+        engine.store(seqs[0][0], seqs[0][1], blocking=False)  # A: shared arena, offload deferred
+        engine.store(seqs[1][0], seqs[1][1], blocking=True)   # B: its own arena, offloaded inline
+        engine.store(seqs[2][0], seqs[2][1], blocking=True)   # C: must not take the shared arena yet
+        torch.cuda.synchronize()
+        gate.set()
+        for _ in range(500):
+            if int(engine.retrieve(seqs[0][0])[1].sum()) == 256:
+                break
+            time.sleep(0.01)
+        for toks, kvs in seqs:
+            got, mask = engine.retrieve(toks)
+            assert int(mask.sum()) == 256
+            for t0 in range(0, 256, cs):
+                part = tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in kvs)
                 want = oracle_roundtrip(oracle, part, fmt, MODEL, torch.bfloat16)
                 have = to_blob(tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in got)).cpu()
                 assert torch.equal(have, want)
