@@ -111,12 +111,36 @@ class LMCacheEngine:
     @torch.no_grad()
     def store(self, tokens: torch.Tensor, kv_tensors_raw: KVCache, skip_existing=True, blocking=True) -> None:
         """tokens [seq_len]; kv_tensors_raw: per layer (K, V), [T,H,D] ("vllm") or [H,T,D] ("huggingface")."""
-        t_start = time.perf_counter()
         fmt = self.metadata.fmt
         assert len(tokens.shape) == 1, f"Invalid shape of tokens: {tokens.shape}"
         assert len(kv_tensors_raw) > 0, "Empty kv_tensors"
         assert len(tokens) == self._num_tokens_in_kv(kv_tensors_raw, fmt), \
             "Number of tokens in the kv cache does not match the input tokens"
+        self._store_from(tokens, lambda: native.KVLayout.from_kv_tuple(self._as_cuda_kv(kv_tensors_raw), fmt),
+                         skip_existing, blocking)
+
+    @_lmcache_nvtx_annotate
+    @torch.no_grad()
+    def store_paged(self, tokens: torch.Tensor, kv_caches, slot_mapping: torch.Tensor, block_size: int,
+                    layout: str = "NBHD", skip_existing=True, blocking=True) -> None:
+        """store() for a serving engine's PAGED KV cache -- what the external vLLM connector does around
+        store() (`lmcache_store_kv`: gather the rows of every layer's cache by slot_mapping into [T,H,D], then
+        store; docs/source/developer_tutorial/LLM_Engine.rst:91-122), without the gather copy: the kernels
+        read the blocks where they lie.
+          kv_caches     per layer a tensor [2, num_blocks, block_size, H, D] (layout "NBHD", vLLM's flash layout)
+                        or [2, num_blocks, H, block_size, D] ("NHBD", BASELINE.json's north star), bf16 / fp16
+          slot_mapping  int64 [len(tokens)]: token t lives in slot slot_mapping[t] = block * block_size + offset
+        The engine's fmt must be "vllm" (chunks are keyed and laid out [L,2,T,H,D])."""
+        assert self.metadata.fmt == "vllm", "paged KV is a vLLM layout"
+        assert len(tokens.shape) == 1, f"Invalid shape of tokens: {tokens.shape}"
+        assert len(kv_caches) > 0, "Empty kv_caches"
+        assert len(tokens) == slot_mapping.numel(), "one slot per token"
+        self._store_from(tokens, lambda: native.KVLayout.paged(kv_caches, slot_mapping, block_size, layout),
+                         skip_existing, blocking)
+
+    def _store_from(self, tokens: torch.Tensor, make_src, skip_existing: bool, blocking: bool) -> None:
+        t_start = time.perf_counter()
+        fmt = self.metadata.fmt
         ntok = len(tokens)
         cs = self.chunk_size
         chunk_hashes = self._prefix_hash(self._chunk_tokens(tokens))
@@ -127,8 +151,7 @@ class LMCacheEngine:
                 logger.info("Stored/updated 0 chunks (all present)")
                 return
         keys = [self._make_key(h, fmt) for h in chunk_hashes[first:]]
-        kv = self._as_cuda_kv(kv_tensors_raw)
-        src = native.KVLayout.from_kv_tuple(kv, fmt)
+        src = make_src()
         t_plan = time.perf_counter()
         if getattr(self.engine_, "supports_kv_layout", False):
             n = self.engine_.put_kv_range(keys, src, fmt, first * cs, ntok, cs, blocking=blocking)
@@ -156,9 +179,51 @@ class LMCacheEngine:
     def retrieve(self, tokens: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Tuple[KVCache, torch.Tensor]:
         """Prefix hits only; `mask` (suffix mask) marks the tokens whose KV is wanted.
         Returns (per-layer (K, V) tuple or (), ret_mask)."""
-        t_start = time.perf_counter()
         fmt = self.metadata.fmt
         tdim = _token_dim(fmt)
+        box = {}
+
+        def make_dst(nret, L, H, D, dtype, dev):
+            shape = (L, 2, nret, H, D) if fmt == "vllm" else (L, 2, H, nret, D)
+            box["blob"] = torch.empty(shape, dtype=dtype, device=dev)
+            return native.KVLayout.from_chunk(box["blob"], fmt)
+
+        got, ret_mask = self._retrieve_into(tokens, mask, make_dst)
+        if got == 0:
+            return (), ret_mask
+        blob = box["blob"].narrow(2 if fmt == "vllm" else 3, 0, got)
+        ret = self._blob_to_tuple_kv(blob)
+        assert ret[0][0].shape[tdim] == got
+        return ret, ret_mask
+
+    @_lmcache_nvtx_annotate
+    @torch.no_grad()
+    def retrieve_into_paged(self, tokens: torch.Tensor, kv_caches, slot_mapping: torch.Tensor, block_size: int,
+                            layout: str = "NBHD", mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """retrieve() straight into a serving engine's PAGED KV cache: the decoded (or copied) KV of token t is
+        written to slot slot_mapping[t] of every layer's cache -- the connector's `lmcache_retrieve_kv` +
+        reshape_and_cache_flash scatter (LLM_Engine.rst:101-122) fused into the decode kernel's store.  Slots
+        need not be contiguous or ordered (CacheBlend-style placement of a non-prefix segment, BASELINE
+        configs[4]).  Returns ret_mask (True where KV was written); the caches of tokens outside it are untouched.
+          slot_mapping  int64 [len(tokens)] (entries of tokens the mask skips are ignored)"""
+        assert self.metadata.fmt == "vllm", "paged KV is a vLLM layout"
+        assert len(tokens) == slot_mapping.numel(), "one slot per token"
+        num_skip_tok = 0 if mask is None else int(len(mask) - int(torch.sum(mask)))
+
+        def make_dst(nret, L, H, D, dtype, dev):
+            c0 = kv_caches[0]
+            assert len(kv_caches) == L and c0.dtype == dtype, "cache geometry / dtype differs from the stored chunks"
+            return native.KVLayout.paged(kv_caches, slot_mapping[num_skip_tok:num_skip_tok + nret], block_size, layout)
+
+        _, ret_mask = self._retrieve_into(tokens, mask, make_dst)
+        return ret_mask
+
+    def _retrieve_into(self, tokens: torch.Tensor, mask: Optional[torch.Tensor], make_dst) -> Tuple[int, torch.Tensor]:
+        """The body of retrieve(): prefix probe, the first-chunk trim of a suffix mask, then every hit chunk
+        written to destination tokens 0 .. got-1 of the layout make_dst(nret, L, H, D, dtype, device) returns.
+        -> (got = tokens written, ret_mask)."""
+        t_start = time.perf_counter()
+        fmt = self.metadata.fmt
         cs = self.chunk_size
         ret_mask = torch.ones_like(tokens, dtype=torch.bool)
         num_skip_tok = 0
@@ -168,6 +233,11 @@ class LMCacheEngine:
         ret_mask[:num_skip_tok] = False
         chunk_hashes = self._prefix_hash(self._chunk_tokens(tokens), num_skip_chunk)
         keys = [self._make_key(h, fmt) for h in chunk_hashes]
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def miss():
+            ret_mask[:] = False
+            return 0, ret_mask
 
         if getattr(self.engine_, "supports_kv_layout", False):
             hits = 0
@@ -177,20 +247,16 @@ class LMCacheEngine:
                 hits += 1
             _, extra, nret = self.plan_retrieve(len(tokens), cs, num_skip_tok, hits)
             if hits == 0 or nret <= 0:
-                ret_mask[:] = False
-                return (), ret_mask
+                return miss()
             try:
                 shape0, dtype = self.engine_.chunk_meta(keys[0])
             except KeyError:  # gone since `contains`: a miss
-                ret_mask[:] = False
-                return (), ret_mask
+                return miss()
             L = shape0[0]
             H, D = (shape0[3], shape0[4]) if fmt == "vllm" else (shape0[2], shape0[4])
-            dev = torch.device("cuda", torch.cuda.current_device())
-            shape = (L, 2, nret, H, D) if fmt == "vllm" else (L, 2, H, nret, D)
-            blob = torch.empty(shape, dtype=dtype, device=dev)
+            dst = make_dst(nret, L, H, D, dtype, dev)
             try:
-                got = self.engine_.get_kv_range(keys[:hits], native.KVLayout.from_chunk(blob, fmt), fmt, -extra, cs)
+                got = self.engine_.get_kv_range(keys[:hits], dst, fmt, -extra, cs)
             except native.NativeError:
                 # a stored blob that does not decode must never reach the model as KV: the whole lookup is a miss
                 logger.exception("retrieve: a cached chunk failed to decode; treated as a miss")
@@ -198,11 +264,9 @@ class LMCacheEngine:
             got = hits if got is None else got
             if got < hits:  # some chunks went missing after `contains`: keep the prefix that arrived
                 hits = got
-                _, extra, nret2 = self.plan_retrieve(len(tokens), cs, num_skip_tok, hits)
-                if hits == 0 or nret2 <= 0:
-                    ret_mask[:] = False
-                    return (), ret_mask
-                blob = blob.narrow(2 if fmt == "vllm" else 3, 0, nret2)
+                _, extra, nret = self.plan_retrieve(len(tokens), cs, num_skip_tok, hits)
+                if hits == 0 or nret <= 0:
+                    return miss()
         else:
             chunks = []
             for chunk in self.engine_.batched_get(iter(keys)):
@@ -212,15 +276,12 @@ class LMCacheEngine:
             hits = len(chunks)
             _, extra, nret = self.plan_retrieve(len(tokens), cs, num_skip_tok, hits)
             if hits == 0 or nret <= 0:
-                ret_mask[:] = False
-                return (), ret_mask
+                return miss()
             c0 = chunks[0]
             L = c0.shape[0]
             H, D = (c0.shape[3], c0.shape[4]) if fmt == "vllm" else (c0.shape[2], c0.shape[4])
-            shape = (L, 2, nret, H, D) if fmt == "vllm" else (L, 2, H, nret, D)
-            blob = torch.empty(shape, dtype=c0.dtype, device=c0.device)
+            dst = make_dst(nret, L, H, D, c0.dtype, c0.device)
             ctx = native.get_context(c0.device.index)
-            dst = native.KVLayout.from_chunk(blob, fmt)
             pos = -extra
             for c in chunks:  # scatter every chunk into its slice (replaces slice + torch.cat, :360-368)
                 T = c.shape[2] if fmt == "vllm" else c.shape[3]
@@ -228,12 +289,10 @@ class LMCacheEngine:
                 if skip < T:
                     ctx.copy_kv(native.KVLayout.from_chunk(c, fmt), skip, T - skip, dst, pos + skip)
                 pos += T
-        ret = self._blob_to_tuple_kv(blob)
-        retrieved = ret[0][0].shape[tdim]
-        ret_mask[num_skip_tok + retrieved:] = False
-        logger.info("Retrieved %d chunks (%d tokens in total) -- elapsed time %.4f", hits, retrieved,
+        ret_mask[num_skip_tok + nret:] = False
+        logger.info("Retrieved %d chunks (%d tokens in total) -- elapsed time %.4f", hits, nret,
                     time.perf_counter() - t_start)
-        return ret, ret_mask
+        return nret, ret_mask
 
     def close(self):
         self.engine_.close()

@@ -518,3 +518,92 @@ def test_jobs_own_their_size_and_status_words(oracle):
                 assert torch.equal(have, want)
     finally:
         engine.close()
+
+
+# ------------------------------------------------------------------ paged KV entry points (rows a19 / f2, BASELINE configs[4])
+def _paged_scatter(cache_layers, kv_tuple, slots, bs, layout):
+    """Reference scatter in torch: token t of every layer's (K, V) [T,H,D] into slot slots[t]."""
+    blk, off = slots // bs, slots % bs
+    for c, (k, v) in zip(cache_layers, kv_tuple):
+        for kvi, x in enumerate((k, v)):
+            if layout == "NBHD":
+                c[kvi, blk, off] = x
+            else:
+                c[kvi, blk, :, off] = x
+
+
+def _paged_gather(cache_layers, slots, bs, layout):
+    blk, off = slots // bs, slots % bs
+    out = []
+    for c in cache_layers:
+        out.append(tuple(c[kvi, blk, off] if layout == "NBHD" else c[kvi, blk, :, off] for kvi in range(2)))
+    return tuple(out)
+
+
+@pytest.mark.parametrize("layout", ["NHBD", "NBHD"])
+@pytest.mark.parametrize("backend", ["cachegen-host", "cuda"])
+def test_paged_store_and_scatter_retrieve_of_independent_segments(layout, backend, oracle):
+    """BASELINE configs[4] at the engine boundary: independent (non-prefix) token segments of a Mistral-7B shaped
+    model are stored from one paged KV cache (store_paged: slot_mapping gather fused into the encode) and
+    written into ANOTHER paged cache at random, non-contiguous, interleaved slots (retrieve_into_paged: decode +
+    scatter in one kernel).  What lands in the slots equals the dense retrieve() and, chunk by chunk, the oracle."""
+    fmt, cs, nl, H, D, bs = "vllm", 256, 32, 8, 128, 16
+    nseg, seg = (8, 2048) if backend == "cachegen-host" else (3, 600)
+    engine = LMCacheEngine(make_cfg(backend, cs), dumb_metadata(fmt, MODEL))
+    try:
+        g = torch.Generator().manual_seed(5)
+        ntot = nseg * seg
+        nblocks = (ntot + bs - 1) // bs + 7
+        shape = (2, nblocks, bs, H, D) if layout == "NBHD" else (2, nblocks, H, bs, D)
+        src = [torch.zeros(shape, dtype=torch.bfloat16, device="cuda") for _ in range(nl)]
+        dst = [torch.zeros(shape, dtype=torch.bfloat16, device="cuda") for _ in range(nl)]
+        # every token of every segment gets its own random slot, in both caches (different permutations)
+        slots_src = torch.randperm(nblocks * bs, generator=g)[:ntot].to("cuda")
+        slots_dst = torch.randperm(nblocks * bs, generator=g)[:ntot].to("cuda")
+        segs = []
+        for i in range(nseg):
+            toks = generate_tokens(seg, "cuda")
+            kv = generate_kv_cache(seg, fmt, "cuda", num_layers=nl, num_heads=H, head_size=D)
+            sl = slice(i * seg, (i + 1) * seg)
+            _paged_scatter(src, kv, slots_src[sl], bs, layout)
+            engine.store_paged(toks, src, slots_src[sl], bs, layout)
+            segs.append((toks, kv, sl))
+        for toks, kv, sl in reversed(segs):  # any order: the segments are independent cache entries
+            m = engine.retrieve_into_paged(toks, dst, slots_dst[sl], bs, layout)
+            assert int(m.sum()) == seg  # the last, short chunk of a 600-token segment is a chunk too
+        torch.cuda.synchronize()
+        for i, (toks, kv, sl) in enumerate(segs):
+            got = _paged_gather(dst, slots_dst[sl], bs, layout)
+            dense, m = engine.retrieve(toks)
+            assert int(m.sum()) == seg
+            for (k, v), (k1, v1) in zip(got, dense):
+                assert torch.equal(k, k1) and torch.equal(v, v1)
+            if backend == "cuda":
+                check_kv_cache_equal(got, kv, seg, fmt)  # raw chunks: lossless
+            elif i in (0, nseg - 1):  # CacheGen chunks: bit-equal to the oracle's dequant(quant(x)), two chunks per checked segment
+                for t0 in (0, seg - cs):
+                    part = tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in kv)
+                    want = oracle_roundtrip(oracle, part, fmt, MODEL, torch.bfloat16)
+                    have = to_blob(tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in got)).cpu()
+                    assert torch.equal(have, want)
+        # nothing outside the requested slots was written
+        used = torch.zeros(nblocks * bs, dtype=torch.bool, device="cuda")
+        used[slots_dst] = True
+        free = (~used).nonzero().flatten()
+        for k, v in _paged_gather(dst, free, bs, layout):
+            assert not k.any() and not v.any()
+        # a suffix mask: only the tokens it marks are written (first-chunk trim of retrieve, cache_engine.py:360-365)
+        toks, kv, sl = segs[0]
+        for c in dst:
+            c.zero_()
+        mask = torch.ones(seg, dtype=torch.bool, device="cuda")
+        mask[:300] = False
+        m = engine.retrieve_into_paged(toks, dst, slots_dst[sl], bs, layout, mask=mask)
+        assert int(m.sum()) == seg - 300 and not m[:300].any()
+        got = _paged_gather(dst, slots_dst[sl], bs, layout)
+        dense, _ = engine.retrieve(toks)
+        for (k, v), (k1, v1) in zip(got, dense):
+            assert torch.equal(k[300:], k1[300:]) and not k[:300].any()
+            assert torch.equal(v[300:], v1[300:]) and not v[:300].any()
+    finally:
+        engine.close()
