@@ -1,28 +1,40 @@
 #!/usr/bin/env python
 """bench.py -- KV encode(+offload) throughput of the MI355X hot path.
 
-Metric (BASELINE.json): "KV encode+offload GB/s per GPU", GB = raw 16-bit KV
-bytes consumed.  Workload at N=1: BASELINE config 2 -- Llama-3-8B, bf16,
-16 384-token context (32 layers x 8 KV heads x 128, 2 GiB), chunk_size 256
-(64 chunks), synthetic KV already resident in HBM as the per-layer (K, V)
-tensors LMCacheEngine.store() receives.
+Metric (BASELINE.json): "KV encode+offload GB/s per GPU; warm-prefix TTFT vs cold", GB = raw 16-bit KV
+bytes consumed.  Workload at N=1: BASELINE configs[1] -- Llama-3-8B, bf16, 16 384-token context
+(32 layers x 8 KV heads x 128, 2 GiB), chunk_size 256 (64 chunks), synthetic KV already resident in HBM
+as the per-layer (K, V) tensors LMCacheEngine.store() receives.
 
-One "step" = one pass of the encode path over the whole context through the C
-ABI (lmc_encode_chunks): gather from the per-layer tensors, quantise, CDF,
-entropy-encode, compact into 64 blobs in an HBM arena.  `value` is that rate
-(inputs and outputs in HBM; PCIe never inside `value`).  The pinned-host
-offload leg (blobs D2H on a side stream, pipelined against the next step's
-kernels) and the decode leg are measured separately and reported in the
-`offload` / `decode` objects of the same JSON line.
+One "step" = one pass of the encode path over the whole context through the C ABI (lmc_encode_chunks):
+gather from the per-layer tensors, quantise, CDF, entropy-encode, compact into 64 blobs in an HBM arena.
+`value` is that rate (inputs and outputs in HBM; PCIe never inside `value`).  Everything else is measured
+outside the timed region, on rank 0, and reported as extra objects of the same JSON line:
 
-N>1 (torch.distributed, one rank per GPU): the path shards by chunk with no
-data-path collective, so every rank encodes its own
-16k-token context (weak scaling); the barrier and the max-over-ranks timing use
-RCCL, the data path does not.
+  roofline       HBM roof of the step (algorithmic bytes / HIP-event time) + the VALU-issue roof the coder sits under
+  offload        the product's store leg: encode + exact-size pinned hipMemcpyAsync D2H (PCIe-inclusive), >= 5 reps
+  retrieve       pinned host -> HBM -> decode (PCIe-inclusive), >= 5 reps
+  store_hidden   the metric's other half, part 1: a decode-step proxy (HBM read of a 16 GB weight buffer on the
+                 compute stream) alone vs with a non-blocking engine.store() of the 16k context in flight
+  ttft_proxy     part 2: (retrieve of the warm 16k prefix + one proxy step) / (one proxy step), target <= 1.05
+  decode         blobs in HBM -> decoded KV
+  seeds          the encode step on seeds 0..4 of the chosen --dist (min / median)
+  other_configs  the other BASELINE geometries (configs[0], [3], [4]) HBM-resident, one job each
+  cpu_baseline   the CPU oracle (C port) on a bounded sample + the reference's own torch formula on the host cores
+
+N>1 (torch.distributed, one rank per GPU): the path shards by chunk with no data-path collective
+(SURVEY.md section 8e), so every rank encodes its own 16k-token context (weak scaling); the barrier and the
+max-over-ranks timing use RCCL, the data path does not.  Every rank also runs the offload leg at the same
+time (its own PCIe link, NUMA-local pinned arena) and, for the sharing path (BASELINE configs[2]), one
+exchange step of encoded chunks through the xgmi:// connector.
+
+LMC_BENCH_STUB=1 rehearses the launch plumbing on CPU (gloo, the timed kernel replaced by a sleep): that is how
+tests/test_distributed_cpu.py runs this file with two ranks.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -36,11 +48,10 @@ if ROOT not in sys.path:
 MODEL = "meta-llama/Llama-3.1-8B-Instruct"
 L, H, D = 32, 8, 128
 CTX, CHUNK = 16384, 256
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per step from the PMC passes committed under profiles/ (see profiles/r01_*_pmc.md): updated by hand
-# whenever the kernels' data flow changes; None until measured.
-TRAFFIC_BYTES_PER_STEP = 4_561_000_000  # profiles/r01_f_pmc.md
-VALU_BUSY_DOMINANT = 1.0                 # k_cdf_encode: SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles), profiles/r01_f_pmc.md
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_GIPS = 614.4    # wave-instructions/s the chip can issue: 1024 SIMDs x 2.4 GHz / 4 cycles (same guide)
+PROXY_BYTES = 16 * (1 << 30)  # one Llama-3-8B decode step streams ~16 GB of bf16 weights
+STUB = os.environ.get("LMC_BENCH_STUB") == "1"
 
 
 def cachegen_bins_llama8b():
@@ -50,21 +61,46 @@ def cachegen_bins_llama8b():
     return kb + vb
 
 
-def make_kv(dev, seed):
-    """Synthetic KV of the named shape: uniform [0,1) like the reference's own
-    tests (tests/test_serde.py:20-21), generated on the GPU per layer."""
+def make_kv(dev, seed, dist="rand", nl=L, ntok=CTX, nh=H, hd=D, dtype=torch.bfloat16):
+    """Synthetic KV of the named shape, generated on the GPU per layer:
+    rand    uniform [0,1) like the reference's own tests (tests/test_serde.py:20-21)
+    randn   standard normal
+    outlier randn x a per-channel log-normal scale (a few loud channels, as real KV has)"""
     g = torch.Generator(device=dev).manual_seed(seed)
     kv = []
-    for _ in range(L):
-        k = torch.rand((CTX, H, D), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
-        v = torch.rand((CTX, H, D), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
-        kv.append((k, v))
+    for _ in range(nl):
+        pair = []
+        for _ in range(2):
+            if dist == "rand":
+                x = torch.rand((ntok, nh, hd), generator=g, device=dev, dtype=torch.float32)
+            else:
+                x = torch.randn((ntok, nh, hd), generator=g, device=dev, dtype=torch.float32)
+                if dist == "outlier":
+                    x = x * torch.exp(1.5 * torch.randn((1, nh, hd), generator=g, device=dev, dtype=torch.float32))
+            pair.append(x.to(dtype))
+        kv.append(tuple(pair))
     return tuple(kv)
 
 
+def median(xs):
+    return float(statistics.median(xs))
+
+
+def load_latest_profile():
+    """profiles/latest.json (written by tools/rocpd_stats.py --json from the committed rocprofv3 passes): HBM
+    bytes and VALU instructions per encode step.  None when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest.json")) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------- CPU baselines
 def cpu_baseline(nchunks_sample):
-    """The CPU oracle (port of the reference's quantise + CDF + our entropy coder)
-    timed on the host cores over a bounded sample of the same workload."""
+    """The CPU oracle (port of the reference's quantise + CDF + our entropy coder) timed on the host cores over a
+    bounded sample of the same workload, and beside it the reference's own formula (torch_quant_vectorized +
+    do_dequantize, cachegen_encoder.py:40-61 / cachegen_decoder.py:24-35) as CPU torch ops."""
     from oracle import lmc_oracle as orc
     orc.build()
     ncores = len(os.sched_getaffinity(0))
@@ -83,22 +119,145 @@ def cpu_baseline(nchunks_sample):
         list(pool.map(lambda _: orc.encode_blob(bits, code, H, D, bins), range(nchunks_sample)))
     dt = time.perf_counter() - t0
     raw = kv.numel() * 2 * nchunks_sample
-    return {"value": round(raw / dt / 1e9, 4), "unit": "GB/s", "cores": ncores, "kind": "port",
-            "sample": f"{nchunks_sample} chunks of 256 tokens (Llama-3-8B shape, {raw / 1e6:.0f} MB raw KV), "
-                      f"oracle/lmc_oracle.c lmco_encode_blob, {workers} chunks at a time x OpenMP over planes/groups"}
+    out = {"value": round(raw / dt / 1e9, 4), "unit": "GB/s", "cores": ncores, "kind": "port",
+           "sample": f"{nchunks_sample} chunks of 256 tokens (Llama-3-8B shape, {raw / 1e6:.0f} MB raw KV), "
+                     f"oracle/lmc_oracle.c lmco_encode_blob, {workers} chunks at a time x OpenMP over planes/groups"}
+    out["reference_formula"] = cpu_reference_formula(kv)
+    return out
 
 
-def main():
+def cpu_reference_formula(kv_chunk):
+    """torch_quant_vectorized (per token absmax, x * (MAX / max) + MAX, round, int8) followed by do_dequantize
+    (((q - MAX) / MAX) * max) and the bf16 cast, restated line for line as CPU torch ops on one chunk
+    [L,2,T,C], with 1 thread and with every host core."""
+    bins = cachegen_bins_llama8b()
+    x = kv_chunk  # bf16 [L,2,T,C]
+    raw = x.numel() * 2
+
+    def once():
+        outs = []
+        for kvi in range(2):
+            for l in range(L):
+                t = x[l, kvi]                                  # [T, C] bf16
+                MAX = bins[kvi * L + l] // 2 - 1
+                max1 = torch.amax(torch.abs(t), dim=-1, keepdim=True)
+                q = torch.round(t * (MAX / max1) + MAX).to(torch.int8)
+                d = ((q.float() - MAX) / MAX) * max1.float()
+                outs.append(d.to(torch.bfloat16))
+        return outs
+
+    res = {}
+    ncores = len(os.sched_getaffinity(0))
+    # torch's intra-op pool on [256 x 1024] tensors stops scaling long before 256 threads (it gets slower): the
+    # "all cores" leg uses at most 64 of them
+    nthreads_all = min(ncores, 64)
+    before = torch.get_num_threads()
+    for label, nt in (("threads_1", 1), ("threads_all", nthreads_all)):
+        torch.set_num_threads(nt)
+        once()
+        reps, t0 = 0, time.perf_counter()
+        while reps < 5 and time.perf_counter() - t0 < 5.0:  # bounded: a few seconds per leg
+            once()
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        res[label + "_GBps"] = round(raw / dt / 1e9, 3)
+    torch.set_num_threads(before)
+    res["threads_all"] = nthreads_all
+    res["sample"] = "one 256-token Llama-3-8B chunk (33.5 MB raw KV): quantise + dequantise + bf16 cast, no entropy coding"
+    return res
+
+
+# ---------------------------------------------------------------------------------------------- helpers (GPU)
+class DecodeStepProxy:
+    """What a decode step does to the memory system: one pass over ~16 GB of bf16 weights on the compute stream, as 32
+    GEMVs of [16384 x 16384] (one per "layer"; batch-1 decode is exactly weight streaming) -- an HBM-bound read, no
+    vLLM in this image.  step() enqueues one pass."""
+
+    def __init__(self, dev):
+        n = 16384
+        self.w = torch.empty((32, n, n), dtype=torch.bfloat16, device=dev)
+        self.w.zero_()
+        self.x = torch.ones(n, dtype=torch.bfloat16, device=dev)
+        self.y = torch.empty(n, dtype=torch.bfloat16, device=dev)
+
+    def step(self):
+        for l in range(32):
+            torch.mv(self.w[l], self.x, out=self.y)
+
+    def time_steps(self, n):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        evs[0].record()
+        for i in range(n):
+            self.step()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        return [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+
+
+def time_encode(ctx, layout, ntok, chunk, bins, blobs, stride, sizes, sp, stream, reps):
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    for _ in range(reps):
+        ctx.encode_chunks(layout, 0, ntok, chunk, bins, blobs.data_ptr(), stride, sizes.data_ptr(), stream=sp)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps
+
+
+def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=False):
+    """Encode / decode rate of another geometry (HBM-resident, one job)."""
+    from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
+    cs = 256
+    kv = make_kv(dev, 0, "rand", nl, ntok, nh, hd, dtype)
+    lay = native.KVLayout.from_kv_tuple(kv, "vllm")
+    bins = CacheGenConfig.from_model_name(model).plane_bins(nl)
+    n = (ntok + cs - 1) // cs
+    stride = native.r16(native.blob_bound(nl, cs, nh, hd))
+    blobs = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    sizes = torch.zeros(n, dtype=torch.int32, device=dev)
+    raw = nl * 2 * ntok * nh * hd * 2
+    st = torch.cuda.current_stream(dev)
+    time_encode(ctx, lay, ntok, cs, bins, blobs, stride, sizes, st.cuda_stream, st, 1)
+    ctx.raise_on_status(name)
+    tenc = time_encode(ctx, lay, ntok, cs, bins, blobs, stride, sizes, st.cuda_stream, st, 5)
+    if paged:  # decode + scatter into a paged cache at random, non-contiguous slots (north-star NHBD layout)
+        bs = 16
+        nblocks = (ntok + bs - 1) // bs + 5
+        caches = [torch.zeros((2, nblocks, nh, bs, hd), dtype=dtype, device=dev) for _ in range(nl)]
+        slots = torch.randperm(nblocks * bs, device=dev)[:ntok]
+        ol = native.KVLayout.paged(caches, slots, bs, "NHBD")
+    else:
+        out = tuple((torch.empty_like(k), torch.empty_like(v)) for k, v in kv)
+        ol = native.KVLayout.from_kv_tuple(out, "vllm")
+    ctx.decode_chunks(blobs.data_ptr(), stride, n, ol, 0, cs)
+    torch.cuda.synchronize()
+    ctx.raise_on_status(name)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ctx.decode_chunks(blobs.data_ptr(), stride, n, ol, 0, cs)
+    e1.record()
+    torch.cuda.synchronize()
+    tdec = e0.elapsed_time(e1) / 5
+    return {"workload": name, "raw_kv_MB": round(raw / 1e6, 1), "chunks": n,
+            "encode_ms": round(tenc, 3), "encode_GBps_raw": round(raw / tenc / 1e6, 1),
+            "decode_ms": round(tdec, 3), "decode_GBps_raw": round(raw / tdec / 1e6, 1),
+            "compression": round(raw / int(sizes.sum()), 3)}
+
+
+# ---------------------------------------------------------------------------------------------- main
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dist", choices=["rand", "randn", "outlier"], default="rand",
+                    help="synthetic KV distribution of the timed workload (SURVEY.md section 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region and the roofline")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the cpu_baseline sample (0 = auto)")
-    ap.add_argument("--exchange", action="store_true",
-                    help="N>1 only, opt-in: time one RCCL/xGMI exchange step of the encoded chunks between ranks "
-                         "(XgmiShardStore; outside the timed region, reported as `exchange`)")
-    args = ap.parse_args()
+    ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the xgmi:// exchange leg")
+    args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,111 +265,121 @@ def main():
     # LMC_BENCH_FORCE_DIST=1 runs the process-group code path with a single rank too (a 1-GPU box can then
     # exercise init / barrier / all_reduce / teardown exactly as the multi-GPU launch does)
     use_dist = world > 1 or os.environ.get("LMC_BENCH_FORCE_DIST") == "1"
+    import torch.distributed as dist
+    from lmcache_amd.distributed import bind_to_gpu_numa, max_over_ranks, sum_over_ranks
     if use_dist:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if STUB:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
-
-    from lmcache_amd import native
-    ctx = native.get_context(local_rank)
-    bins = cachegen_bins_llama8b()
-    kv = make_kv(dev, seed=rank)
-    layout = native.KVLayout.from_kv_tuple(kv, "vllm")
-    nchunks = CTX // CHUNK
-    stride = native.r16(native.blob_bound(L, CHUNK, H, D))
-    blobs = torch.empty(nchunks * stride, dtype=torch.uint8, device=dev)
-    sizes = torch.zeros(nchunks, dtype=torch.int32, device=dev)
-    ctx.reserve(L, H, D, CHUNK, nchunks)
+    numa = None
+    cpus_before = os.sched_getaffinity(0)
+    if not STUB:
+        torch.cuda.set_device(local_rank)
+        # pinned arenas are first-touched by this process: run it on the NUMA node of its GPU (N>1: every rank its own)
+        numa = bind_to_gpu_numa(local_rank)
+    dev = torch.device("cpu") if STUB else torch.device(f"cuda:{local_rank}")
     raw_bytes = L * 2 * CTX * H * D * 2
+    nchunks = CTX // CHUNK
 
-    stream = torch.cuda.Stream(device=dev)
-    sp = stream.cuda_stream
-
-    def step():
-        ctx.encode_chunks(layout, 0, CTX, CHUNK, bins, blobs.data_ptr(), stride, sizes.data_ptr(), stream=sp)
+    def sync():
+        if not STUB:
+            torch.cuda.synchronize()
 
     def barrier():
         if use_dist:
-            import torch.distributed as dist
             dist.barrier()
+
+    if STUB:
+        def step():
+            time.sleep(0.002)
+        ctx = None
+    else:
+        from lmcache_amd import native
+        ctx = native.get_context(local_rank)
+        bins = cachegen_bins_llama8b()
+        kv = make_kv(dev, rank, args.dist)
+        layout = native.KVLayout.from_kv_tuple(kv, "vllm")
+        stride = native.r16(native.blob_bound(L, CHUNK, H, D))
+        blobs = torch.empty(nchunks * stride, dtype=torch.uint8, device=dev)
+        sizes = torch.zeros(nchunks, dtype=torch.int32, device=dev)
+        ctx.reserve(L, H, D, CHUNK, nchunks)
+        stream = torch.cuda.Stream(device=dev)
+        sp = stream.cuda_stream
+
+        def step():
+            ctx.encode_chunks(layout, 0, CTX, CHUNK, bins, blobs.data_ptr(), stride, sizes.data_ptr(), stream=sp)
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    ctx.raise_on_status("bench warmup")
+    sync()
+    if ctx is not None:
+        ctx.raise_on_status("bench warmup")
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ----
     barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    if not STUB:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
+    if not STUB:
+        ev0.record(stream)
     for _ in range(args.steps):
         step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
+    if not STUB:
+        ev1.record(stream)
+    sync()
     elapsed = time.perf_counter() - t0
-    gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
     barrier()
-    ctx.raise_on_status("bench")
-    if use_dist:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    gpu_ms_per_step = elapsed * 1e3 / args.steps if STUB else ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
+    if ctx is not None:
+        ctx.raise_on_status("bench")
+    elapsed = max_over_ranks(elapsed, dev)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * raw_bytes * args.steps / elapsed / 1e9
 
-    # ---- optional: one exchange step of the encoded chunks over RCCL/xGMI (row f1; outside the timed region) ----
-    exchange = None
-    if args.exchange and use_dist:
-        import torch.distributed as dist
-        from lmcache_amd.storage_backend.connector.xgmi_exchange import XgmiShardStore
-        szs = sizes.cpu().tolist()
-        store = XgmiShardStore()
-        items = [(f"bench@{world}@{rank}@{i:04x}", blobs[i * stride:i * stride + szs[i]]) for i in range(nchunks)]
-        torch.cuda.synchronize(); dist.barrier()
-        t0 = time.perf_counter()
-        store.exchange_put(items)
-        torch.cuda.synchronize(); dist.barrier()
-        t_put = time.perf_counter() - t0
-        peer = (rank + 1) % world
-        want = [f"bench@{world}@{peer}@{i:04x}" for i in range(nchunks)]
-        t0 = time.perf_counter()
-        got = store.exchange_get(want)
-        torch.cuda.synchronize(); dist.barrier()
-        t_get = time.perf_counter() - t0
-        nbytes = torch.tensor([float(sum(szs))], device=dev, dtype=torch.float64)
-        dist.all_reduce(nbytes)
-        ok = all(g is not None for g in got)
-        exchange = {"put_GBps_blob_all_ranks": round(float(nbytes.item()) / t_put / 1e9, 1),
-                    "get_GBps_blob_all_ranks": round(float(nbytes.item()) / t_get / 1e9, 1),
-                    "put_ms": round(t_put * 1e3, 2), "get_ms": round(t_get * 1e3, 2), "all_hits": ok,
-                    "note": "one batch_isend_irecv per call; includes the all_gather_object control round trips"}
+    # ---- N>1: every rank's own offload leg at the same time (its PCIe link, its NUMA-local arena), and one
+    # exchange step of encoded chunks through the xgmi:// connector (BASELINE configs[2]); outside the timed region
+    offload_all = exchange = None
+    if use_dist and not STUB and not args.no_extras:
+        offload_all = all_ranks_offload(ctx, layout, bins, dev, local_rank, world)
+        if not args.no_exchange:
+            exchange = exchange_leg(blobs, sizes, stride, nchunks, rank, world, dev)
 
     if rank != 0:
         if use_dist:
-            import torch.distributed as dist
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
+            dist.destroy_process_group()
+        return
+
+    res = {"metric": "KV encode+offload GB/s per GPU (raw 16-bit KV bytes consumed; encode into HBM blobs)",
+           "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16->u8 symbols (fp32 quantise, u32 rANS)", "data": f"synthetic ({args.dist})",
+           "config": {"workload": "Llama-3-8B bf16 KV, 16384-token context, CacheGen encode, chunk_size=256 "
+                                  "(BASELINE configs[1])",
+                      "layers": L, "kv_heads": H, "head_dim": D, "context_tokens": CTX, "chunk_tokens": CHUNK,
+                      "chunks": nchunks, "raw_kv_bytes": raw_bytes, "sharding": f"{world} x independent contexts",
+                      "numa_node": numa}}
+    if STUB:
+        res["data"] = "stub (CPU rehearsal of the launch plumbing, no kernel ran)"
+        print(json.dumps(res))
+        if use_dist:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
     # ---- rank 0 extras (outside the timed region) -------------------------------
+    from lmcache_amd import native
     sz = sizes.cpu().numpy().astype(np.int64)
     blob_bytes = int(sz.sum())
-    P, C = 2 * L, H * D
-    G = (C + 63) // 64
-    # algorithmic bytes per step, SURVEY.md 8(d): B_enc = P*T*C*e + S + P*C*66 + P*C*4 + P*T*2 per chunk,
-    # with OUR container: lengths are one u32 per 64-channel group (P*G*4) instead of per channel
-    static = native.blob_static_bytes(L, CHUNK, H, D, bins)
-    S = blob_bytes - nchunks * static
+    # algorithmic bytes per step (with OUR container): raw KV read once + blobs written once
     algo_bytes = raw_bytes + blob_bytes
 
     # per-kernel HIP-event timing on the launch stream (lmc_ctx_profile)
@@ -225,27 +394,119 @@ def main():
     ctx.profile(False)
     kms = ksum / reps
     achieved = algo_bytes / (gpu_ms_per_step / 1e3) / 1e9
-    serial = algo_bytes / (float(kms.sum()) / 1e3) / 1e9
+    prof = load_latest_profile() or {}
+    valu_insts = prof.get("valu_insts_per_step")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": TRAFFIC_BYTES_PER_STEP,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": prof.get("traffic_bytes_per_step"),
                 "kernel": knames[int(np.argmax(kms))],
                 "gpu_ms_per_step": round(gpu_ms_per_step, 4),
                 "kernels_ms_serial": {n: round(float(v), 4) for n, v in zip(knames, kms)},
-                "achieved_serial": round(serial, 1),
                 "algorithmic_bytes_per_step": int(algo_bytes),
-                # from the SQ PMC pass committed under profiles/ (not measured live): the dominant kernel is an
-                # integer entropy coder and sits under the VALU-issue roof, not the HBM one
-                "valu_busy_dominant_kernel": VALU_BUSY_DOMINANT,
+                # the dominant kernel is an integer entropy coder: the roof it sits under is VALU issue, not HBM
+                "valu": None if not valu_insts else {
+                    "bound": "valu", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GIPS,
+                    "achieved": round(valu_insts / (gpu_ms_per_step / 1e3) / 1e9, 1),
+                    "frac": round(valu_insts / (gpu_ms_per_step / 1e3) / 1e9 / VALU_PEAK_GIPS, 4),
+                    "valu_insts_per_step": valu_insts,
+                    "valu_busy_dominant_kernel": prof.get("valu_busy_dominant_kernel")},
+                "profile_source": prof.get("source"),
                 "note": "achieved = (raw KV read once + blob written once) per step / HIP-event time of one step "
                         "(the whole encode job: k_quantize + k_cdf_encode) on the launch stream over the timed region; "
-                        "kernels_ms_serial = per-kernel HIP events of one job (lmc_ctx_profile); traffic = HBM bytes per "
-                        "step from rocprofv3 FETCH_SIZE/WRITE_SIZE (profiles/), FETCH_SIZE doubled for the 16-B/lane "
-                        "streams per MI355X_MICROARCH.md"}
+                        "kernels_ms_serial = per-kernel HIP events of one job (lmc_ctx_profile); traffic and the VALU "
+                        "instruction count come from the rocprofv3 PMC passes summarised in profiles/latest.json "
+                        "(FETCH_SIZE doubled for the 16-B/lane streams per MI355X_MICROARCH.md)"}
+    res["roofline"] = roofline
 
-    # store leg as the product runs it (LMCLocalBackend, local_serde="cachegen"): fused encode on the compute
-    # stream, blob sizes read back through a pinned word, exact-size hipMemcpyAsync of every blob to pinned host
-    # DRAM on the side stream.  PCIe-inclusive, so never `value`.
+    if not args.no_extras:
+        extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, stream, sp, raw_bytes, blob_bytes,
+               algo_bytes, gpu_ms_per_step)
+    if offload_all is not None:
+        res["offload_all_ranks"] = offload_all
+    if exchange is not None:
+        res["exchange"] = exchange
+    if not args.no_cpu_baseline:
+        os.sched_setaffinity(0, cpus_before)  # the CPU baseline gets every host core, not only the GPU's NUMA node
+        res["cpu_baseline"] = cpu_baseline(args.cpu_chunks or 128)
+    print(json.dumps(res))
+    if use_dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+
+
+def all_ranks_offload(ctx, layout, bins, dev, local_rank, world):
+    """Every rank stores its context to ITS pinned arena at the same time: what the host side (PCIe links, DRAM
+    channels) sustains when all GPUs of the node offload together."""
+    import torch.distributed as dist
+    from lmcache_amd.distributed import max_over_ranks, sum_over_ranks
     from lmcache_amd.storage_backend.serde.cachegen_device import PinnedArena, get_codec
+    codec = get_codec(local_rank)
+    arena = PinnedArena(slab_bytes=640 << 20)
+
+    def once():
+        arena.reset()
+        job = codec.encode(layout, 0, CTX, CHUNK, bins)
+        hblobs, done = codec.offload(job, None, arena)
+        done.synchronize()
+        return sum(b.nbytes for b in hblobs)
+
+    once()
+    dist.barrier()
+    t0 = time.perf_counter()
+    nbytes = 0
+    for _ in range(3):
+        nbytes = once()
+    dt = (time.perf_counter() - t0) / 3
+    dt = max_over_ranks(dt, dev)
+    tot = sum_over_ranks(float(nbytes), dev)
+    arena.close()
+    return {"pcie_GBps_blob_all_ranks": round(tot / dt / 1e9, 1), "ms_per_context_max": round(dt * 1e3, 3),
+            "raw_kv_GBps_all_ranks": round(world * L * 2 * CTX * H * D * 2 / dt / 1e9, 1),
+            "note": "all ranks store their 16k context to their own NUMA-local pinned arena concurrently"}
+
+
+def exchange_leg(blobs, sizes, stride, nchunks, rank, world, dev):
+    """One exchange of encoded chunks between the ranks through the xgmi:// connector: every rank publishes its 64
+    chunks (blobs land in the HBM arena of the key's owner rank, a peer write over xGMI), then fetches the next
+    rank's chunks (peer reads)."""
+    import torch.distributed as dist
+    from lmcache_amd.distributed import max_over_ranks, sum_over_ranks
+    from lmcache_amd.storage_backend.connector import CreateConnector
+    try:
+        conn = CreateConnector(f"xgmi://bench{os.environ.get('MASTER_PORT', '0')}:{world}")
+        szs = sizes.cpu().tolist()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(nchunks):
+            conn.set_device(f"bench@{world}@{rank}@{i:04x}", blobs[i * stride:i * stride + szs[i]])
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_put = max_over_ranks(time.perf_counter() - t0, dev)
+        peer = (rank + 1) % world
+        t0 = time.perf_counter()
+        got = [conn.get_device(f"bench@{world}@{peer}@{i:04x}") for i in range(nchunks)]
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_get = max_over_ranks(time.perf_counter() - t0, dev)
+        ok = all(g is not None for g in got)
+        tot = sum_over_ranks(float(sum(szs)), dev)
+        conn.close()
+        return {"put_GBps_blob_all_ranks": round(tot / t_put / 1e9, 1), "get_GBps_blob_all_ranks": round(tot / t_get / 1e9, 1),
+                "put_ms": round(t_put * 1e3, 2), "get_ms": round(t_get * 1e3, 2), "all_hits": ok,
+                "note": "xgmi:// connector: blobs resident in the owner rank's HBM arena, peer copies over xGMI"}
+    except Exception as e:  # informational leg
+        return {"error": repr(e)}
+
+
+def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, stream, sp, raw_bytes, blob_bytes,
+           algo_bytes, gpu_ms_per_step):
+    from lmcache_amd.cache_engine import LMCacheEngine
+    from lmcache_amd.config import LMCacheEngineConfig, LMCacheEngineMetadata
+    from lmcache_amd.storage_backend.serde.cachegen_device import PinnedArena, get_codec
+    nchunks = CTX // CHUNK
+    local_rank = dev.index
+
+    # ---- store / retrieve legs as the product runs them (PCIe-inclusive, never `value`) --------------------
     offload = retrieve = None
     try:
         codec = get_codec(local_rank)
@@ -260,76 +521,180 @@ def main():
                 return hblobs
 
             hblobs = store_once()  # warm: first touch of the pinned slab
-            t0 = time.perf_counter()
-            for _ in range(3):
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
                 hblobs = store_once()
-            dt = (time.perf_counter() - t0) / 3
+                ts.append(time.perf_counter() - t0)
+            dt = median(ts)
+            # the D2H of the same blobs alone (already encoded): what PCIe takes by itself
+            szl = sizes.cpu().tolist()
+            td = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for i in range(nchunks):
+                    native.memcpy_async(hblobs[i].ptr, blobs.data_ptr() + i * stride, szl[i], "d2h",
+                                        (codec.copy_stream if i % 2 == 0 else codec.copy_stream2).cuda_stream)
+                codec.copy_stream.synchronize()
+                codec.copy_stream2.synchronize()
+                td.append(time.perf_counter() - t0)
+            d2h = median(td)
+            enc = gpu_ms_per_step / 1e3
+            overlap = (enc + d2h - dt) / min(enc, d2h) * 100.0
             offload = {"encode_plus_offload_GBps_raw_kv": round(raw_bytes / dt / 1e9, 1),
                        "pcie_GBps_blob": round(blob_bytes / dt / 1e9, 1), "ms_per_context": round(dt * 1e3, 3),
+                       "d2h_alone_ms": round(d2h * 1e3, 3), "encode_alone_ms": round(enc * 1e3, 3),
+                       "overlap_pct": round(max(0.0, min(100.0, overlap)), 1), "reps": 5,
                        "blob_bytes": blob_bytes, "compression": round(raw_bytes / blob_bytes, 3),
-                       "note": "PCIe-inclusive (pinned slab pre-allocated, as in a running backend); not `value`"}
+                       "note": "median of 5; PCIe-inclusive (pinned slab pre-allocated, as in a running backend); not "
+                               "`value`.  overlap_pct = share of the shorter leg (encode) hidden behind the longer (D2H)"}
             # warm-prefix retrieve: pinned host -> HBM on the side stream, decode straight into per-layer tensors,
             # H2D of batch b+1 overlapping the decode of batch b
             out_r = tuple((torch.empty_like(k), torch.empty_like(v)) for k, v in kv)
             out_rl = native.KVLayout.from_kv_tuple(out_r, "vllm")
-            codec.decode(hblobs, out_rl, 0, CHUNK)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            codec.decode(hblobs, out_rl, 0, CHUNK)
-            torch.cuda.current_stream().synchronize()
-            dt = time.perf_counter() - t0
-            ctx.raise_on_status("bench retrieve")
+            codec.finish_decode(codec.decode(hblobs, out_rl, 0, CHUNK))
+            tr = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                codec.finish_decode(codec.decode(hblobs, out_rl, 0, CHUNK))
+                tr.append(time.perf_counter() - t0)
+            dt = median(tr)
             retrieve = {"host_to_decoded_kv_GBps_raw": round(raw_bytes / dt / 1e9, 1), "ms_per_context": round(dt * 1e3, 3),
-                        "pcie_GBps_blob": round(blob_bytes / dt / 1e9, 1),
+                        "pcie_GBps_blob": round(blob_bytes / dt / 1e9, 1), "reps": 5,
                         "raw_h2d_would_take_ms": round(raw_bytes / (blob_bytes / dt) * 1e3, 1),
-                        "note": "warm 16k prefix: encoded chunks in pinned host DRAM -> decoded KV in HBM (PCIe-inclusive)"}
+                        "note": "median of 5; warm 16k prefix: encoded chunks in pinned host DRAM -> decoded KV in HBM "
+                                "(PCIe-inclusive; the decode kernel is hidden behind the H2D)"}
             del out_r
             arena.close()
     except Exception as e:  # these legs are informational
         offload = offload or {"error": repr(e)}
         retrieve = retrieve or {"error": repr(e)}
+    res["offload"], res["retrieve"] = offload, retrieve
 
-    # decode leg (retrieve): blobs in HBM -> decoded KV written straight into per-layer tensors
+    # ---- decode leg: blobs in HBM -> decoded KV written straight into per-layer tensors ----------------------
     out = tuple((torch.empty_like(k), torch.empty_like(v)) for k, v in kv)
     out_layout = native.KVLayout.from_kv_tuple(out, "vllm")
     ctx.decode_chunks(blobs.data_ptr(), stride, nchunks, out_layout, 0, CHUNK, stream=sp)
     torch.cuda.synchronize()
     ctx.raise_on_status("bench decode")
     ctx.profile(True)
-    dsum = 0.0
+    ds = []
     for _ in range(5):
         ctx.decode_chunks(blobs.data_ptr(), stride, nchunks, out_layout, 0, CHUNK, stream=sp)
         torch.cuda.synchronize()
-        dsum += ctx.profile_read()[0]
+        ds.append(ctx.profile_read()[0])
     ctx.profile(False)
-    dms = dsum / 5
-    decode = {"GBps_raw_kv": round(raw_bytes / (dms / 1e3) / 1e9, 1), "ms_per_context": round(dms, 3),
-              "roofline_frac": round(algo_bytes / (dms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
+    dms = median(ds)
+    res["decode"] = {"GBps_raw_kv": round(raw_bytes / (dms / 1e3) / 1e9, 1), "ms_per_context": round(dms, 3),
+                     "roofline_frac": round(algo_bytes / (dms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
     # size-independent property at full size: decode(encode(x)) reproduces x within the quantisation bound
     k0, o0 = kv[0][0].float(), out[0][0].float()
     mx = k0.abs().amax(dim=(1, 2), keepdim=True)
-    err_ok = bool(((o0 - k0).abs() <= mx / (2 * 15) + mx * 2.0 ** -7).all())
+    res["roundtrip_within_bound"] = bool(((o0 - k0).abs() <= mx / (2 * 15) + mx * 2.0 ** -7).all())
+    del out, k0, o0
 
-    res = {"metric": "KV encode+offload GB/s per GPU (raw 16-bit KV bytes consumed; encode into HBM blobs)",
-           "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16->u8 symbols (fp32 quantise, u32 rANS)", "data": "synthetic",
-           "config": {"workload": "Llama-3-8B bf16 KV, 16384-token context, CacheGen encode, chunk_size=256 "
-                                  "(BASELINE configs[1])",
-                      "layers": L, "kv_heads": H, "head_dim": D, "context_tokens": CTX, "chunk_tokens": CHUNK,
-                      "chunks": nchunks, "raw_kv_bytes": raw_bytes, "sharding": f"{world} x independent contexts"},
-           "roofline": roofline, "offload": offload, "retrieve": retrieve, "decode": decode, "roundtrip_within_bound": err_ok}
-    if exchange is not None:
-        res["exchange"] = exchange
-    if not args.no_cpu_baseline:
-        n = args.cpu_chunks or 128
-        res["cpu_baseline"] = cpu_baseline(n)
-    print(json.dumps(res))
-    if use_dist:
-        import torch.distributed as dist
-        dist.barrier()
+    # ---- the metric's other half: store hidden behind decode, warm-prefix TTFT (BASELINE.json north_star) -------
+    try:
+        res.update(overlap_legs(dev, kv, raw_bytes))
+    except Exception as e:
+        res["store_hidden"] = {"error": repr(e)}
+
+    # ---- the encode step on seeds 0..4 of the chosen distribution -------------------------------------------
+    per_seed = []
+    for s in range(5):
+        kvs = make_kv(dev, s, args.dist)
+        ls = native.KVLayout.from_kv_tuple(kvs, "vllm")
+        time_encode(ctx, ls, CTX, CHUNK, bins, blobs, stride, sizes, sp, stream, 1)
+        per_seed.append(round(time_encode(ctx, ls, CTX, CHUNK, bins, blobs, stride, sizes, sp, stream, 5), 4))
+        del kvs, ls
+    ctx.raise_on_status("bench seeds")
+    res["seeds"] = {"dist": args.dist, "ms_per_step": per_seed, "min": min(per_seed), "median": median(per_seed),
+                    "GBps_raw_median": round(raw_bytes / median(per_seed) / 1e6, 1)}
+
+    # ---- the other BASELINE geometries, HBM-resident --------------------------------------------------------
+    try:
+        others = [shape_rate(native, ctx, dev, "configs[0] shape: fp16 [32 L, 32 H, 4096 tok, 128 hd] (C = 4096)",
+                             32, 32, 128, torch.float16, 4096, "mistralai/Mistral-7B-Instruct-v0.2"),
+                  shape_rate(native, ctx, dev, "configs[3] rank shape: Llama-3-70B TP=8, 32k context (80 L, C = 128)",
+                             80, 1, 128, torch.bfloat16, 32768, "Llama-3-70B"),
+                  shape_rate(native, ctx, dev, "configs[4]: Mistral-7B, 8 x 2048 tokens, decode + scatter into paged "
+                                               "NHBD blocks at random slots", 32, 8, 128, torch.bfloat16, 16384,
+                             "mistralai/Mistral-7B-Instruct-v0.2", paged=True)]
+    except Exception as e:
+        others = [{"error": repr(e)}]
+    res["other_configs"] = others
+
+
+def overlap_legs(dev, kv, raw_bytes):
+    """store_hidden and ttft_proxy through LMCacheEngine (local_device="cpu", local_serde="cachegen": encoded chunks
+    in pinned host DRAM).  The model's decode step is a proxy: an HBM-bound pass over 16 GB on the compute stream;
+    store() is issued on a side stream as the vLLM connector does (LLM_Engine.rst:91)."""
+    from lmcache_amd.cache_engine import LMCacheEngine
+    from lmcache_amd.config import LMCacheEngineConfig, LMCacheEngineMetadata
+    cfg = LMCacheEngineConfig.from_legacy(chunk_size=CHUNK, backend="cpu", local_serde="cachegen")
+    meta = LMCacheEngineMetadata(MODEL, 1, 0, "vllm", "bfloat16")
+    proxy = DecodeStepProxy(dev)
+    proxy.time_steps(3)
+    alone = median(proxy.time_steps(10))
+    side = torch.cuda.Stream(device=dev)
+    hidden, store_ms = [], []
+    reps = 5
+    g = torch.Generator().manual_seed(1)
+    engine = LMCacheEngine(cfg, meta)
+    engine.engine_.host_arena.reserve((reps + 1) * (640 << 20))   # a backend sized for its working set
+    for r in range(reps):
+        toks = torch.randint(0, 32000, (CTX,), generator=g)
+        last_key = engine._make_key(engine._prefix_hash(engine._chunk_tokens(toks))[-1], "vllm")
         torch.cuda.synchronize()
-        dist.destroy_process_group()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(side):
+            engine.store(toks, kv, skip_existing=False, blocking=False)
+        t_call = time.perf_counter() - t0
+        steps = []
+        done_at = None
+        while done_at is None and len(steps) < 32:   # decode steps run while the store is in flight
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            proxy.step()
+            e1.record()
+            e1.synchronize()
+            steps.append(e0.elapsed_time(e1))
+            if engine.engine_.contains(last_key):
+                done_at = time.perf_counter() - t0
+        while done_at is None:
+            time.sleep(0.0005)
+            if engine.engine_.contains(last_key):
+                done_at = time.perf_counter() - t0
+        hidden.append(median(steps))
+        store_ms.append(done_at * 1e3)
+        last_toks = toks
+    store_hidden = {"proxy_step_ms_alone": round(alone, 3), "proxy_step_ms_during_store": round(median(hidden), 3),
+                    "ratio": round(median(hidden) / alone, 4), "target": "<= 1.05",
+                    "store_completion_ms": round(median(store_ms), 3), "store_call_returns_after_ms": round(t_call * 1e3, 3),
+                    "reps": reps,
+                    "note": "median over 5 non-blocking engine.store() of the 16k context (side stream): proxy decode steps "
+                            "(16 GB HBM read each) that ran while encode + pinned offload were in flight vs alone"}
+    # warm-prefix TTFT proxy: retrieve the 16k prefix (pinned host -> HBM -> decode), then one decode step
+    ttft = []
+    for r in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ret, mask = engine.retrieve(last_toks)
+        proxy.step()
+        torch.cuda.synchronize()
+        ttft.append((time.perf_counter() - t0) * 1e3)
+        assert int(mask.sum()) == CTX
+        del ret
+    ttft = ttft[1:]
+    engine.close()
+    ttft_proxy = {"retrieve_plus_one_step_ms": round(median(ttft), 3), "one_step_ms": round(alone, 3),
+                  "ratio": round(median(ttft) / alone, 3), "target": "<= 1.05", "reps": reps,
+                  "pcie_floor_ms": round(0.0 + raw_bytes / 4.2 / 52e9 * 1e3, 2),
+                  "note": "engine.retrieve() of the warm 16k prefix from pinned host DRAM (510 MB of blobs over one PCIe "
+                          "Gen5 x16 link, ~52 GB/s measured: that transfer alone is the floor shown) + one proxy step, "
+                          "over one proxy step; chunk-pipelined H2D/decode, not yet layer-pipelined (DESIGN.md section 5)"}
+    del proxy
+    return {"store_hidden": store_hidden, "ttft_proxy": ttft_proxy}
 
 
 if __name__ == "__main__":

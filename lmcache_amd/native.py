@@ -180,20 +180,17 @@ class _PointerTables:
     """Device copies of plane-pointer tables (lmc_kv_layout.plane_ptrs), keyed by the pointers themselves.
 
     A serving engine hands the same per-layer KV tensors to every store()/retrieve(), so the table of a call
-    is almost always one uploaded before: no copy, no host wait.  A new table goes through a pinned staging
-    slot with an asynchronous copy on the caller's current stream (the kernels that read it are queued behind
-    it on that stream); the host never waits for the device here (the reference's own note on this path:
-    "synchronize is harmful", local_backend.py:83-90)."""
-    SLOTS = 16          # pinned staging slots, reused round-robin (a slot is free once its copy's event fired)
-    MAX_CACHED = 64
+    is almost always one uploaded before: no copy, no host wait.  A table seen for the first time goes through
+    pinned staging on a PRIVATE copy stream and the host waits for that 2 KiB copy alone (~20 us) -- never for
+    the work queued on the caller's stream (the reference's own note on this path: "synchronize is harmful",
+    local_backend.py:83-90) -- so the table is complete before a kernel on ANY stream can be launched with it."""
+    MAX_CACHED = 4096   # 2 KiB each; when full the cache is dropped after a device synchronise (once in a blue moon)
 
     def __init__(self):
         self._lock = threading.Lock()
         self._cache = {}     # (device index, ptrs tuple) -> device int64 tensor
-        self._order = []
-        self._stage = None   # PinnedBuffer, SLOTS x 2 KiB
-        self._events = [None] * self.SLOTS
-        self._next = 0
+        self._stage = None   # PinnedBuffer, 2 KiB
+        self._streams = {}   # device index -> private copy stream
 
     def get(self, ptrs: Sequence[int], device: torch.device) -> torch.Tensor:
         key = (device.index, tuple(ptrs))
@@ -204,24 +201,20 @@ class _PointerTables:
             n = len(ptrs)
             assert n <= 256, "at most 256 planes"
             if self._stage is None:
-                self._stage = PinnedBuffer(self.SLOTS * 2048)
-            k = self._next
-            self._next = (k + 1) % self.SLOTS
-            if self._events[k] is not None:
-                self._events[k].synchronize()   # 16 uploads ago: long done
-            view = self._stage.tensor[k * 2048:k * 2048 + 8 * n].view(torch.int64)
-            view.copy_(torch.tensor(ptrs, dtype=torch.int64))
+                self._stage = PinnedBuffer(2048)
+            self._stage.tensor[:8 * n].view(torch.int64).copy_(torch.tensor(ptrs, dtype=torch.int64))
             with torch.cuda.device(device):
-                t = torch.empty(n, dtype=torch.int64, device=device)
-                cur = torch.cuda.current_stream(device)
-                memcpy_async(t.data_ptr(), self._stage.ptr + k * 2048, 8 * n, "h2d", cur.cuda_stream)
-                ev = torch.cuda.Event()
-                ev.record(cur)
-            self._events[k] = ev
+                st = self._streams.get(device.index)
+                if st is None:
+                    st = self._streams[device.index] = torch.cuda.Stream(device=device)
+                if len(self._cache) >= self.MAX_CACHED:
+                    torch.cuda.synchronize(device)  # nobody reads the old tables any more
+                    self._cache.clear()
+                with torch.cuda.stream(st):  # the block belongs to the private stream: nothing else is queued on it
+                    t = torch.empty(n, dtype=torch.int64, device=device)
+                memcpy_async(t.data_ptr(), self._stage.ptr, 8 * n, "h2d", st.cuda_stream)
+                st.synchronize()  # this copy only
             self._cache[key] = t
-            self._order.append(key)
-            if len(self._order) > self.MAX_CACHED:
-                self._cache.pop(self._order.pop(0), None)
             return t
 
 
@@ -521,13 +514,14 @@ def memcpy_async(dst_ptr: int, src_ptr: int, nbytes: int, kind: str, stream: int
     check(lib().lmc_memcpy_async(dst_ptr, src_ptr, nbytes, k, stream), "lmc_memcpy_async")
 
 
-def blob_info(blob: bytes) -> BlobHeader:
-    """Parse + validate a blob header on the host (lmc_blob_info)."""
+def blob_info(blob: bytes, total_len: Optional[int] = None) -> BlobHeader:
+    """Parse + validate a blob header on the host (lmc_blob_info).  `blob` may be just the first 128 bytes
+    when the blob's length is passed as total_len (a blob that lives in device memory)."""
     h = BlobHeader()
     if len(blob) < HEADER_BYTES:
         raise NativeError("blob shorter than its header")
     buf = (ctypes.c_uint8 * HEADER_BYTES).from_buffer_copy(bytes(blob[:HEADER_BYTES]))
-    rc = lib().lmc_blob_info(buf, len(blob), ctypes.byref(h))
+    rc = lib().lmc_blob_info(buf, len(blob) if total_len is None else total_len, ctypes.byref(h))
     check(rc, "lmc_blob_info")
     return h
 

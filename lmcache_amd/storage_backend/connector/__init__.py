@@ -2,9 +2,10 @@
 
 The reference's network connectors (lm:// TCP, redis://, redis-sentinel://) move
 opaque bytes and are outside the hot path (SURVEY.md section 2 #8, section 8 "out of scope"):
-a deployment keeps using the reference's.  Here only the in-process `mem://`
-connector exists, so that LMCRemoteBackend + the serde can be exercised end to
-end without a server process.  The RCCL/xGMI connector is row f1 ("next").
+a deployment keeps using the reference's.  Two connectors exist here: the
+in-process `mem://` (LMCRemoteBackend + the serde end to end without a server
+process) and `xgmi://` (row f1: chunks shared between the instances of one node,
+resident in the GPUs' HBM and moved over xGMI -- xgmi_connector.py).
 """
 import re
 import threading
@@ -48,6 +49,9 @@ def CreateConnector(url: str) -> RemoteConnector:
     scheme = m.group(1)
     if scheme == "mem":
         return InProcessConnector(f"{m.group(2)}:{m.group(3)}")
+    if scheme == "xgmi":  # xgmi://<store name>:<ranks sharing it (0: WORLD_SIZE)>: HBM arenas + HIP IPC, row f1
+        from lmcache_amd.storage_backend.connector.xgmi_connector import XgmiConnector
+        return XgmiConnector(m.group(2), int(m.group(3)))
     if scheme in ("lm", "redis", "redis-sentinel"):
         raise ValueError(f"{scheme}:// connectors are network I/O outside lmcache_amd's scope "
                          f"(use the reference's lmcache.storage_backend.connector)")

@@ -128,6 +128,9 @@ class LMCPipelinedRemoteBackend(LMCRemoteBackend):
         if self.supports_kv_layout:
             from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
             self.cachegen_config = CacheGenConfig.from_model_name(metadata.model_name)
+        # a connector whose blobs live in device memory (xgmi://): chunks go encode arena -> owner's HBM -> decode
+        # arena without a host hop
+        self._dev_conn = hasattr(self.connection, "set_device") and self.supports_kv_layout
         self.fetch_batch = 8                      # blobs handed to one decode call at most
         self._fetcher = ThreadPoolExecutor(max_workers=1, thread_name_prefix="lmc-fetch")
         self._prefetched = {}                     # key -> bytes fetched by chunk_meta, consumed by the next read
@@ -170,6 +173,13 @@ class LMCPipelinedRemoteBackend(LMCRemoteBackend):
     def chunk_meta(self, key: CacheEngineKey):
         from lmcache_amd import native
         from lmcache_amd.storage_backend.serde.cachegen_decoder import output_spec
+        if self._dev_conn:
+            got = self.connection.peek(key.to_string(), native.HEADER_BYTES)
+            if got is None:
+                self.existing_keys.discard(key)
+                raise KeyError(key)
+            h = native.blob_info(got[0], total_len=got[1])
+            return output_spec(self.fmt, h.num_layers, h.ntokens, h.num_heads, h.head_size)
         bs = self._prefetched.get(key)
         if bs is None:
             bs = self.connection.get(key.to_string())
@@ -190,6 +200,13 @@ class LMCPipelinedRemoteBackend(LMCRemoteBackend):
         codec = get_codec(src.device.index)
         with torch.cuda.device(src.device):
             job = codec.encode(src, tok_begin, tok_end, chunk_tokens, self.cachegen_config.plane_bins(src.L))
+            if self._dev_conn:  # device to device: every blob straight into its owner's HBM arena
+                sizes = codec.sizes_of(job)
+                for i, key in enumerate(keys):
+                    self.connection.set_device(key.to_string(), job.arena[i * job.stride:i * job.stride + sizes[i]])
+                    self.existing_keys.add(key)
+                job.offload_issued = True  # the copies have completed (set_device publishes after they land)
+                return n
         # drain the device arena now (the next encode reuses it); only the connector writes may be deferred
         if self._host_arena is None:
             self._host_arena = PinnedArena(slab_bytes=64 << 20)
@@ -223,12 +240,23 @@ class LMCPipelinedRemoteBackend(LMCRemoteBackend):
                 first += len(batch)
                 batch = []
 
+        def arrivals():
+            if not self._dev_conn:
+                yield from self._arrivals(keys)
+                return
+            for idx, key in enumerate(keys):  # blobs in device memory: no blocking I/O, so no fetch thread
+                t = self.connection.get_device(key.to_string()) if self.contains(key) else None
+                yield idx, t, idx + 1 < len(keys)
+
         try:
-            for idx, bs, backlog in self._arrivals(keys):
+            for idx, bs, backlog in arrivals():
                 if bs is None:
                     self.existing_keys.discard(keys[idx])
                     break
-                h = native.blob_info(bs)  # raises NativeError on a bad header / truncated blob
+                if self._dev_conn:
+                    h = native.blob_info(bs[:native.HEADER_BYTES].cpu().numpy().tobytes(), total_len=bs.numel())
+                else:
+                    h = native.blob_info(bs)  # raises NativeError on a bad header / truncated blob
                 if (h.num_layers, h.num_heads, h.head_size) != (dst.L, dst.H, dst.D) or h.ntokens > chunk_tokens:
                     raise native.NativeError(f"chunk {idx}: blob geometry does not match the destination")
                 batch.append(bs)

@@ -31,6 +31,7 @@ class PinnedArena:
     def __init__(self, slab_bytes: int = 256 << 20):
         self.slab_bytes = slab_bytes
         self._slabs: List[native.PinnedBuffer] = []
+        self._spare: List[native.PinnedBuffer] = []   # slabs allocated ahead of need (reserve)
         self._used = 0
         self._lock = threading.Lock()
         self.total_allocated = 0
@@ -39,13 +40,24 @@ class PinnedArena:
         need = native.r16(max(nbytes, 16))
         with self._lock:
             if not self._slabs or self._used + need > self._slabs[-1].nbytes:
-                self._slabs.append(native.PinnedBuffer(max(self.slab_bytes, need)))
+                k = next((i for i, b in enumerate(self._spare) if b.nbytes >= need), None)
+                self._slabs.append(self._spare.pop(k) if k is not None
+                                   else native.PinnedBuffer(max(self.slab_bytes, need)))
                 self._used = 0
             slab = self._slabs[-1]
             off = self._used
             self._used += need
             self.total_allocated += need
         return HostBlob(slab, off, nbytes)
+
+    def reserve(self, nbytes: int) -> None:
+        """Allocate slabs for `nbytes` more bytes now (hipHostMalloc of hundreds of MB takes tens of ms: a backend
+        sized for its working set pays that at start-up, not inside a store)."""
+        with self._lock:
+            have = sum(b.nbytes for b in self._spare)
+            while have < nbytes:
+                self._spare.append(native.PinnedBuffer(self.slab_bytes))
+                have += self.slab_bytes
 
     def reset(self):
         """Recycle the newest slab (callers that own every blob handed out so far)."""
@@ -58,9 +70,9 @@ class PinnedArena:
 
     def close(self):
         with self._lock:
-            for s in self._slabs:
+            for s in self._slabs + self._spare:
                 s.free()
-            self._slabs = []
+            self._slabs, self._spare = [], []
 
 
 @dataclass
@@ -251,12 +263,16 @@ class CacheGenDeviceCodec:
                batch_chunks: Optional[int] = None) -> Optional[DecodeJob]:
         """H2D the blobs on the side stream and decode them on the current stream straight into `dst`,
         pipelined in batches of `decode_batch_chunks` (copy of batch b+1 overlaps the decode of batch b).
-        host_blobs: HostBlob (pinned) or bytes-like (staged through pinned memory).
+        host_blobs: HostBlob (pinned), bytes-like (staged through pinned memory) or uint8 CUDA tensors (blobs
+        that are already in HBM: copied device to device).
         Asynchronous: returns a DecodeJob; finish_decode(job) waits for it and raises on a corrupt blob."""
         n = len(host_blobs)
         if n == 0:
             return None
-        sizes = [hb.nbytes if isinstance(hb, HostBlob) else len(hb) for hb in host_blobs]
+        def _is_dev(b):
+            return isinstance(b, torch.Tensor) and b.is_cuda
+
+        sizes = [hb.nbytes if isinstance(hb, HostBlob) else (hb.numel() if _is_dev(hb) else len(hb)) for hb in host_blobs]
         stride = native.r16(max(sizes))
         with self._lock:
             with torch.cuda.device(self.device):
@@ -267,7 +283,7 @@ class CacheGenDeviceCodec:
                     self.copy_stream.wait_event(self._dec_free)  # previous decode has read the slots
                 cs = self.copy_stream.cuda_stream
                 staged_off = 0
-                pageable = [hb for hb in host_blobs if not isinstance(hb, HostBlob)]
+                pageable = [hb for hb in host_blobs if not isinstance(hb, HostBlob) and not _is_dev(hb)]
                 if pageable:
                     need = sum(native.r16(len(b)) for b in pageable)
                     if self._stage is None or self._stage.nbytes < need:
@@ -283,6 +299,12 @@ class CacheGenDeviceCodec:
                     b1 = min(n, b0 + B)
                     for i in range(b0, b1):
                         hb = host_blobs[i]
+                        if _is_dev(hb):
+                            # a blob already in HBM (xgmi:// connector): a device copy on the decoding stream itself,
+                            # ordered behind whatever produced the tensor
+                            native.memcpy_async(arena.data_ptr() + i * stride, hb.data_ptr(), sizes[i], "d2d",
+                                                cur.cuda_stream)
+                            continue
                         if isinstance(hb, HostBlob):
                             src_ptr = hb.ptr
                         else:

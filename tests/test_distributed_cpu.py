@@ -120,3 +120,45 @@ def test_shard_exchange_world2():
 
 def test_shard_exchange_world3():
     assert _run_world(_exchange_worker, 3, 33533 + os.getpid() % 2000) == [0, 1, 2]
+
+
+def test_bench_launch_plumbing_world2_stub():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per GPU), with
+    LMC_BENCH_STUB=1: gloo instead of RCCL and a sleep instead of the kernel, so that process-group init, the
+    barrier / synchronize bracket, the max-over-ranks reduction, the whole-job value and the teardown are all
+    exercised without a GPU -- the first real 8-GPU run must not die in launch plumbing."""
+    import json
+    import subprocess
+    port = 29700 + os.getpid() % 2000
+    env = dict(os.environ, LMC_BENCH_STUB="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "4", "--warmup", "1"], env=env, capture_output=True, text=True,
+                         timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 prints ONE JSON line
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["higher_is_better"] is True and r["unit"] == "GB/s" and r["vs_baseline"] is None
+    # whole-job value: both ranks' bytes over the max-over-ranks time of exactly 4 steps (2 ms sleeps)
+    raw = 32 * 2 * 16384 * 8 * 128 * 2
+    assert abs(r["value"] - 2 * raw * 4 / (r["ms_per_step"] * 4 / 1e3) / 1e9) / r["value"] < 1e-3
+    assert 2.0 <= r["ms_per_step"] < 50.0
+
+
+def test_numa_topology_helpers(tmp_path):
+    """GPU -> NUMA node -> CPU list, read from sysfs (bind_to_gpu_numa pins a rank's pinned arenas next to its GPU)."""
+    from lmcache_amd.distributed import gpu_numa_node, numa_cpus
+    dev = tmp_path / "pci" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("64-67,192-193\n")
+    assert gpu_numa_node("0000:C1:00.0", str(tmp_path / "pci")) == 1
+    assert gpu_numa_node("0000:ff:00.0", str(tmp_path / "pci")) is None
+    assert numa_cpus(1, str(tmp_path / "node")) == [64, 65, 66, 67, 192, 193]
+    assert numa_cpus(7, str(tmp_path / "node")) == []
+    (dev / "numa_node").write_text("-1\n")
+    assert gpu_numa_node("0000:c1:00.0", str(tmp_path / "pci")) is None

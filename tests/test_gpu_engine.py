@@ -132,6 +132,13 @@ def test_cachegen_unmatched_size(oracle):
 def make_cfg(backend, chunk_size=256):
     if backend == "cachegen-host":
         return LMCacheEngineConfig.from_legacy(chunk_size=chunk_size, backend="cpu", local_serde="cachegen")
+    if backend.startswith("xgmi://"):  # a fresh store per test process: xgmi://<name>:<world>
+        import os
+        name, world = backend[len("xgmi://"):].split(":")
+        backend = f"xgmi://{name}{os.getpid()}:{world}"
+        serde = "torch" if "lossless" in name else "cachegen"
+        return LMCacheEngineConfig.from_legacy(chunk_size=chunk_size, backend=backend, remote_serde=serde,
+                                               pipelined_backend="pipe" in name)
     if backend.startswith("mem://"):
         serde = "cachegen" if backend.endswith("1") else "torch"
         return LMCacheEngineConfig.from_legacy(chunk_size=chunk_size, backend=backend, remote_serde=serde,
@@ -157,7 +164,7 @@ def test_retrieve_device(backend, src_device):
 
 
 @pytest.mark.parametrize("fmt", ["vllm", "huggingface"])
-@pytest.mark.parametrize("backend", ["cuda", "cpu", "mem://lossless:0", "mem://losslesspipe:0"])
+@pytest.mark.parametrize("backend", ["cuda", "cpu", "mem://lossless:0", "mem://losslesspipe:0", "xgmi://lossless:1"])
 def test_same_retrieve_store_lossless(fmt, backend):
     """store -> retrieve is bit exact for the lossless paths (tests/test_cache_engine.py:108-151)."""
     num_tokens = 2000
@@ -174,7 +181,8 @@ def test_same_retrieve_store_lossless(fmt, backend):
 
 
 @pytest.mark.parametrize("fmt", ["vllm", "huggingface"])
-@pytest.mark.parametrize("backend", ["cachegen-host", "mem://cachegen:1", "mem://cachegenpipe:1"])
+@pytest.mark.parametrize("backend", ["cachegen-host", "mem://cachegen:1", "mem://cachegenpipe:1", "xgmi://cg:1",
+                                     "xgmi://cgpipe:1"])
 def test_same_retrieve_store_cachegen_equals_oracle(fmt, backend, oracle):
     """The CacheGen paths return exactly do_dequantize(torch_quant_vectorized(x)) per chunk."""
     num_tokens, cs, nl = 600, 256, 4
@@ -182,6 +190,8 @@ def test_same_retrieve_store_cachegen_equals_oracle(fmt, backend, oracle):
     kv_cache = generate_kv_cache(num_tokens, fmt, "cuda", num_layers=nl)
     engine = LMCacheEngine(make_cfg(backend, cs), dumb_metadata(fmt, MODEL))
     try:
+        if backend == "xgmi://cgpipe:1":  # blobs go encode arena -> HBM arena of the owner -> decode arena
+            assert engine.engine_._dev_conn and engine.engine_.supports_kv_layout
         engine.store(tokens, kv_cache)
         retrieved_cache, ret_mask = engine.retrieve(tokens)
         assert int(torch.sum(ret_mask)) == num_tokens
@@ -197,6 +207,8 @@ def test_same_retrieve_store_cachegen_equals_oracle(fmt, backend, oracle):
             assert torch.equal(got, want), f"chunk at {t0}"
     finally:
         engine.close()
+        if hasattr(engine.engine_, "connection") and hasattr(engine.engine_.connection, "unlink"):
+            engine.engine_.connection.unlink()
 
 
 @pytest.mark.parametrize("fmt", ["vllm", "huggingface"])
