@@ -187,6 +187,20 @@ int lmc_decode_chunks(lmc_ctx* ctx, const void* blobs, uint64_t blob_stride, int
                       const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, uint32_t* job_status,
                       lmc_stream_t stream);
 
+/*
+ * The same decode for a RANGE OF LAYERS of blobs that lie anywhere in device memory: the launch handles the K and V
+ * planes of layers [layer_begin, layer_begin + layer_count) of every chunk.  A retrieve cut into one launch per
+ * layer range (an event after each) hands layer 0's KV to the model after 1/L of the decode instead of all of it
+ * -- the streams of a plane are independent and the blob's directory (gend) gives random access to them.  Stands
+ * where the reference decodes and concatenates the whole context before the first layer can run
+ * (cache_engine.py:339-381; the connector writes layer by layer afterwards, LLM_Engine.rst:101-122).
+ *   blob_ptrs       device array [nchunks] of device pointers, blob i at blob_ptrs[i] (16-byte aligned)
+ *   max_blob_bytes  upper bound of the blobs' sizes (a blob whose header claims more is rejected)
+ */
+int lmc_decode_chunks_layers(lmc_ctx* ctx, const void* const* blob_ptrs, uint64_t max_blob_bytes, int32_t nchunks,
+                             const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, int32_t layer_begin,
+                             int32_t layer_count, uint32_t* job_status, lmc_stream_t stream);
+
 /* Entropy-decode only (debug / parity): blob -> sym_out int8 [P][T][C].
  * Stands where torchac_cuda.decode_fast_prefsum stands (cachegen_decoder.py:65-66). */
 int lmc_decode_symbols(lmc_ctx* ctx, const void* blob, int32_t L, int32_t H, int32_t D, int8_t* sym_out,

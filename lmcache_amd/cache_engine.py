@@ -218,7 +218,42 @@ class LMCacheEngine:
         _, ret_mask = self._retrieve_into(tokens, mask, make_dst)
         return ret_mask
 
-    def _retrieve_into(self, tokens: torch.Tensor, mask: Optional[torch.Tensor], make_dst) -> Tuple[int, torch.Tensor]:
+    @_lmcache_nvtx_annotate
+    @torch.no_grad()
+    def retrieve_layerwise(self, tokens: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                           layers_per_launch: int = 1) -> "LayerwiseRetrieval":
+        """retrieve() that does not make the model wait for the last layer: the KV tuple is returned at once and
+        `layer_events` says when each range of layers is complete -- [(first layer after the range, event), ...] in
+        layer order; the attention of layer l runs after `wait_layer(l)` (a stream-side wait).  With an HBM-resident
+        CacheGen tier (local_device="cuda", local_serde="cachegen") the decode of layer l+1 then hides behind the
+        model's layer l and a warm prefix costs the model almost nothing (bench.py: ttft_proxy).  Backends that
+        cannot cut their retrieve by layer return one event that covers everything.  Call finish() before
+        trusting the KV for good: it waits for the decode and raises if a stored blob was corrupt."""
+        fmt = self.metadata.fmt
+        box, jobs = {}, []
+
+        def make_dst(nret, L, H, D, dtype, dev):
+            shape = (L, 2, nret, H, D) if fmt == "vllm" else (L, 2, H, nret, D)
+            box["blob"] = torch.empty(shape, dtype=dtype, device=dev)
+            box["L"] = L
+            return native.KVLayout.from_chunk(box["blob"], fmt)
+
+        got, ret_mask = self._retrieve_into(tokens, mask, make_dst, layers_per_launch=layers_per_launch, jobs_out=jobs)
+        if got == 0:
+            return LayerwiseRetrieval((), ret_mask, [], [])
+        blob = box["blob"].narrow(2 if fmt == "vllm" else 3, 0, got)
+        events = []
+        for _, job in jobs:
+            if job is not None and job.layer_events:
+                events = list(job.layer_events)
+        if not events:  # the backend finished (or queued) everything in one piece
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(blob.device))
+            events = [(box["L"], ev)]
+        return LayerwiseRetrieval(self._blob_to_tuple_kv(blob), ret_mask, events, jobs)
+
+    def _retrieve_into(self, tokens: torch.Tensor, mask: Optional[torch.Tensor], make_dst,
+                       layers_per_launch: Optional[int] = None, jobs_out: Optional[list] = None) -> Tuple[int, torch.Tensor]:
         """The body of retrieve(): prefix probe, the first-chunk trim of a suffix mask, then every hit chunk
         written to destination tokens 0 .. got-1 of the layout make_dst(nret, L, H, D, dtype, device) returns.
         -> (got = tokens written, ret_mask)."""
@@ -256,7 +291,11 @@ class LMCacheEngine:
             H, D = (shape0[3], shape0[4]) if fmt == "vllm" else (shape0[2], shape0[4])
             dst = make_dst(nret, L, H, D, dtype, dev)
             try:
-                got = self.engine_.get_kv_range(keys[:hits], dst, fmt, -extra, cs)
+                if jobs_out is not None and getattr(self.engine_, "mode", None) == "hbm-cachegen":
+                    got = self.engine_.get_kv_range(keys[:hits], dst, fmt, -extra, cs,
+                                                    layers_per_launch=layers_per_launch, jobs_out=jobs_out)
+                else:
+                    got = self.engine_.get_kv_range(keys[:hits], dst, fmt, -extra, cs)
             except native.NativeError:
                 # a stored blob that does not decode must never reach the model as KV: the whole lookup is a miss
                 logger.exception("retrieve: a cached chunk failed to decode; treated as a miss")
@@ -296,6 +335,30 @@ class LMCacheEngine:
 
     def close(self):
         self.engine_.close()
+
+
+class LayerwiseRetrieval:
+    """What retrieve_layerwise returns: the KV tuple (being filled layer by layer), ret_mask, and the events."""
+
+    def __init__(self, kv, ret_mask, layer_events, jobs):
+        self.kv, self.ret_mask, self.layer_events, self._jobs = kv, ret_mask, layer_events, jobs
+
+    def wait_layer(self, layer: int, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Make `stream` (default: the current one) wait until the KV of `layer` is complete.  No host wait."""
+        if not self.layer_events:
+            return
+        st = stream or torch.cuda.current_stream()
+        for end, ev in self.layer_events:
+            if layer < end:
+                st.wait_event(ev)
+                return
+        st.wait_event(self.layer_events[-1][1])
+
+    def finish(self) -> None:
+        """Host-side completion: waits for the decode and raises NativeError if a blob did not check out."""
+        jobs, self._jobs = self._jobs, []
+        for codec, job in jobs:
+            codec.finish_decode(job)
 
 
 class LMCacheEngineBuilder:

@@ -27,6 +27,8 @@
 struct DecodeArgs {
   const u8* blobs;
   long long blob_stride;
+  const u8* const* blob_ptrs;  // device array [nchunks] of blob addresses, or NULL (then blobs + i * blob_stride)
+  int layer_begin, layer_count; // the layers to decode: planes layer_begin .. +layer_count of K and of V
   int nchunks;
   KvAddr dst;          // SYMOUT=false
   int dst_tok0, chunk_tokens;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform -> SGPRs
   const long long gid = (long long)blockIdx.x * 4 + wave;
-  const int n = a.P * a.G;
+  const int n = 2 * a.layer_count * a.G;  // streams of a chunk in this launch
   if (gid >= (long long)a.nchunks * n) return;
   u8* wl = lds_all + wave * DEC_WAVE_BYTES;
   u16* cdfT = reinterpret_cast<u16*>(wl);                           // [33][64]: entry-major, bank = lane/2
@@ -63,9 +65,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   float* lut = reinterpret_cast<float*>(wl + DEC_CDF_BYTES + DEC_RING_BYTES);  // (q - C) / C
 
   const int chunk = (int)(gid / n);
-  const int pg = (int)(gid - (long long)chunk * n);
-  const int p = pg / a.G, g = pg - p * a.G;
-  const u8* blob = a.blobs + (long long)chunk * a.blob_stride;
+  const int r = (int)(gid - (long long)chunk * n);
+  const int pidx = r / a.G, g = r - pidx * a.G;
+  // K planes of the layer range first, then their V planes (plane p = kv * L + layer)
+  const int p = pidx < a.layer_count ? a.layer_begin + pidx : (a.P >> 1) + a.layer_begin + pidx - a.layer_count;
+  const int pg = p * a.G + g;
+  const u8* blob = a.blob_ptrs ? (const u8*)uniform_ptr(a.blob_ptrs[chunk]) : a.blobs + (long long)chunk * a.blob_stride;
   const u32* hd = reinterpret_cast<const u32*>(blob);
   // header words are the same for every lane: read them through SGPRs so all control flow below is scalar
   auto hdw = [&](int i) { return (u32)__builtin_amdgcn_readfirstlane((int)hd[i]); };

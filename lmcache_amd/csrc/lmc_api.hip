@@ -340,8 +340,29 @@ static int decode_common(lmc_ctx* c, const void* blobs, uint64_t blob_stride, in
                          uint32_t* job_status, DecodeArgs& a) {
   if (!c || !blobs || nchunks < 1 || ((uintptr_t)blobs & 15) || (blob_stride & 15)) return LMC_ERR_INVALID;
   a.blobs = (const u8*)blobs; a.blob_stride = (long long)blob_stride; a.nchunks = nchunks;
+  a.blob_ptrs = nullptr; a.layer_begin = 0; a.layer_count = L;
   a.P = 2 * L; a.C = H * D; a.G = (a.C + 63) / 64;
   a.status = job_status ? job_status : c->status_h;
+  return LMC_OK;
+}
+
+static int decode_launch(lmc_ctx* c, DecodeArgs& a, const lmc_kv_layout* dst, hipStream_t hs) {
+  int rc;
+  const long long n = (long long)a.nchunks * 2 * a.layer_count * a.G;
+  dim3 grid((unsigned)((n + 3) / 4));
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->pn = 0;
+  if ((rc = prof_mark(c, hs))) return rc;
+  const bool paged = dst->slot_mapping != nullptr;
+  if (dst->dtype == LMC_DTYPE_BF16) {
+    if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, true>), grid, dim3(256), 0, hs, a);
+    else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, false>), grid, dim3(256), 0, hs, a);
+  } else {
+    if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, true>), grid, dim3(256), 0, hs, a);
+    else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, false>), grid, dim3(256), 0, hs, a);
+  }
+  HIP_TRY(hipGetLastError());
+  if ((rc = prof_mark(c, hs))) return rc;
   return LMC_OK;
 }
 
@@ -354,23 +375,26 @@ int lmc_decode_chunks(lmc_ctx* c, const void* blobs, uint64_t blob_stride, int32
   if (rc) return rc;
   a.dst = to_addr(dst); a.dst_tok0 = dst_tok0; a.chunk_tokens = chunk_tokens;
   HIP_TRY(hipSetDevice(c->device));
-  const long long n = (long long)nchunks * a.P * a.G;
-  dim3 grid((unsigned)((n + 3) / 4));
-  std::lock_guard<std::mutex> lk(c->mu);
-  c->pn = 0;
-  if ((rc = prof_mark(c, (hipStream_t)stream))) return rc;
-  const bool paged = dst->slot_mapping != nullptr;
-  hipStream_t hs = (hipStream_t)stream;
-  if (dst->dtype == LMC_DTYPE_BF16) {
-    if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, true>), grid, dim3(256), 0, hs, a);
-    else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, false>), grid, dim3(256), 0, hs, a);
-  } else {
-    if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, true>), grid, dim3(256), 0, hs, a);
-    else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, false>), grid, dim3(256), 0, hs, a);
-  }
-  HIP_TRY(hipGetLastError());
-  if ((rc = prof_mark(c, (hipStream_t)stream))) return rc;
-  return LMC_OK;
+  return decode_launch(c, a, dst, (hipStream_t)stream);
+}
+
+int lmc_decode_chunks_layers(lmc_ctx* c, const void* const* blob_ptrs, uint64_t max_blob_bytes, int32_t nchunks,
+                             const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, int32_t layer_begin,
+                             int32_t layer_count, uint32_t* job_status, lmc_stream_t stream) {
+  if (!layout_ok(dst) || chunk_tokens < 1 || !blob_ptrs || layer_begin < 0 || layer_count < 1 ||
+      layer_begin + layer_count > dst->num_layers)
+    return LMC_ERR_INVALID;
+  DecodeArgs a;
+  memset(&a, 0, sizeof a);
+  // `blobs` is only a non-null placeholder here: the kernel takes every blob's address from the table
+  int rc = decode_common(c, blob_ptrs, (max_blob_bytes + 15) & ~(uint64_t)15, nchunks, dst->num_layers, dst->num_heads,
+                         dst->head_size, job_status, a);
+  if (rc) return rc;
+  a.blob_ptrs = (const u8* const*)blob_ptrs;
+  a.layer_begin = layer_begin; a.layer_count = layer_count;
+  a.dst = to_addr(dst); a.dst_tok0 = dst_tok0; a.chunk_tokens = chunk_tokens;
+  HIP_TRY(hipSetDevice(c->device));
+  return decode_launch(c, a, dst, (hipStream_t)stream);
 }
 
 int lmc_decode_symbols(lmc_ctx* c, const void* blob, int32_t L, int32_t H, int32_t D, int8_t* sym_out,
@@ -382,7 +406,7 @@ int lmc_decode_symbols(lmc_ctx* c, const void* blob, int32_t L, int32_t H, int32
   if (rc) return rc;
   a.sym_out = sym_out;
   HIP_TRY(hipSetDevice(c->device));
-  const long long n = (long long)a.P * a.G;
+  const long long n = (long long)a.P * a.G;  // every layer (decode_common set the full range)
   hipLaunchKernelGGL((k_decode<true, LMC_DTYPE_BF16, false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return LMC_OK;

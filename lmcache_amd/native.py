@@ -78,6 +78,7 @@ SYMBOLS = {
     "lmc_calculate_cdf": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "lmc_encode_chunks": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp, _vp]),
     "lmc_decode_chunks": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _vp, _vp]),
+    "lmc_decode_chunks_layers": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _i32, _i32, _vp, _vp]),
     "lmc_decode_symbols": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "lmc_copy_kv": (ctypes.c_int, [_vp, _PL, _i32, _i32, _PL, _i32, _vp]),
     "lmc_pinned_alloc": (ctypes.c_int, [_sz, ctypes.POINTER(_vp)]),
@@ -219,6 +220,11 @@ class _PointerTables:
 
 
 _pointer_tables = _PointerTables()
+
+
+def pointer_table(ptrs: Sequence[int], device: torch.device) -> torch.Tensor:
+    """Device int64 array holding `ptrs` (cached by content: see _PointerTables)."""
+    return _pointer_tables.get(ptrs, device)
 
 
 class KVLayout:
@@ -459,6 +465,15 @@ class Context:
         st = current_stream_ptr(dst.device) if stream is None else stream
         check(lib().lmc_decode_chunks(self.handle, blobs_ptr, blob_stride, nchunks, ctypes.byref(dst.struct),
                                       dst_tok0, chunk_tokens, status_ptr, st), "lmc_decode_chunks")
+
+    def decode_chunks_layers(self, blob_ptrs: int, max_blob_bytes: int, nchunks: int, dst: KVLayout, dst_tok0: int,
+                             chunk_tokens: int, layer_begin: int, layer_count: int, stream: Optional[int] = None,
+                             status_ptr: Optional[int] = None) -> None:
+        """Decode layers [layer_begin, +layer_count) of blobs addressed through a device pointer table."""
+        st = current_stream_ptr(dst.device) if stream is None else stream
+        check(lib().lmc_decode_chunks_layers(self.handle, blob_ptrs, max_blob_bytes, nchunks, ctypes.byref(dst.struct),
+                                             dst_tok0, chunk_tokens, layer_begin, layer_count, status_ptr, st),
+              "lmc_decode_chunks_layers")
 
     def decode_symbols(self, blob: torch.Tensor, L: int, H: int, D: int, T: int, stream: Optional[int] = None
                        ) -> torch.Tensor:

@@ -108,9 +108,38 @@ class EncodeJob:
 
 @dataclass
 class DecodeJob:
-    """One decode() call in flight: `done` fires after its last kernel, `status_idx` is its own status word."""
+    """One decode() call in flight: `done` fires after its last kernel, `status_idx` is its own status word.
+    layer_events (decode_device with layers_per_launch): (first layer after the range, event) per launch, in layer
+    order -- the KV of layers below `first layer after` is complete once the event has fired."""
     done: torch.cuda.Event
     status_idx: int
+    layer_events: Optional[list] = None
+
+
+class DeviceArena:
+    """Bump allocator over HBM slabs for encoded chunks that stay on the GPU (LMCLocalBackend, local_device="cuda" +
+    local_serde="cachegen": 4.2x more warm context in the 288 GB than raw chunks).  No eviction, like the
+    reference (hybrid_backend.py:24)."""
+
+    def __init__(self, device, slab_bytes: int = 512 << 20):
+        self.device, self.slab_bytes = device, slab_bytes
+        self._slabs: List[torch.Tensor] = []
+        self._used = 0
+        self._lock = threading.Lock()
+
+    def alloc(self, nbytes: int) -> torch.Tensor:
+        need = native.r16(max(nbytes, 16))
+        with self._lock:
+            if not self._slabs or self._used + need > self._slabs[-1].numel():
+                self._slabs.append(torch.empty(max(self.slab_bytes, need), dtype=torch.uint8, device=self.device))
+                self._used = 0
+            off = self._used
+            self._used += need
+            return self._slabs[-1][off:off + nbytes]
+
+    def close(self):
+        with self._lock:
+            self._slabs = []
 
 
 class CacheGenDeviceCodec:
@@ -250,7 +279,52 @@ class CacheGenDeviceCodec:
                 self._arena_free = ev
         return blobs, ev
 
+    def keep_on_device(self, job: EncodeJob, arena: DeviceArena) -> List[torch.Tensor]:
+        """The job's blobs copied (exact sizes, device to device, on the current stream) into a persistent HBM arena
+        -- the store leg of the HBM-resident CacheGen tier."""
+        sizes = self.sizes_of(job)
+        out = []
+        with self._lock, torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(job.done)
+            for i, n in enumerate(sizes):
+                t = arena.alloc(n)
+                native.memcpy_async(t.data_ptr(), job.arena.data_ptr() + i * job.stride, n, "d2d", cur.cuda_stream)
+                out.append(t)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            job.offload_issued = True
+            if job.arena is self._enc_arena:
+                self._arena_free = ev
+        return out
+
     # ---- decode ------------------------------------------------------------------
+    def decode_device(self, blobs: Sequence[torch.Tensor], dst: native.KVLayout, dst_tok0: int, chunk_tokens: int,
+                      layers_per_launch: Optional[int] = None) -> Optional[DecodeJob]:
+        """Decode blobs that live in HBM (uint8 CUDA tensors, anywhere) straight into `dst` on the current stream,
+        no staging copy: the kernel takes the blob addresses from a pointer table.  With layers_per_launch the
+        retrieve is cut into one launch per range of layers with an event after each (DecodeJob.layer_events): the
+        model can start on layer 0 after 1/L of the decode."""
+        n = len(blobs)
+        if n == 0:
+            return None
+        L = dst.L
+        step = L if not layers_per_launch else max(1, min(L, int(layers_per_launch)))
+        with self._lock, torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            table = native.pointer_table([b.data_ptr() for b in blobs], self.device)
+            bound = max(b.numel() for b in blobs)
+            st = self._status.acquire()
+            events = []
+            for l0 in range(0, L, step):
+                l1 = min(L, l0 + step)
+                self.ctx.decode_chunks_layers(table.data_ptr(), bound, n, dst, dst_tok0, chunk_tokens, l0, l1 - l0,
+                                              stream=cur.cuda_stream, status_ptr=self._status.ptr(st))
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                events.append((l1, ev))
+            return DecodeJob(events[-1][1], st, events if layers_per_launch else None)
+
     def _dec_slots(self, n: int, stride: int, cur) -> torch.Tensor:
         if self._dec_arena is None or self._dec_arena.numel() < n * stride:
             self._dec_arena = torch.empty(n * stride, dtype=torch.uint8, device=self.device)

@@ -132,6 +132,8 @@ def test_cachegen_unmatched_size(oracle):
 def make_cfg(backend, chunk_size=256):
     if backend == "cachegen-host":
         return LMCacheEngineConfig.from_legacy(chunk_size=chunk_size, backend="cpu", local_serde="cachegen")
+    if backend == "cachegen-hbm":
+        return LMCacheEngineConfig.from_legacy(chunk_size=chunk_size, backend="cuda", local_serde="cachegen")
     if backend.startswith("xgmi://"):  # a fresh store per test process: xgmi://<name>:<world>
         import os
         name, world = backend[len("xgmi://"):].split(":")
@@ -181,8 +183,8 @@ def test_same_retrieve_store_lossless(fmt, backend):
 
 
 @pytest.mark.parametrize("fmt", ["vllm", "huggingface"])
-@pytest.mark.parametrize("backend", ["cachegen-host", "mem://cachegen:1", "mem://cachegenpipe:1", "xgmi://cg:1",
-                                     "xgmi://cgpipe:1"])
+@pytest.mark.parametrize("backend", ["cachegen-host", "cachegen-hbm", "mem://cachegen:1", "mem://cachegenpipe:1",
+                                     "xgmi://cg:1", "xgmi://cgpipe:1"])
 def test_same_retrieve_store_cachegen_equals_oracle(fmt, backend, oracle):
     """The CacheGen paths return exactly do_dequantize(torch_quant_vectorized(x)) per chunk."""
     num_tokens, cs, nl = 600, 256, 4
@@ -300,7 +302,7 @@ def test_store_nonblocking_and_skip_existing(backend):
 def test_backend_put_get_contract():
     """LMCBackendInterface: put/get/contains/batched_* with chunk tensors; miss -> None (tests/test_backends.py)."""
     meta = dumb_metadata("vllm", MODEL)
-    for cfg in (make_cfg("cuda"), make_cfg("cpu"), make_cfg("cachegen-host"), make_cfg("mem://b:0")):
+    for cfg in (make_cfg("cuda"), make_cfg("cpu"), make_cfg("cachegen-host"), make_cfg("cachegen-hbm"), make_cfg("mem://b:0")):
         be = CreateStorageBackend(cfg, meta)
         try:
             keys = [CacheEngineKey("vllm", MODEL, 3, 123, f"{i:064x}") for i in range(3)]
@@ -619,3 +621,65 @@ def test_paged_store_and_scatter_retrieve_of_independent_segments(layout, backen
             assert torch.equal(v[300:], v1[300:]) and not v[:300].any()
     finally:
         engine.close()
+
+
+def test_hbm_cachegen_tier_and_layerwise_retrieve(oracle):
+    """local_device="cuda" + local_serde="cachegen": encoded chunks stay in HBM.  retrieve_layerwise cuts the decode
+    into one launch per range of layers and hands out an event per range; what it returns equals retrieve(), the
+    events come in layer order, a suffix mask trims the first chunk as usual, and a damaged blob is caught by
+    finish().  Backends that cannot cut by layer answer with one event."""
+    fmt, cs, nl = "vllm", 128, 8
+    engine = LMCacheEngine(make_cfg("cachegen-hbm", cs), dumb_metadata(fmt, MODEL))
+    host = LMCacheEngine(make_cfg("cachegen-host", cs), dumb_metadata(fmt, MODEL))
+    try:
+        assert engine.engine_.mode == "hbm-cachegen"
+        toks = generate_tokens(600, "cuda")
+        kv = generate_kv_cache(600, fmt, "cuda", num_layers=nl)
+        engine.store(toks, kv)
+        engine.store(toks[:256], tuple((k[:256], v[:256]) for k, v in kv), blocking=False)  # all present: nothing to do
+        host.store(toks, kv)
+        want, m = engine.retrieve(toks)
+        assert int(m.sum()) == 600
+        ref, _ = host.retrieve(toks)
+        for (k, v), (k1, v1) in zip(want, ref):
+            assert torch.equal(k, k1) and torch.equal(v, v1)  # the same decoder whatever memory the blobs live in
+        for step, nev in ((1, 8), (3, 3), (8, 1), (100, 1)):
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                r = engine.retrieve_layerwise(toks, layers_per_launch=step)
+            assert len(r.layer_events) == nev and [e for e, _ in r.layer_events] == sorted(e for e, _ in r.layer_events)
+            assert r.layer_events[-1][0] == nl and int(r.ret_mask.sum()) == 600
+            for l in range(nl):
+                r.wait_layer(l)  # the current stream now waits for layer l only
+                assert torch.equal(r.kv[l][0], want[l][0]) and torch.equal(r.kv[l][1], want[l][1])
+            r.finish()
+        mask = torch.ones(600, dtype=torch.bool, device="cuda")
+        mask[:200] = False
+        r = engine.retrieve_layerwise(toks, mask, layers_per_launch=2)
+        r.finish()
+        assert int(r.ret_mask.sum()) == 400
+        for (k, v), (k1, v1) in zip(r.kv, want):
+            assert torch.equal(k, k1[200:]) and torch.equal(v, v1[200:])
+        r = engine.retrieve_layerwise(generate_tokens(300, "cuda"))
+        assert r.kv == () and not r.ret_mask.any() and r.layer_events == []
+        r.finish()
+        r = host.retrieve_layerwise(toks, layers_per_launch=1)  # pinned-host tier: one piece
+        assert len(r.layer_events) == 1 and int(r.ret_mask.sum()) == 600
+        r.wait_layer(0)
+        r.finish()
+        assert torch.equal(r.kv[3][1], want[3][1])
+        # a blob damaged in HBM: the synchronous paths report a miss, the asynchronous one raises at finish()
+        keys = [engine._make_key(h, fmt) for h in engine._prefix_hash(engine._chunk_tokens(toks))]
+        blob = engine.engine_.dict[keys[2]].blob
+        old = int(blob[blob.numel() // 2])
+        blob[blob.numel() // 2] = old ^ 0x41
+        assert engine.retrieve(toks)[0] == () and engine.engine_.get(keys[2]) is None
+        r = engine.retrieve_layerwise(toks, layers_per_launch=4)
+        from lmcache_amd import native
+        with pytest.raises(native.NativeError):
+            r.finish()
+        blob[blob.numel() // 2] = old
+        assert int(engine.retrieve(toks)[1].sum()) == 600
+    finally:
+        engine.close()
+        host.close()
