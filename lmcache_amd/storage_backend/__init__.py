@@ -3,7 +3,8 @@
 
   remote only                -> LMCRemoteBackend (serde + connector), LMCPipelinedRemoteBackend if pipelined_backend
   local "cpu" / "cuda"       -> LMCLocalBackend  (HBM, pinned raw, or pinned CacheGen via local_serde)
-  local path (disk) / hybrid -> outside the hot path (file I/O, orchestration: SURVEY.md section 2 #3, #5)
+  local + remote             -> LMCHybridBackend (write-through / read-through over the two above)
+  local path (disk)          -> outside the hot path (file I/O: SURVEY.md section 2 #3)
 """
 from lmcache_amd.config import LMCacheEngineConfig, LMCacheEngineMetadata
 from lmcache_amd.logging import init_logger
@@ -26,6 +27,8 @@ def CreateStorageBackend(config: LMCacheEngineConfig, metadata: LMCacheEngineMet
         raise ValueError(f"local disk backend ({local!r}) is file I/O outside lmcache_amd's scope; "
                          f"use the reference's LMCLocalDiskBackend")
     if local is not None and remote is not None:
-        raise ValueError("hybrid (local + remote) orchestration is outside lmcache_amd's scope; "
-                         "use the reference's LMCHybridBackend over these backends")
+        if local not in ("cpu", "cuda"):
+            raise ValueError(f"local disk tier ({local!r}) is file I/O outside lmcache_amd's scope")
+        from lmcache_amd.storage_backend.hybrid_backend import LMCHybridBackend
+        return LMCHybridBackend(config, metadata)
     raise ValueError(f"Invalid configuration: {config}")

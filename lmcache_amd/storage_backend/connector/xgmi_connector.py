@@ -58,6 +58,11 @@ def _r256(n: int) -> int:
     return (n + 255) & ~255
 
 
+# arenas this process owns, by (store name, rank): two connectors of one process on the same store and rank (two
+# engines in one process) are two handles of ONE arena -- a second allocation would orphan what the first one holds
+_OWN_ARENAS: Dict[Tuple[str, int], list] = {}
+
+
 class XgmiConnector(RemoteConnector):
     def __init__(self, name: str, world: int, rank: Optional[int] = None, device: Optional[str] = None,
                  arena_bytes: Optional[int] = None, nslots: int = 1 << 15):
@@ -90,6 +95,12 @@ class XgmiConnector(RemoteConnector):
             if magic != _MAGIC or w != self.world or rec != _REC_BYTES:
                 raise ValueError(f"xgmi://{name}: directory belongs to another world ({w} ranks) or version")
         # ---- this rank's arena -------------------------------------------------------------------------------
+        own = _OWN_ARENAS.get((name, self.rank))
+        if own is not None:
+            own[1] += 1
+            self._peers[self.rank] = own[0]
+            self._closed = False
+            return
         if self.device.type == "cuda":
             arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=self.device)
             from torch.multiprocessing.reductions import reduce_tensor
@@ -106,6 +117,7 @@ class XgmiConnector(RemoteConnector):
             self._keep += [f, mm]
             arena = torch.frombuffer(mm, dtype=torch.uint8)
         self._peers[self.rank] = arena
+        _OWN_ARENAS[(name, self.rank)] = [arena, 1]
         self._closed = False
 
     # ------------------------------------------------------------------ plumbing
@@ -234,6 +246,11 @@ class XgmiConnector(RemoteConnector):
         if self._closed:
             return
         self._closed = True
+        own = _OWN_ARENAS.get((self.name, self.rank))
+        if own is not None:
+            own[1] -= 1
+            if own[1] <= 0:
+                del _OWN_ARENAS[(self.name, self.rank)]
         self._peers.clear()
         try:
             self._dir.close()

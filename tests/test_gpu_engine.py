@@ -683,3 +683,50 @@ def test_hbm_cachegen_tier_and_layerwise_retrieve(oracle):
     finally:
         engine.close()
         host.close()
+
+
+def test_hybrid_backend_two_instances_share_through_xgmi(oracle):
+    """BASELINE configs[2] at the engine boundary on one GPU: two engines ("vLLM instances"), each with a local
+    pinned-host tier in front of the shared xgmi:// store (LMCHybridBackend: write-through, read-through, warm-up
+    from what the store already holds).  What instance A stored, instance B retrieves -- bit-equal to the oracle's
+    dequant(quant(x)) -- first through the shared store, then from its own local tier."""
+    import os
+    from lmcache_amd.storage_backend.hybrid_backend import LMCHybridBackend
+    fmt, cs, nl = "vllm", 256, 4
+    url = f"xgmi://hyb{os.getpid()}:1"
+    cfg = LMCacheEngineConfig(cs, "cpu", url, "cachegen", False, False)
+    meta = LMCacheEngineMetadata(MODEL, 1, 0, fmt, "bfloat16")
+    a = LMCacheEngine(cfg, meta)
+    b = c = None
+    try:
+        assert isinstance(a.engine_, LMCHybridBackend)
+        toks = generate_tokens(600, "cuda")
+        kv = generate_kv_cache(600, fmt, "cuda", num_layers=nl)
+        a.store(toks, kv)
+        b = LMCacheEngine(cfg, meta)                      # second instance: warm-up pulls A's chunks
+        assert len(b.engine_.local_store.dict) == 3
+        got, m = b.retrieve(toks)
+        assert int(m.sum()) == 600
+        for t0 in range(0, 600, cs):
+            part = tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in kv)
+            want = oracle_roundtrip(oracle, part, fmt, MODEL, torch.bfloat16)
+            have = to_blob(tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in got)).cpu()
+            assert torch.equal(have, want)
+        # a chunk stored by B after A started reaches A through the shared store (read-through), then sits in A's local tier
+        toks2 = generate_tokens(256, "cuda")
+        kv2 = generate_kv_cache(256, fmt, "cuda", num_layers=nl)
+        b.store(toks2, kv2)
+        key2 = a._make_key(a._prefix_hash(a._chunk_tokens(toks2))[0], fmt)
+        assert not a.engine_.local_store.contains(key2) and a.engine_.contains(key2)
+        got2, m2 = a.retrieve(toks2)
+        assert int(m2.sum()) == 256 and a.engine_.local_store.contains(key2)
+        # the decoded chunk is re-encoded by the fill: CacheGen is idempotent on its own output's symbols
+        got3, _ = a.retrieve(toks2)
+        for (k, v), (k1, v1) in zip(got2, got3):
+            assert torch.equal(k, k1) and torch.equal(v, v1)
+    finally:
+        conn = a.engine_.remote_store.connection
+        for e in (a, b):
+            if e is not None:
+                e.close()
+        conn.unlink()
