@@ -113,15 +113,16 @@ def gen_quant():
     np.savez_compressed(os.path.join(OUT, "quant.npz"), **store)
     print("quant.npz", len(store), "arrays")
 
-    # edge rows: all-zero, inf, nan, denormal max, single spike, negative-only
-    x = torch.randn(2, 8, 64).to(torch.bfloat16)
+    # edge rows: all-zero, inf, nan, denormal max, single spike, negative-only (own seeded generator: reproducible)
+    ge = torch.Generator().manual_seed(4242)
+    x = torch.randn(2, 8, 64, generator=ge).to(torch.bfloat16)
     x[0, 1, :] = 0
     x[1, 2, 0] = float("inf")
     x[1, 3, 5] = float("nan")
     x[0, 4, :] = 1e-40
     x[0, 5, :] = 0
     x[0, 5, 7] = -3.0
-    x[1, 6, :] = -torch.rand(64).to(torch.bfloat16)
+    x[1, 6, :] = -torch.rand(64, generator=ge).to(torch.bfloat16)
     eb = torch.tensor([32., 16.])
     q, m = torch_quant_vectorized(eb, x)
     d = do_dequantize(q.to(torch.uint8).float(), eb, m)
@@ -129,6 +130,28 @@ def gen_quant():
                         x=bits(x), sym=q.numpy(), scale=bits(m.squeeze(-1)),
                         deq_bf16=bits(d.to(torch.bfloat16)), bins=eb.to(torch.int32).numpy())
     print("quant_edge.npz rows", q[0, 1, :4].tolist(), q[1, 2, :4].tolist(), q[1, 3, :4].tolist())
+
+
+def gen_bins():
+    """The per-layer bins tables of every model the reference knows: CacheGenConfig.from_model_name
+    (cachegen_basics.py:32-78) expanded the way CacheGenSerializer.make_key_bins / make_value_bins do
+    (cachegen_encoder.py:339-350; the tensors are built on the CPU here, their .cuda() is all that is skipped)."""
+    from lmcache.storage_backend.serde.cachegen_basics import CacheGenConfig
+    out = {}
+    for name in ("mistralai/Mistral-7B-Instruct-v0.2", "lmsys/longchat-7b-16k", "Qwen/Qwen-7B",
+                 "meta-llama/Llama-3.1-8B-Instruct", "THUDM/glm-4-9b-chat"):
+        cfg = CacheGenConfig.from_model_name(name)
+        kb = torch.zeros(cfg["key_third_layers"])
+        kb[:cfg["key_first_layers"]] = cfg["key_first_bins"]
+        kb[cfg["key_first_layers"]:cfg["key_second_layers"]] = cfg["key_second_bins"]
+        kb[cfg["key_second_layers"]:cfg["key_third_layers"]] = cfg["key_third_bins"]
+        vb = torch.zeros(cfg["key_third_layers"])
+        vb[:cfg["value_first_layers"]] = cfg["value_first_bins"]
+        vb[cfg["value_first_layers"]:] = cfg["value_second_bins"]
+        out[name] = {"key_bins": [int(b) for b in kb], "value_bins": [int(b) for b in vb]}
+    with open(os.path.join(OUT, "bins.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("bins.json", {k: len(v["key_bins"]) for k, v in out.items()})
 
 
 def gen_cdf():
@@ -225,6 +248,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_hash()
     gen_quant()
+    gen_bins()
     gen_cdf()
     gen_layout()
     gen_engine()

@@ -109,6 +109,16 @@ def test_config_loaders(tmp_path):
 
 def test_cachegen_tables(oracle):
     from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
+    # the five models the reference knows, against tables generated by importing the reference
+    # (oracle/gen_golden.py gen_bins -> tests/golden/bins.json): product and oracle restate them identically
+    import json
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "bins.json")))
+    assert len(golden) == 5
+    for name, g in golden.items():
+        cfg = CacheGenConfig.from_model_name(name)
+        assert cfg.key_bins() == g["key_bins"] and cfg.value_bins() == g["value_bins"], name
+        bins, nl = oracle.cachegen_bins(name)
+        assert bins.tolist() == g["key_bins"] + g["value_bins"] and nl == len(g["key_bins"])
     for name in ("mistralai/Mistral-7B-Instruct-v0.2", "meta-llama/Llama-3.1-8B-Instruct", "THUDM/glm-4-9b-chat"):
         cfg = CacheGenConfig.from_model_name(name)
         bins, nl = oracle.cachegen_bins(name)
