@@ -194,7 +194,17 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
   u32* hist = lds_all + ENC_WAVES * (ENC_RING_WORDS / 2) + wave * ENC_TAB_DWORDS;  // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
   u16* tab = reinterpret_cast<u16*>(hist);          // [33][64] u16 CDF, written after hist is in registers
 
-  const long long gid = (long long)blockIdx.x * ENC_WAVES + wave;
+  // Workgroup -> streams.  When the streams of a chunk fill whole workgroups, consecutive workgroups take the SAME
+  // position of consecutive CHUNKS (chunk = block % nchunks): the predecessors a workgroup's placement depends on
+  // (lower positions of its own chunk) were then dispatched at least nchunks workgroups earlier and have normally
+  // published their lengths by the time it looks back -- with chunk-major order they finish at the same moment
+  // and every look-back waits for the slowest of them.
+  long long gid = (long long)blockIdx.x * ENC_WAVES + wave;
+  if (ENCODE && (a.P * a.G) % ENC_WAVES == 0) {
+    const int wpc = a.P * a.G / ENC_WAVES;  // workgroups per chunk
+    const int ch = (int)(blockIdx.x % (unsigned)a.nchunks), pos = (int)(blockIdx.x / (unsigned)a.nchunks);
+    gid = ((long long)ch * wpc + pos) * ENC_WAVES + wave;
+  }
   if (gid >= ngroups_total) return;
   const int g = (int)(gid % a.G);
   const long long pc = gid / a.G;
