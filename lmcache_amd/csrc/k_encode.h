@@ -98,7 +98,7 @@ __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, c
   }
 }
 
-#define ENC_WAVES 4           // waves (= group streams) per workgroup (8 measured 2 % slower)
+#define ENC_WAVES 4           // waves (= group streams) per workgroup (2 and 8 measured 1-2 % slower)
 #define ENC_TAB_DWORDS 1056   // 4224 B per wave: histogram [32][64] u16, then (aliased) CDF table [33][64] u16
 #define ENC_RING_WORDS 256    // + a 512-B staging ring for the renormalisation words (flushed 256 B at a time)
 #define ENC_WAVE_DWORDS (ENC_TAB_DWORDS + ENC_RING_WORDS / 2)
