@@ -10,8 +10,10 @@ a single `batch_isend_irecv` (ncclGroupStart/End underneath on the "nccl" = RCCL
 
 The exchange is SPMD: every rank of the group calls `exchange_put` / `exchange_get` at the same point
 (e.g. a prefill instance and a decode instance at a hand-over, or N replicas at a scheduling tick).
-Control metadata (who wants which key, which sizes) travels with `all_gather_object`; payloads travel as
-uint8 tensors -- device tensors when the group's backend is nccl/RCCL, CPU tensors under gloo (which is
+Control metadata (who wants which key, which sizes) travels as FIXED-SIZE records in uint8 tensors -- 256 bytes
+per (key, three integers), the counterpart of the reference's 158-byte ClientMetaMessage
+(lmcache/protocol.py:45-47) -- with one `all_gather` of the counts and one of the padded record arrays: no
+pickled Python objects on the wire; payloads travel as uint8 tensors -- device tensors when the group's backend is nccl/RCCL, CPU tensors under gloo (which is
 how the logic is tested without GPUs, tests/test_distributed_cpu.py).
 
 Blobs are opaque here (the bytes `CacheGenSerializer.to_bytes` / `lmc_encode_chunks` produce), exactly as
@@ -56,14 +58,47 @@ class XgmiShardStore:
             return t.to(self.device).contiguous()
         return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(self.device)
 
+    # ------------------------------------------------------------------ control plane: fixed-size records
+    _REC = 256  # bytes per record: key (<= 224 bytes, zero padded) | key length | three int64
+
+    def _gather_records(self, recs: Sequence[Tuple[str, int, int, int]]) -> List[List[Tuple[str, int, int, int]]]:
+        """all_gather of every rank's list of (key, a, b, c) records -> one list per rank."""
+        import struct
+        n = len(recs)
+        cnt = torch.tensor([n], dtype=torch.int64, device=self.device)
+        counts = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(counts, cnt, group=self.group)
+        counts = [int(c.item()) for c in counts]
+        mx = max(counts + [1])
+        buf = bytearray(mx * self._REC)
+        for i, (k, a, b, c) in enumerate(recs):
+            kb = k.encode("utf-8")
+            if len(kb) > 224:
+                raise ValueError("key longer than 224 bytes")
+            off = i * self._REC
+            buf[off:off + len(kb)] = kb
+            struct.pack_into("<qqqq", buf, off + 224, len(kb), a, b, c)
+        mine = torch.frombuffer(buf, dtype=torch.uint8).to(self.device)
+        parts = [torch.empty(mx * self._REC, dtype=torch.uint8, device=self.device) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        out = []
+        for r in range(self.world):
+            raw = parts[r].cpu().numpy().tobytes()
+            lst = []
+            for i in range(counts[r]):
+                off = i * self._REC
+                kl, a, b, c = struct.unpack_from("<qqqq", raw, off + 224)
+                lst.append((raw[off:off + kl].decode("utf-8"), a, b, c))
+            out.append(lst)
+        return out
+
     # ------------------------------------------------------------------ collective: route blobs to their owners
     def exchange_put(self, items: Sequence[Tuple[str, object]]) -> int:
         """Every rank contributes (key, blob) pairs; each blob ends up in its owner's shard.
         Returns the number of blobs this rank now owns from this call."""
         mine = [(k, self._as_blob(b)) for k, b in items]
-        meta = [(k, int(t.numel()), self.owner(k)) for k, t in mine]
-        all_meta: List[Optional[list]] = [None] * self.world
-        dist.all_gather_object(all_meta, meta, group=self.group)
+        all_meta = [[(k, n, o) for k, n, o, _ in lst]
+                    for lst in self._gather_records([(k, int(t.numel()), self.owner(k), 0) for k, t in mine])]
         ops, recvs = [], []
         for k, t in mine:  # my blobs that live elsewhere
             o = self.owner(k)
@@ -92,8 +127,7 @@ class XgmiShardStore:
         """Every rank asks for its own list of keys; returns the blobs (None for a miss, never raises on a
         miss -- the contract of LMCBackendInterface.get, abstract_backend.py:47-63)."""
         want = list(keys)
-        all_want: List[Optional[list]] = [None] * self.world
-        dist.all_gather_object(all_want, want, group=self.group)
+        all_want = [[k for k, _, _, _ in lst] for lst in self._gather_records([(k, 0, 0, 0) for k in want])]
         # what I can serve: (requester, position in its list, size or -1)
         serve = []
         for r in range(self.world):
@@ -101,8 +135,8 @@ class XgmiShardStore:
                 if self.owner(k) == self.rank:
                     t = self.shard.get(k)
                     serve.append((r, pos, -1 if t is None else int(t.numel())))
-        all_serve: List[Optional[list]] = [None] * self.world
-        dist.all_gather_object(all_serve, serve, group=self.group)
+        all_serve = [[(r, pos, n) for _, r, pos, n in lst]
+                     for lst in self._gather_records([("", r, pos, n) for r, pos, n in serve])]
         out: List[Optional[torch.Tensor]] = [None] * len(want)
         ops = []
         for r, pos, n in serve:  # sends, in my serve order

@@ -730,3 +730,74 @@ def test_hybrid_backend_two_instances_share_through_xgmi(oracle):
             if e is not None:
                 e.close()
         conn.unlink()
+
+
+# ------------------------------------------------------------------ the BASELINE.json configs at their full sizes
+def test_baseline_config0_full_size_lossless():
+    """BASELINE configs[0] as written: fp16 KV [32 layers, 32 heads, 4096 tok, 128 hd] (2 GiB, "huggingface"
+    layout [H,T,D] per layer), chunk_size 256, store -> retrieve through the engine with the raw pinned-host tier
+    (16 chunks of 128 MiB): exact; and the same shape through the remote torch serde on the first 1024 tokens."""
+    fmt, nl, H, D, T = "huggingface", 32, 32, 128, 4096
+    g = torch.Generator(device="cuda").manual_seed(0)
+    kv = tuple((torch.rand((H, T, D), generator=g, device="cuda").to(torch.float16),
+                torch.rand((H, T, D), generator=g, device="cuda").to(torch.float16)) for _ in range(nl))
+    toks = torch.randint(0, 32000, (T,), generator=torch.Generator().manual_seed(0))
+    engine = LMCacheEngine(make_cfg("cpu", 256), LMCacheEngineMetadata("test_model", 1, 0, fmt, "half"))
+    try:
+        engine.store(toks, kv)
+        assert len(engine.engine_.dict) == 16
+        ret, m = engine.retrieve(toks)
+        assert int(m.sum()) == T
+        for (k, v), (k0, v0) in zip(ret, kv):
+            assert k.dtype == torch.float16 and torch.equal(k, k0) and torch.equal(v, v0)
+        del ret
+    finally:
+        engine.close()
+    remote = LMCacheEngine(make_cfg("mem://c0torch:0", 256), LMCacheEngineMetadata("test_model", 1, 0, fmt, "half"))
+    try:
+        part = tuple((k[:, :1024], v[:, :1024]) for k, v in kv)
+        remote.store(toks[:1024], part)
+        ret, m = remote.retrieve(toks[:1024])
+        assert int(m.sum()) == 1024
+        for (k, v), (k0, v0) in zip(ret, part):
+            assert torch.equal(k, k0) and torch.equal(v, v0)
+    finally:
+        remote.close()
+
+
+def test_baseline_config3_rank_shape_full_size(oracle):
+    """BASELINE configs[3], one TP rank at full size: Llama-3-70B, TP = 8 -> 80 layers x 1 KV head x 128, 32 768
+    tokens (1.25 GiB), CacheGen chunks offloaded to pinned host DRAM under keys that carry (world_size 8, worker 3).
+    Every decoded value is within the quantisation bound of the original; two sampled chunks equal the oracle."""
+    fmt, cs, nl, H, D, T = "vllm", 256, 80, 1, 128, 32768
+    model = "Llama-3-70B"
+    g = torch.Generator(device="cuda").manual_seed(3)
+    kv = tuple((torch.randn((T, H, D), generator=g, device="cuda").to(torch.bfloat16),
+                torch.randn((T, H, D), generator=g, device="cuda").to(torch.bfloat16)) for _ in range(nl))
+    toks = torch.randint(0, 128000, (T,), generator=torch.Generator().manual_seed(3))
+    engine = LMCacheEngine(make_cfg("cachegen-host", cs), LMCacheEngineMetadata(model, 8, 3, fmt, "bfloat16"))
+    try:
+        engine.store(toks, kv)
+        assert len(engine.engine_.dict) == 128
+        assert all(k.world_size == 8 and k.worker_id == 3 for k in engine.engine_.dict)
+        ret, m = engine.retrieve(toks)
+        assert int(m.sum()) == T
+        from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
+        bins = CacheGenConfig.from_model_name(model).plane_bins(nl)
+        for l, ((k, v), (k0, v0)) in enumerate(zip(ret, kv)):
+            for x, x0, b in ((k, k0, bins[l]), (v, v0, bins[nl + l])):
+                mx = x0.float().abs().amax(dim=(1, 2), keepdim=True)
+                tol = mx / (2 * (b // 2 - 1)) + mx * 2.0 ** -7
+                assert bool(((x.float() - x0.float()).abs() <= tol).all()), l
+        for t0 in (0, T - cs):
+            part = tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in kv)
+            blob = to_blob(part).cpu()
+            L_, _, T_, H_, D_ = blob.shape
+            bits, code = oracle.torch_to_bits(blob.reshape(L_, 2, T_, H_ * D_))
+            sym, scale = oracle.quantize(bits, code, np.array(bins, np.int32))
+            want = oracle.bits_to_torch(oracle.dequantize(sym, scale, code, np.array(bins, np.int32), oracle.BF16),
+                                        oracle.BF16).reshape(L_, 2, T_, H_, D_)
+            have = to_blob(tuple((k[t0:t0 + cs], v[t0:t0 + cs]) for k, v in ret)).cpu()
+            assert torch.equal(have, want)
+    finally:
+        engine.close()
