@@ -19,8 +19,8 @@
 // column in LDS ([entry][lane] u16, bank = lane/2: conflict free), state
 // update, ballot/mbcnt pop of 16-bit words.  The words come from a 512-word LDS
 // ring refilled half a ring ahead of the consumer with coalesced loads, so no
-// global-memory latency sits on the per-token dependency chain.  6.1 KiB of
-// LDS per wave -> 6 waves per SIMD.
+// global-memory latency sits on the per-token dependency chain.  4.9 KiB of
+// LDS per wave -> 8 waves per SIMD.
 #pragma once
 #include "lmc_device.h"
 
@@ -37,10 +37,10 @@ struct DecodeArgs {
   u32* status;
 };
 
-// per-wave LDS: cdfT [33][64] u16 (4224) | word ring: 64-word mirror prefix + 512 x u16 (1152) | lut 32 x f32 (128)
+// per-wave LDS: cdfT [33][64] u16 (4224) | word ring: 256 x u16 + 64-word mirror (640) | lut 32 x f32 (128)
 #define DEC_CDF_BYTES 4224
-#define DEC_RING_WORDS 512
-#define DEC_RING_BYTES (2 * (64 + DEC_RING_WORDS))
+#define DEC_RING_WORDS 256
+#define DEC_RING_BYTES (2 * (DEC_RING_WORDS + 64))
 #define DEC_WAVE_BYTES (DEC_CDF_BYTES + DEC_RING_BYTES + 128)
 
 
@@ -52,7 +52,7 @@ __device__ __forceinline__ u64 uniform_ptr(const void* p) {  // a pointer every 
 }
 
 template <bool SYMOUT, int DT_OUT, bool PAGED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_decode(DecodeArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k_decode(DecodeArgs a) {
   __shared__ __attribute__((aligned(16))) u8 lds_all[4 * DEC_WAVE_BYTES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform -> SGPRs
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   if (gid >= (long long)a.nchunks * n) return;
   u8* wl = lds_all + wave * DEC_WAVE_BYTES;
   u16* cdfT = reinterpret_cast<u16*>(wl);                           // [33][64]: entry-major, bank = lane/2
-  u16* ring = reinterpret_cast<u16*>(wl + DEC_CDF_BYTES) + 64;      // stream words by consumption order; ring[-64..-1] mirrors ring[448..511]
+  u16* ring = reinterpret_cast<u16*>(wl + DEC_CDF_BYTES);           // stream words, word j at slot j % 256; slots 256..319 mirror 0..63
   float* lut = reinterpret_cast<float*>(wl + DEC_CDF_BYTES + DEC_RING_BYTES);  // (q - C) / C
 
   const int chunk = (int)(gid / n);
@@ -139,10 +139,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
         }
       }
     }
-    cdf_column_to_lds(hreg, T, nsym, cdfT, lane);
-    if (!active) {  // idle lanes: any strictly increasing column keeps the search in range
+    wave_lds_fence();  // the staging is dead (every lane holds its counts): the table takes its place
+    if (nsym <= 16u) {
+      // planes with at most 16 symbols (16 / 17 bins: most of them): 16 entries of 32 bits in four quarters,
+      // tab32[quarter][lane][4], entry i = cdf[i] << 16 | (cdf[i + 1] - cdf[i]): one ds_read_b128 brings a quarter
+      cdf_column_to_lds_wide(hreg, T, nsym, reinterpret_cast<u32*>(cdfT), lane);
+      if (!active) {  // idle lanes: any strictly increasing column keeps the search in range
 #pragma unroll
-      for (int i = 0; i < 33; i++) cdfT[i * 64 + lane] = (u16)i;
+        for (int i = 0; i < 16; i++) reinterpret_cast<u32*>(cdfT)[(i >> 2) * 256 + lane * 4 + (i & 3)] = ((u32)i << 16) | 1u;
+      }
+    } else {
+      cdf_column_to_lds(hreg, T, nsym, cdfT, lane);
+      if (!active) {
+#pragma unroll
+        for (int i = 0; i < 33; i++) cdfT[i * 64 + lane] = (u16)i;
+      }
     }
   }
   // ---- dequantisation LUT; the per-token scales are fetched 64 tokens at a time inside the loop ----
@@ -167,47 +178,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   }
   const u32 nwords = ((end - start) >> 1) - 128u;  // 16-bit words in front of the 64 states
   u32 x = (u32)words[nwords + 2 * lane] | ((u32)words[nwords + 2 * lane + 1] << 16);
-  // Word k (k = 0, 1, ... in the order the decoder consumes them) is words[nwords - 1 - k]; it is staged
-  // in ring[k % 512].  The ring is refilled half a ring (256 words) at a time: the loads of the next half
-  // are ISSUED into registers when at most 384 words are ahead of the consumer and WRITTEN to the ring
-  // when at most 256 are (by then the older half is fully consumed) -- ~10 tokens later, so their
-  // latency is off the per-token dependency chain.  Reads past the end of a corrupt stream stay inside
-  // the ring (index masked, loads guarded); the final state / count check reports them.
-  u16 pend[4];
-  auto ring_issue = [&](u32 k0) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const u32 k = k0 + i * 64 + lane;
-      pend[i] = k < nwords ? words[nwords - 1 - k] : (u16)0;
-    }
+  // The decoder consumes the stream from its end: after `e` = number of words not yet consumed, a token whose
+  // cnt lanes renormalise takes words [e - cnt, e), ascending with the lane (the encoder's append order).  The
+  // words are staged in STREAM ORDER in a 256-word LDS ring, word j at slot j % 256, in blocks of 128 words
+  // (block b = words [128 b, 128 b + 128), one coalesced dword per lane): two blocks are resident, the loads of
+  // the next lower one are ISSUED into a register when e <= 128 top + 64 (top = upper resident block; that is at
+  // least one token, normally 4-5, before its slots are free) and WRITTEN to the ring when e <= 128 top (the
+  // upper block is consumed; a token takes at most 64 words, so the block below covers the next token alone):
+  // their latency is off the per-token dependency chain.  Slots 256..319 mirror slots 0..63, so a token's words
+  // are at consecutive slots whatever e.  A corrupt stream cannot leave the ring (slot index masked, rank < 64,
+  // loads guarded); the final state / count check reports it.
+  typedef __attribute__((address_space(3))) u32* lds_u32w;
+  const lds_u32w ring32 = (lds_u32w)reinterpret_cast<u32*>(ring);
+  const LMC_GLOBAL u32* const words32 = (const LMC_GLOBAL u32*)words;  // streams start 16-byte aligned
+  auto block_load = [&](int b) -> u32 {
+    const int d = 64 * b + lane;  // dword = words 2d, 2d + 1; the 128 state words that follow belong to the stream too
+    return (b >= 0 && (u32)(2 * d + 1) < nwords + 128u) ? words32[d] : 0u;
   };
-  auto ring_commit = [&](u32 k0) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) ring[(k0 + i * 64 + lane) & (DEC_RING_WORDS - 1)] = pend[i];
-    if (k0 & 256u) ring[lane - 64] = pend[3];  // mirror of ring[448 + lane]: lets the consumer index without a wrap
+  auto block_commit = [&](int b, u32 v) {
+    ring32[((b & 1) << 6) + lane] = v;
+    if (!(b & 1) && lane < 32) ring32[128 + lane] = v;  // mirror of slots 0..63
   };
-  ring_issue(0);
-  ring_commit(0);
-  ring_issue(256);
-  ring_commit(256);
-  u32 filled = 512;     // words [0, filled) are in the ring
-  u32 consumed = 0;     // wave-uniform
-  u32 trigger = 128;    // next ring event when consumed reaches this (= filled - 384, then filled - 256)
-  u32 pending = 0;      // loads for [filled, filled + 256) are in flight
+  int top_blk = (int)((nwords + 127u) >> 7) - 1;  // block of the last word (-1: no words at all)
+  block_commit(top_blk, block_load(top_blk));
+  block_commit(top_blk - 1, block_load(top_blk - 1));
+  int e = (int)nwords;             // wave-uniform
+  int trig = 128 * top_blk + 64;   // next ring event when e <= trig
+  u32 pending = 0, pend = 0;       // the loads of block top_blk - 2 are in flight (in pend)
   wave_lds_fence();
 
   // The symbol search is a binary search over the lane's CDF column.  Symbols are 0 .. nsym-1 (nsym = bins - 1),
   // so planes with nsym <= 16 (16 bins: most of them) search entries 0..15 only (TOP = 4), the others 0..31
   // (TOP = 8).  Its first two levels run on three pivots held in registers.
   typedef const __attribute__((address_space(3))) u16* lds_u16p;  // 32-bit LDS pointers: no generic-pointer math
-  const lds_u16p col = (lds_u16p)cdfT + lane;
-  const u32 top = nsym <= 16u ? 4u : 8u;  // wave-uniform
-  const lds_u16p colB = col + 2u * top * 64u;
-  const u32 pA = col[top * 64u], pB = colB[0], pC = col[3u * top * 64u];
+  typedef const __attribute__((address_space(3))) u32* lds_u32p;
   typedef const __attribute__((address_space(3))) float* lds_f32p;
-  const u32 col_addr = (u32)(size_t)col;
-  const u32 lut_bias = col_addr - ((u32)(size_t)(lds_f32p)lut << 5);
-  const lds_u16p ringl = (lds_u16p)ring;
+  const bool wide = nsym <= 16u;             // wave-uniform: 16 packed 32-bit entries in quarters, else 33 u16 entries
+  const u32 top = wide ? 4u : 8u;
+  // the lane's column: u16 entries 128 B apart, or (wide) four 16-byte quarters 1024 B apart
+  const u32 col_addr = (u32)(size_t)(lds_u16p)cdfT + ((u32)lane << (wide ? 4 : 1));
+  const u32 colB_addr = col_addr + 2048u;    // entry 16 of 33 / quarter 2 of 4
+  // first two search levels: three pivots in registers (wide: whole entries, compared against slot << 16 | 0xffff)
+  const u32 pA = wide ? *(lds_u32p)(size_t)(col_addr + 1024u) : (u32)*(lds_u16p)(size_t)(col_addr + 1024u);
+  const u32 pB = wide ? *(lds_u32p)(size_t)colB_addr : (u32)*(lds_u16p)(size_t)colB_addr;
+  const u32 pC = wide ? *(lds_u32p)(size_t)(col_addr + 3072u) : (u32)*(lds_u16p)(size_t)(col_addr + 3072u);
+  const u32 lut_addr = (u32)(size_t)(lds_f32p)lut;
+  u32 lut_lo = lut_addr, lut_hi = lut_addr + 32u;  // LUT entries 0 and 8: in VGPRs, one v_cndmask picks between them
+  asm volatile("" : "+v"(lut_lo), "+v"(lut_hi));
+  // narrow: lut[s] with s = (qa - col) >> 7 is at ((qa - col) >> 5) + &lut = (qa - lut_bias) >> 5
+  const u32 lut_bias = col_addr - (lut_addr << 5);
+  const u64 full_exec = __builtin_amdgcn_read_exec();  // the search narrows exec and restores it from here
+  const u32 ring_addr = (u32)(size_t)(lds_u16p)ring;
   const u32 Lv = active ? LMC_RANS_L : 0u;  // idle lanes never renormalise: x < 0 is never true
 
   // destination: uniform base (SGPRs) + per-lane 32-bit byte offset
@@ -223,62 +244,118 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   }
   const int tdst0 = a.dst_tok0 + chunk * a.chunk_tokens;
 
-  // One token: search, state update, word pop; returns the LDS address of the symbol's CDF entry.
-  auto decode_token = [&](auto top_tag) -> u32 {
-    constexpr int TOP = decltype(top_tag)::value;
-    u32 slot = x & 0xffffu;
-    asm volatile("" : "+v"(slot));  // keep `slot` a plain VGPR: SDWA compares would cost a wait state each
-    // q walks the column: q = &cdf[s] for the largest probed s with cdf[s] <= slot
-    const bool geB = pB <= slot;
-    const u32 pm = geB ? pC : pA;
-    lds_u16p q = geB ? colB : col;
-    {
-      const lds_u16p q2 = q + TOP * 64;
-      q = pm <= slot ? q2 : q;
-    }
-#pragma unroll
-    for (int step = TOP / 2; step >= 1; step >>= 1) {
-      const lds_u16p q2 = q + step * 64;
-      const u32 v = *q2;
-      q = v <= slot ? q2 : q;
-    }
-    const u32 lo = q[0], hi = q[64];  // the symbol's own two entries; entry 32 is 65536 stored as 0
-    const u32 qa = (u32)(size_t)q;
-    const u32 f = (hi - lo) & 0xffffu;
-    x = __umul24(f, x >> 16) + slot - lo;
-    const bool need = x < Lv;
-    const u64 mask = __ballot(need);
-    const u32 cnt = (u32)__popcll(mask);
-    // the encoder appended this token's words in ascending lane order; counted from the tail that is
-    // descending, so rank r of cnt takes consumption index consumed + cnt - 1 - r
-    const int last = (int)((consumed + cnt - 1u) & (DEC_RING_WORDS - 1));  // scalar; last - rank is in [-63, 511]
-    if (need) x = (x << 16) | (u32)ringl[last - (int)lane_rank(mask)];
+  // The word pop of one token (after the state update): renormalising lanes take this step's words.  Branch
+  // free: every lane reads a slot (rank < 64 keeps it inside ring + mirror), the renormalising ones keep it.
+  auto decode_pop = [&](u64 mask) {  // mask = lanes with x < L
+    e -= (int)__popcll(mask);
+    const u32 sbase = ring_addr + (((u32)e & (DEC_RING_WORDS - 1)) << 1);   // scalar: slot of word e - cnt
+    u32 w = *(lds_u16p)(size_t)(sbase + (lane_rank(mask) << 1));
+    asm volatile("" : "+v"(w));  // read by every lane: no exec masking around the pop
+    u32 xw;
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(xw) : "v"(w), "v"(x), "s"(0x01000504u));  // x << 16 | w
+    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(xw), "s"(mask));
     // the ring bookkeeping is wave-uniform: pin it to SGPRs so its tests are scalar branches
-    consumed += cnt;
-    if (consumed >= trigger) {
+    if (__builtin_expect(e <= trig, 0)) {
       if (pending == 0u) {
-        ring_issue(filled);
+        pend = block_load(top_blk - 2);
         pending = 1u;
-        trigger = (u32)__builtin_amdgcn_readfirstlane((int)(filled - 256u));
+        trig = 128 * top_blk;
       } else {
-        wave_lds_fence();  // every lane's reads of the older half are done
-        ring_commit(filled);
-        filled = (u32)__builtin_amdgcn_readfirstlane((int)(filled + 256u));
+        wave_lds_fence();  // every lane's reads of the upper block are done
+        block_commit(top_blk - 2, pend);
+        top_blk = __builtin_amdgcn_readfirstlane(top_blk - 1);
         pending = 0u;
-        trigger = (u32)__builtin_amdgcn_readfirstlane((int)(filled - 384u));
+        trig = 128 * top_blk + 64;
         wave_lds_fence();
       }
     }
-    return qa;
+  };
+  // One token: search, state update, word pop.  Returns the symbol as an LDS address: of its dequantisation LUT
+  // entry (wide) or of its CDF entry (narrow); `lv` receives the LUT value.
+  // A search level on exec:  v_cmpx_le_u32 (exec = lanes whose pivot <= slot) ; moves / adds of those lanes ;
+  // s_mov exec, full -- the selects become double-rate moves and the compare feeds no v_cndmask.
+#define LMC_SEARCH_STEP(q, piv, slot, STEP_BYTES)                                                   \
+  asm("v_cmpx_le_u32_e32 vcc, %1, %2\n\tv_add_u32_e32 %0, %3, %0\n\ts_mov_b64 exec, %4"            \
+      : "+v"(q) : "v"(piv), "v"(slot), "i"(STEP_BYTES), "s"(full_exec) : "vcc")
+  auto decode_token = [&](auto top_tag, float& lv) -> u32 {
+    constexpr int TOP = decltype(top_tag)::value;
+    constexpr bool WIDE = TOP == 4;
+    if constexpr (WIDE) {
+      // Planes with at most 16 symbols.  Entry i = cdf[i] << 16 | freq[i], so "cdf[i] <= slot" is one unsigned
+      // compare of the whole entry with slot << 16 | 0xffff.  Levels 1-2 on the register pivots pick a quarter,
+      // ONE ds_read_b128 brings its four entries, levels 3-4 select among them in registers: a single LDS round
+      // trip per token in the search, and `r` follows the symbol as the address of its LUT entry.
+      u32 sl;
+      u64 mask;
+      asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(sl) : "v"(x), "v"(0xffffu));
+      const bool geB = pB <= sl;
+      const u32 pm = geB ? pC : pA;
+      u32 q = geB ? colB_addr : col_addr;
+      u32 r = geB ? lut_hi : lut_lo;
+      asm("v_cmpx_le_u32_e32 vcc, %2, %3\n\tv_add_u32_e32 %0, 0x400, %0\n\tv_add_u32_e32 %1, 16, %1\n\ts_mov_b64 exec, %4"
+          : "+v"(q), "+v"(r) : "v"(pm), "v"(sl), "s"(full_exec) : "vcc");
+      const u32x4_t e4 = *(const __attribute__((address_space(3))) u32x4_t*)(size_t)q;
+      u32 e0 = e4.x, e1 = e4.y, d;
+      // levels 3-4 among the quarter's entries, then x = freq * (x >> 16) + (slot - start) (start is the entry's
+      // upper half, freq its lower half) and the renormalisation test, as one block: no hazard padding in between
+      asm("v_cmpx_le_u32_e32 vcc, %[e2], %[sl]\n\t"
+          "v_mov_b32_e32 %[e0], %[e2]\n\t"
+          "v_mov_b32_e32 %[e1], %[e3]\n\t"
+          "v_add_u32_e32 %[r], 8, %[r]\n\t"
+          "s_mov_b64 exec, %[full]\n\t"
+          "v_cmpx_le_u32_e32 vcc, %[e1], %[sl]\n\t"
+          "v_mov_b32_e32 %[e0], %[e1]\n\t"
+          "v_add_u32_e32 %[r], 4, %[r]\n\t"
+          "s_mov_b64 exec, %[full]\n\t"
+          "v_sub_u32_sdwa %[d], %[x], %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+          "v_mad_u32_u16 %[x], %[x], %[e0], %[d] op_sel:[1,0,0,0]\n\t"
+          "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
+          : [e0] "+v"(e0), [e1] "+v"(e1), [r] "+v"(r), [x] "+v"(x), [d] "=&v"(d), [m] "=&s"(mask)
+          : [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [full] "s"(full_exec), [lv] "v"(Lv)
+          : "vcc");
+      if (!SYMOUT) lv = *(lds_f32p)(size_t)r;  // issued here: back by the time the word pop below has its word
+      return decode_pop(mask), r;
+    } else {
+      constexpr u32 ESTRIDE = 128u;  // bytes between entries of a lane's column
+      u32 slot = x & 0xffffu;
+      asm volatile("" : "+v"(slot));  // keep `slot` a plain VGPR: SDWA compares would cost a wait state each
+      // q walks the column: q = &cdf[s] for the largest probed s with cdf[s] <= slot.  Two levels on register pivots,
+      const bool geB = pB <= slot;
+      const u32 pm = geB ? pC : pA;
+      u32 q = geB ? colB_addr : col_addr;
+      LMC_SEARCH_STEP(q, pm, slot, TOP * ESTRIDE);
+      // ... the others on the column in LDS
+#pragma unroll
+      for (int step = TOP / 2; step >= 1; step >>= 1) {
+        const u32 v = *(lds_u16p)(size_t)(q + step * ESTRIDE);
+        if (step == 4) LMC_SEARCH_STEP(q, v, slot, 4 * ESTRIDE);
+        else if (step == 2) LMC_SEARCH_STEP(q, v, slot, 2 * ESTRIDE);
+        else LMC_SEARCH_STEP(q, v, slot, 1 * ESTRIDE);
+      }
+      const u32 lo = *(lds_u16p)(size_t)q, hi = *(lds_u16p)(size_t)(q + ESTRIDE);  // entry 32 is 65536 stored as 0
+      if (!SYMOUT) lv = *(lds_f32p)(size_t)((q - lut_bias) >> 5);
+      const u32 f = (hi - lo) & 0xffffu;
+      x = __umul24(f, x >> 16) + slot - lo;
+      return decode_pop(__ballot(x < Lv)), q;
+    }
   };
 
   const u32 nskip = SYMOUT ? 0u : (tdst0 < 0 ? min(T, (u32)(-tdst0)) : 0u);  // tokens that land below dst token 0
   auto run = [&](auto src_tag, auto top_tag) {
     constexpr bool SRC_BF16 = decltype(src_tag)::value;
-    for (u32 t = 0; t < nskip; t++) (void)decode_token(top_tag);  // retrieve()'s first-chunk trim: decode, do not store
-    // !PAGED: the row of token t starts at rowp (uniform), one stride_token further each token
-    LMC_GLOBAL u8* rowp = (LMC_GLOBAL u8*)ubase + (long long)(tdst0 + (int)nskip) * a.dst.stride_token * 2;
+    constexpr bool WIDE = decltype(top_tag)::value == 4;
+    for (u32 t = 0; t < nskip; t++) {  // retrieve()'s first-chunk trim: decode, do not store
+      float lv_skip;
+      (void)decode_token(top_tag, lv_skip);
+    }
+    // !PAGED: the rows of this stream through a raw buffer descriptor: base = row of the first stored token,
+    // soffset (scalar) = one stride_token further each token, voffset = the lane's channel.  The descriptor's range
+    // check (on voffset only) drops the stores of idle lanes, whose voffset is out of range: no exec masking.
     const long long row_step = a.dst.stride_token * 2;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(ubase + (u64)((long long)(tdst0 + (int)nskip) * row_step)), (short)0, (int)0xfffffff0u, 0x00020000);
+    const u32 voff = active ? lane_off : 0xfffffff8u;
+    u32 soff = 0;
     // per-token scales: lane i of `sc` holds the fp32 scale of token t0 + i (64 tokens per block), fetched with
     // one coalesced load a block ahead and handed to all lanes with v_readlane
     auto scale_bits = [&](u32 tb) -> u32 { return (!SYMOUT && tb + lane < T) ? (u32)scl[tb + lane] : 0u; };
@@ -288,26 +365,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
     u32 sc_next = scale_bits(nskip);
     u32 off = lane_off;
     for (u32 t0 = nskip; t0 < T; t0 += 64) {
-      const u32 t1 = min(T, t0 + 64u);
+      const u32 nt = (u32)__builtin_amdgcn_readfirstlane((int)min(T - t0, 64u));
       const float sc = scale_f32(sc_next);
-      sc_next = scale_bits(t1);
-      for (u32 t = t0; t < t1; t++) {
-        const u32 qa = decode_token(top_tag);
+      sc_next = scale_bits(t0 + nt);
+      for (u32 i = 0; i < nt; i++) {
+        float lv = 0.0f;
+        const u32 sa = decode_token(top_tag, lv);
         if (SYMOUT) {
-          if (active) *((LMC_GLOBAL int8_t*)(ubase + (u64)t * a.C) + lane_off) = (int8_t)((qa - col_addr) >> 7);
+          const u32 sym = WIDE ? (sa - lut_addr) >> 2 : (sa - col_addr) >> 7;
+          if (active) *((LMC_GLOBAL int8_t*)(ubase + (u64)(t0 + i) * a.C) + lane_off) = (int8_t)sym;
         } else {
-          const float scale = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), (int)(t - t0)));
-          if (active) {
-            // lut[s] with s = (qa - col) / 128: its LDS address is ((qa - col) >> 5) + &lut = (qa - lut_bias) >> 5
-            const float val = *(lds_f32p)(size_t)((qa - lut_bias) >> 5) * scale;
-            u16 bits;
-            if (DT_OUT == LMC_DTYPE_BF16) bits = __builtin_bit_cast(unsigned short, (__bf16)val);  // v_cvt_pk_bf16_f32, RNE
-            else bits = (u16)f2fp16(val);
-            LMC_GLOBAL u8* const row = PAGED ? (LMC_GLOBAL u8*)ubase + lmc_tok_off(a.dst, tdst0 + (int)t) * 2 : rowp;
-            asm volatile("" : "+v"(off));  // keeps the zero-extension next to the store: SGPR base + 32-bit VGPR offset
-            __builtin_nontemporal_store(bits, (LMC_GLOBAL u16*)(row + off));  // written once, read by someone else later
+          const float scale = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), (int)i));
+          const float val = lv * scale;
+          u16 bits;
+          if (DT_OUT == LMC_DTYPE_BF16) bits = __builtin_bit_cast(unsigned short, (__bf16)val);  // v_cvt_pk_bf16_f32, RNE
+          else bits = (u16)f2fp16(val);
+          if (PAGED) {
+            if (active) {
+              LMC_GLOBAL u8* const row = (LMC_GLOBAL u8*)ubase + lmc_tok_off(a.dst, tdst0 + (int)(t0 + i)) * 2;
+              asm volatile("" : "+v"(off));  // keeps the zero-extension next to the store: SGPR base + 32-bit VGPR offset
+              __builtin_nontemporal_store(bits, (LMC_GLOBAL u16*)(row + off));  // written once, read by someone else later
+            }
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b16((short)bits, rsrc, (int)voff, (int)soff, 2 /* nt */);
+            soff += (u32)row_step;
           }
-          rowp += row_step;
         }
       }
     }
@@ -321,7 +403,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   }
 
   const bool state_bad = active && x != LMC_RANS_L;
-  if (consumed != nwords || __ballot(state_bad)) {
+  if (e != 0 || __ballot(state_bad)) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_STREAM);
   }
 }

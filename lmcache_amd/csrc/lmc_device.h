@@ -204,6 +204,29 @@ __device__ __forceinline__ void cdf_column_to_lds(const u32 (&hreg)[16], u32 T, 
   }
 }
 
+// The same column for planes with at most 16 symbols, in the decoder's packed form: 16 entries of 32 bits,
+// entry i = cdf[i] << 16 | (cdf[i + 1] - cdf[i]) (start and frequency of symbol i; cdf[16] <= 65520), stored as
+// tab32[i / 4][lane][i % 4]: a lane's four entries of a quarter are one aligned 16-byte read, bank-conflict free.
+__device__ __forceinline__ void cdf_column_to_lds_wide(const u32 (&hreg)[16], u32 T, u32 nsym, u32* tab32, int lane) {
+  const u32 magic = (T == 1u) ? 0xffffffffu : (u32)(0x100000000ull / T);
+  const bool pow2 = (T & (T - 1u)) == 0u;
+  const u32 sh = 31u - (u32)__builtin_clz(T);
+  const u32 half_m1 = sh ? (1u << (sh - 1u)) - 1u : 0u;
+  u32 n = hreg[0] & 0xffffu, prev = 0;
+#pragma unroll
+  for (int i = 1; i <= 16; i++) {
+    u32 ci = LMC_CDF_SCALE + (u32)i;
+    if ((u32)i < nsym) {
+      const u32 v = n * LMC_CDF_SCALE;
+      if (pow2) ci = (sh ? (v + half_m1 + ((v >> sh) & 1u)) >> sh : v) + (u32)i;
+      else ci = rne_div_u32(v, T, magic) + (u32)i;
+    }
+    tab32[((i - 1) >> 2) * 256 + lane * 4 + ((i - 1) & 3)] = (prev << 16) | (ci - prev);
+    prev = ci;
+    if (i < 16) n += (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+  }
+}
+
 // One rANS state update x' = ((x / f) << 16) + (x % f) + st for x < f * 2^16, 1 <= f < 2^16,
 // c = 2^16 - f.  With q = x / f:  x' = x + q * c + st, so only the quotient is needed.
 // qe = trunc(fma(float(x), rcp(f), -0.05)): float(x) is off by <= 2^-24 relative, v_rcp_f32 by
