@@ -225,6 +225,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   const u32 lut_addr = (u32)(size_t)(lds_f32p)lut;
   u32 lut_lo = lut_addr, lut_hi = lut_addr + 32u;  // LUT entries 0 and 8: in VGPRs, one v_cndmask picks between them
   asm volatile("" : "+v"(lut_lo), "+v"(lut_hi));
+  u32 c_ffff = 0xffffu;
+  asm volatile("" : "+v"(c_ffff));
   // narrow: lut[s] with s = (qa - col) >> 7 is at ((qa - col) >> 5) + &lut = (qa - lut_bias) >> 5
   const u32 lut_bias = col_addr - (lut_addr << 5);
   const u64 full_exec = __builtin_amdgcn_read_exec();  // the search narrows exec and restores it from here
@@ -249,11 +251,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   auto decode_pop = [&](u64 mask) {  // mask = lanes with x < L
     e -= (int)__popcll(mask);
     const u32 sbase = ring_addr + (((u32)e & (DEC_RING_WORDS - 1)) << 1);   // scalar: slot of word e - cnt
-    u32 w = *(lds_u16p)(size_t)(sbase + (lane_rank(mask) << 1));
-    asm volatile("" : "+v"(w));  // read by every lane: no exec masking around the pop
-    u32 xw;
-    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(xw) : "v"(w), "v"(x), "s"(0x01000504u));  // x << 16 | w
-    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(xw), "s"(mask));
+    // under exec = mask: rank, slot address, word, x = x << 16 | word; then exec is restored.  No branch around it
+    // (an empty mask makes the four instructions no-ops) and no select afterwards.
+    u32 t;
+    asm volatile("s_mov_b64 exec, %[m]\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], %[mlo], 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], %[mhi], %[t]\n\t"
+                 "v_lshl_add_u32 %[t], %[t], 1, %[sb]\n\t"
+                 "ds_read_u16 %[t], %[t]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_perm_b32 %[x], %[t], %[x], %[sel]\n\t"
+                 "s_mov_b64 exec, %[full]"
+                 : [x] "+v"(x), [t] "=&v"(t)
+                 : [m] "s"(mask), [mlo] "s"((u32)mask), [mhi] "s"((u32)(mask >> 32)), [sb] "s"(sbase),
+                   [sel] "s"(0x01000504u), [full] "s"(full_exec)
+                 : "memory");
     // the ring bookkeeping is wave-uniform: pin it to SGPRs so its tests are scalar branches
     if (__builtin_expect(e <= trig, 0)) {
       if (pending == 0u) {
@@ -285,15 +297,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       // compare of the whole entry with slot << 16 | 0xffff.  Levels 1-2 on the register pivots pick a quarter,
       // ONE ds_read_b128 brings its four entries, levels 3-4 select among them in registers: a single LDS round
       // trip per token in the search, and `r` follows the symbol as the address of its LUT entry.
-      u32 sl;
+      u32 sl, q, r, pm;
       u64 mask;
-      asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(sl) : "v"(x), "v"(0xffffu));
-      const bool geB = pB <= sl;
-      const u32 pm = geB ? pC : pA;
-      u32 q = geB ? colB_addr : col_addr;
-      u32 r = geB ? lut_hi : lut_lo;
-      asm("v_cmpx_le_u32_e32 vcc, %2, %3\n\tv_add_u32_e32 %0, 0x400, %0\n\tv_add_u32_e32 %1, 16, %1\n\ts_mov_b64 exec, %4"
-          : "+v"(q), "+v"(r) : "v"(pm), "v"(sl), "s"(full_exec) : "vcc");
+      // levels 1-2 as one block (the two wait states between v_cmp and the selects that read vcc are explicit)
+      asm("v_lshl_or_b32 %[sl], %[x], 16, %[ffff]\n\t"
+          "v_cmp_le_u32_e32 vcc, %[pB], %[sl]\n\t"
+          "s_nop 1\n\t"
+          "v_cndmask_b32_e32 %[q], %[colA], %[colB], vcc\n\t"
+          "v_cndmask_b32_e32 %[pm], %[pA], %[pC], vcc\n\t"
+          "v_cndmask_b32_e32 %[r], %[lutlo], %[luthi], vcc\n\t"
+          "v_cmpx_le_u32_e32 vcc, %[pm], %[sl]\n\t"
+          "v_add_u32_e32 %[q], 0x400, %[q]\n\t"
+          "v_add_u32_e32 %[r], 16, %[r]\n\t"
+          "s_mov_b64 exec, %[full]"
+          : [sl] "=&v"(sl), [q] "=&v"(q), [r] "=&v"(r), [pm] "=&v"(pm)
+          : [x] "v"(x), [ffff] "v"(c_ffff), [pA] "v"(pA), [pB] "v"(pB), [pC] "v"(pC), [colA] "v"(col_addr),
+            [colB] "v"(colB_addr), [lutlo] "v"(lut_lo), [luthi] "v"(lut_hi), [full] "s"(full_exec)
+          : "vcc");
       const u32x4_t e4 = *(const __attribute__((address_space(3))) u32x4_t*)(size_t)q;
       u32 e0 = e4.x, e1 = e4.y, d;
       // levels 3-4 among the quarter's entries, then x = freq * (x >> 16) + (slot - start) (start is the entry's
