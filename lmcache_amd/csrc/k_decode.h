@@ -14,13 +14,17 @@
 //                                  fp32 subtraction and IEEE division
 //   out = RNE16(t)
 //
-// One wave = one group stream, lane = channel.  Per token: first search level
-// on three register pivots, then three dependent probes of the lane's CDF
-// column in LDS ([entry][lane] u16, bank = lane/2: conflict free), state
-// update, ballot/mbcnt pop of 16-bit words.  The words come from a 512-word LDS
-// ring refilled half a ring ahead of the consumer with coalesced loads, so no
-// global-memory latency sits on the per-token dependency chain.  4.9 KiB of
-// LDS per wave -> 8 waves per SIMD.
+// One wave = one group stream, lane = channel.  Per token: two search levels on three register pivots, then
+//   planes with <= 16 symbols (16/17 bins, most planes): ONE ds_read_b128 of the lane's quarter of packed
+//     entries (cdf << 16 | freq), the last two levels as exec-predicated moves among them, and the state
+//     update straight from the selected entry (v_mad_u32_u16 with op_sel) -- one LDS round trip in the search;
+//   other planes: three dependent probes of the lane's u16 column ([entry][lane], bank = lane/2) and the
+//     symbol's two entries;
+// then the pop of 16-bit words under exec = renormalising lanes (mbcnt rank, one ds_read_u16).  The words come
+// from a 256-word LDS ring in stream order, refilled a block (128 words, one dword per lane) ahead of the
+// consumer, so no global-memory latency sits on the per-token dependency chain.  The dequantised value leaves
+// through a raw buffer store (row = scalar offset, channel = vector offset; idle lanes fall outside the
+// descriptor's range).  4.9 KiB of LDS per wave -> 8 waves per SIMD.
 #pragma once
 #include "lmc_device.h"
 
