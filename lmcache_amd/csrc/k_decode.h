@@ -348,19 +348,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       const u32 pm = geB ? pC : pA;
       u32 q = geB ? colB_addr : col_addr;
       LMC_SEARCH_STEP(q, pm, slot, TOP * ESTRIDE);
-      // ... the others on the column in LDS
-#pragma unroll
-      for (int step = TOP / 2; step >= 1; step >>= 1) {
-        const u32 v = *(lds_u16p)(size_t)(q + step * ESTRIDE);
-        if (step == 4) LMC_SEARCH_STEP(q, v, slot, 4 * ESTRIDE);
-        else if (step == 2) LMC_SEARCH_STEP(q, v, slot, 2 * ESTRIDE);
-        else LMC_SEARCH_STEP(q, v, slot, 1 * ESTRIDE);
+      // ... one on the column in LDS (step 4), then the five entries q .. q + 4 in ONE round trip: the last two
+      // levels, the symbol's start and end are picked among them by exec-predicated moves
+      {
+        const u32 v = *(lds_u16p)(size_t)(q + 4 * ESTRIDE);
+        LMC_SEARCH_STEP(q, v, slot, 4 * ESTRIDE);
       }
-      const u32 lo = *(lds_u16p)(size_t)q, hi = *(lds_u16p)(size_t)(q + ESTRIDE);  // entry 32 is 65536 stored as 0
+      u32 e0 = *(lds_u16p)(size_t)q, e1 = *(lds_u16p)(size_t)(q + ESTRIDE), e2 = *(lds_u16p)(size_t)(q + 2 * ESTRIDE);
+      const u32 e3 = *(lds_u16p)(size_t)(q + 3 * ESTRIDE), e4 = *(lds_u16p)(size_t)(q + 4 * ESTRIDE);
+      u32 h, f, d;
+      u64 mask;
+      asm("v_cmpx_le_u32_e32 vcc, %[e2], %[slot]\n\t"
+          "v_mov_b32_e32 %[e0], %[e2]\n\t"
+          "v_mov_b32_e32 %[e1], %[e3]\n\t"
+          "v_mov_b32_e32 %[e2], %[e4]\n\t"
+          "v_add_u32_e32 %[q], 0x100, %[q]\n\t"
+          "s_mov_b64 exec, %[full]\n\t"
+          "v_mov_b32_e32 %[h], %[e1]\n\t"
+          "v_cmpx_le_u32_e32 vcc, %[e1], %[slot]\n\t"
+          "v_mov_b32_e32 %[e0], %[e1]\n\t"
+          "v_mov_b32_e32 %[h], %[e2]\n\t"
+          "v_add_u32_e32 %[q], 0x80, %[q]\n\t"
+          "s_mov_b64 exec, %[full]\n\t"
+          "v_sub_u16_e32 %[f], %[h], %[e0]\n\t"       // entry 32 is 65536 stored as 0: the 16-bit difference is right
+          "v_sub_u32_e32 %[d], %[slot], %[e0]\n\t"
+          "v_mad_u32_u16 %[x], %[x], %[f], %[d] op_sel:[1,0,0,0]\n\t"
+          "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
+          : [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [q] "+v"(q), [x] "+v"(x), [h] "=&v"(h), [f] "=&v"(f),
+            [d] "=&v"(d), [m] "=&s"(mask)
+          : [e3] "v"(e3), [e4] "v"(e4), [slot] "v"(slot), [full] "s"(full_exec), [lv] "v"(Lv)
+          : "vcc");
       if (!SYMOUT) lv = *(lds_f32p)(size_t)((q - lut_bias) >> 5);
-      const u32 f = (hi - lo) & 0xffffu;
-      x = __umul24(f, x >> 16) + slot - lo;
-      return decode_pop(__ballot(x < Lv)), q;
+      return decode_pop(mask), q;
     }
   };
 
