@@ -16,13 +16,13 @@
 //   CDF     cdf[i] = RNE(n_i * 65504 / T) + i, exact integer arithmetic
 //           (cdf_column_to_lds, shared with the decoder), kept in LDS as
 //           tab[entry][lane] u16 (aliases the dead histogram: 4.2 KiB per wave)
-//   pass 2  tokens T-1..0: renormalise (ballot + mbcnt append of 16-bit words,
-//           ascending lane order, into a 512-byte LDS ring that is flushed 256 B at
-//           a time), then x = (x/f << 16) + x%f + start, computed as
+//   pass 2  tokens T-1..0: renormalise -- under exec = emitting lanes (v_cmpx on the state's upper half): mbcnt
+//           rank, ds_write_b16 of the low half into a 256-word LDS ring (+ 64 slots so that a step never wraps;
+//           flushed 256 B at a time), x >>= 16 -- then x = (x/f << 16) + x%f + start, computed as
 //           x + (x/f) * (2^16 - f) + start (rans_put)
 //   tail    64 states, zero pad to 16 B; then the stream is moved to its final place in the blob
 //           (single-pass prefix over the group lengths of the chunk, one look-back per workgroup)
-// 4.7 KiB of LDS per wave -> 8 waves per SIMD.
+// 4.75 KiB of LDS per wave -> 8 waves per SIMD.
 #pragma once
 #include "lmc_device.h"
 
@@ -100,8 +100,9 @@ __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, c
 
 #define ENC_WAVES 4           // waves (= group streams) per workgroup (2 and 8 measured 1-2 % slower)
 #define ENC_TAB_DWORDS 1056   // 4224 B per wave: histogram [32][64] u16, then (aliased) CDF table [33][64] u16
-#define ENC_RING_WORDS 256    // + a 512-B staging ring for the renormalisation words (flushed 256 B at a time)
-#define ENC_WAVE_DWORDS (ENC_TAB_DWORDS + ENC_RING_WORDS / 2)
+#define ENC_RING_WORDS 256    // + a staging ring for the renormalisation words (flushed 256 B at a time)
+#define ENC_RING_DWORDS ((ENC_RING_WORDS + 64) / 2)  // ... with a 64-word extension: a step never wraps
+#define ENC_WAVE_DWORDS (ENC_TAB_DWORDS + ENC_RING_DWORDS)
 
 struct PendingTile {
   int chunk, pg;
@@ -185,13 +186,12 @@ __device__ __forceinline__ u32 sym_of_token(const u32* symq, int C, int t, bool 
 
 template <bool QUADSYM, bool ENCODE>
 __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
-  // the four staging rings come first so that each is 512-byte aligned (the word index wraps with one and-or)
-  __shared__ __attribute__((aligned(512))) u32 lds_all[ENC_WAVES * ENC_WAVE_DWORDS];
+  __shared__ __attribute__((aligned(16))) u32 lds_all[ENC_WAVES * ENC_WAVE_DWORDS];  // the staging rings, then the tables
   const int lane = threadIdx.x & 63;
   // everything derived from the wave id is wave-uniform: keep it in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long ngroups_total = (long long)a.nchunks * a.P * a.G;
-  u32* hist = lds_all + ENC_WAVES * (ENC_RING_WORDS / 2) + wave * ENC_TAB_DWORDS;  // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
+  u32* hist = lds_all + ENC_WAVES * ENC_RING_DWORDS + wave * ENC_TAB_DWORDS;  // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
   u16* tab = reinterpret_cast<u16*>(hist);          // [33][64] u16 CDF, written after hist is in registers
 
   // Workgroup -> streams.  When the streams of a chunk fill whole workgroups, consecutive workgroups take the SAME
@@ -330,21 +330,38 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
   // one token: renormalise (append this step's words in ascending lane order), then encode
   // The words of a step (a few dozen bytes) go to a wave-private LDS ring; whenever 128 words have gathered
   // they leave with one coalesced 256-byte store.
-  u16* const ring = reinterpret_cast<u16*>(lds_all + wave * (ENC_RING_WORDS / 2));
+  u16* const ring = reinterpret_cast<u16*>(lds_all + wave * (ENC_RING_DWORDS));
   typedef __attribute__((address_space(3))) u16* lds_u16w;
-  u32 ring_addr = (u32)(size_t)(lds_u16w)ring;  // 512-byte aligned LDS address
-  asm volatile("" : "+v"(ring_addr));           // in a VGPR, so that (x & 0x1fe) | ring_addr is one v_and_or_b32
+  const u32 ring_addr = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(lds_u16w)ring);
+  const u64 full_exec = __builtin_amdgcn_read_exec();
   LMC_GLOBAL u32* const out32 = (LMC_GLOBAL u32*)out;
   u32 flushed = 0;  // words already in global memory (a multiple of 128), wave-uniform
+  // The ring has 256 slots and a 64-slot extension: a step's words go to consecutive slots from wcur % 256 on
+  // (no wrap inside a step); what ran past slot 255 is brought back to slots 0.. when the upper half is flushed
+  // (a step that crosses a multiple of 256 always completes the upper half: at most 127 words are unflushed).
   auto code_token = [&](u32 st, u32 f) {
-    const u32 xh = x >> 16;
-    const bool emit = xh >= f;  // <=> x >= f << 16
-    const u64 mask = __ballot(emit);
-    if (emit) *(lds_u16w)(size_t)(ring_addr | (((wcur + lane_rank(mask)) << 1) & (2 * ENC_RING_WORDS - 1))) = (u16)x;
-    x = emit ? xh : x;
-    wcur += (u32)__popcll(mask);
+    // emit <=> x >= f << 16.  Under exec = emitting lanes: rank, slot, store of the low half, x >>= 16.
+    const u32 wbase = ring_addr + ((wcur & (ENC_RING_WORDS - 1)) << 1);  // scalar
+    u32 t, cnt;
+    asm volatile("v_cmpx_ge_u32_sdwa vcc, %[x], %[f] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                 "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                 "s_nop 0\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                 "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
+                 "ds_write_b16 %[t], %[x]\n\t"
+                 "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                 "s_mov_b64 exec, %[full]"
+                 : [x] "+v"(x), [t] "=&v"(t), [cnt] "=&s"(cnt)
+                 : [f] "v"(f), [wb] "s"(wbase), [full] "s"(full_exec)
+                 : "vcc", "scc", "memory");
+    wcur += cnt;
     if (wcur - flushed >= 128u) {
       wave_lds_fence();
+      if (flushed & 128u) {  // the upper half leaves: bring the words that ran past slot 255 back to slots 0..
+        const u32 over = wcur - flushed - 128u;  // < 64
+        if ((u32)lane < over) ring[lane] = ring[ENC_RING_WORDS + lane];
+      }
       out32[(flushed >> 1) + lane] = reinterpret_cast<const u32*>(ring)[((flushed & (ENC_RING_WORDS - 1)) >> 1) + lane];
       flushed += 128u;
     }

@@ -32,6 +32,8 @@ struct QuantArgs {
   int8_t* sym8;          // !QUAD: [P][T][C]
   u8* scale_base;        // scale of (chunk, p, t) at scale_base + chunk*scale_stride + 2*(p*Tc + t)
   long long scale_stride;
+  unsigned long long* agg;  // the coder's look-back granules, zeroed here (saves a memset dispatch), or NULL
+  long long agg_n;
 };
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -235,6 +237,10 @@ __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int sub = lane / G, sl = lane % G;
   const int p = (int)blockIdx.y, chunk = (int)blockIdx.z;
+  if (QUAD && a.agg) {  // the launch has at least 256 threads per plane-chunk, a plane-chunk at most 64 granules
+    const long long i = (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    if (i < a.agg_n) a.agg[i] = 0ull;
+  }
   const int TO = (a.TQ + 1) >> 1;
   int oct = ((int)blockIdx.x * 4 + wave) * RPW + sub;
   const bool ovalid = oct < TO && chunk * a.P + p < a.pc_limit;

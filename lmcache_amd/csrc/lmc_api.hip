@@ -309,6 +309,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     qa.sym4 = c->sym4;
     qa.scale_base = (u8*)blobs + hl.off_scales;  // off_scales does not depend on T
     qa.scale_stride = (long long)blob_stride;
+    qa.agg = c->agg; qa.agg_n = (long long)nchunks * PG;  // zeroed by the quantiser: one dispatch less per job
     if ((rc = prof_mark(c, s))) return rc;
     if ((rc = launch_quant<true>(qa, s))) return rc;
     if ((rc = prof_mark(c, s))) return rc;
@@ -325,7 +326,6 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     ea.agg = c->agg; ea.sizes = sizes;
     ea.L = L; ea.H = H; ea.D = D; ea.dtype = src->dtype;
     const long long ngroups = (long long)nchunks * PG;
-    HIP_TRY(hipMemsetAsync(ea.agg, 0, (size_t)ngroups * 8, s));
     hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + ENC_WAVES - 1) / ENC_WAVES)), dim3(64 * ENC_WAVES), 0, s, ea);
     HIP_TRY(hipGetLastError());
     if ((rc = prof_mark(c, s))) return rc;
