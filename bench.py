@@ -82,6 +82,12 @@ def make_kv(dev, seed, dist="rand", nl=L, ntok=CTX, nh=H, hd=D, dtype=torch.bflo
     return tuple(kv)
 
 
+def stage(name):
+    """Progress marker on stderr (LMC_BENCH_VERBOSE=1): says which leg a fault belongs to."""
+    if os.environ.get("LMC_BENCH_VERBOSE"):
+        print(f"[bench] {name}", file=sys.stderr, flush=True)
+
+
 def median(xs):
     return float(statistics.median(xs))
 
@@ -205,6 +211,7 @@ def time_encode(ctx, layout, ntok, chunk, bins, blobs, stride, sizes, sp, stream
 
 
 def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=False):
+    stage(f"shape {name}")
     """Encode / decode rate of another geometry (HBM-resident, one job)."""
     from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
     cs = 256
@@ -506,6 +513,7 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
     nchunks = CTX // CHUNK
     local_rank = dev.index
 
+    stage("store/retrieve legs")
     # ---- store / retrieve legs as the product runs them (PCIe-inclusive, never `value`) --------------------
     offload = retrieve = None
     try:
@@ -571,6 +579,7 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
         retrieve = retrieve or {"error": repr(e)}
     res["offload"], res["retrieve"] = offload, retrieve
 
+    stage("decode leg")
     # ---- decode leg: blobs in HBM -> decoded KV written straight into per-layer tensors ----------------------
     out = tuple((torch.empty_like(k), torch.empty_like(v)) for k, v in kv)
     out_layout = native.KVLayout.from_kv_tuple(out, "vllm")
@@ -605,12 +614,14 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
     res["roundtrip_within_bound"] = bool(((o0 - k0).abs() <= mx / (2 * 15) + mx * 2.0 ** -7).all())
     del out, k0, o0
 
+    stage("overlap legs")
     # ---- the metric's other half: store hidden behind decode, warm-prefix TTFT (BASELINE.json north_star) -------
     try:
         res.update(overlap_legs(dev, kv, raw_bytes))
     except Exception as e:
         res["store_hidden"] = {"error": repr(e)}
 
+    stage("seeds")
     # ---- the encode step on seeds 0..4 of the chosen distribution -------------------------------------------
     per_seed = []
     for s in range(5):
@@ -623,6 +634,7 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
     res["seeds"] = {"dist": args.dist, "ms_per_step": per_seed, "min": min(per_seed), "median": median(per_seed),
                     "GBps_raw_median": round(raw_bytes / median(per_seed) / 1e6, 1)}
 
+    stage("other configs")
     # ---- the other BASELINE geometries, HBM-resident --------------------------------------------------------
     try:
         others = [shape_rate(native, ctx, dev, "configs[0] shape: fp16 [32 L, 32 H, 4096 tok, 128 hd] (C = 4096)",

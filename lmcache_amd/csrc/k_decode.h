@@ -406,11 +406,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       return SRC_BF16 ? __uint_as_float(sb << 16) : (float)__builtin_bit_cast(_Float16, (unsigned short)sb);
     };
     u32 sc_next = scale_bits(nskip);
-    u32 off = lane_off;
     for (u32 t0 = nskip; t0 < T; t0 += 64) {
       const u32 nt = (u32)__builtin_amdgcn_readfirstlane((int)min(T - t0, 64u));
       const float sc = scale_f32(sc_next);
       sc_next = scale_bits(t0 + nt);
+      // PAGED: lane i works out the block row of token t0 + i once (slot_mapping load + division); every token
+      // then takes its row with two v_readlane and the store goes through a descriptor based at that row
+      long long tok_off2 = 0;
+      if (PAGED && !SYMOUT) tok_off2 = (t0 + (u32)lane < T) ? lmc_tok_off(a.dst, tdst0 + (int)(t0 + (u32)lane)) * 2 : 0ll;
       for (u32 i = 0; i < nt; i++) {
         float lv = 0.0f;
         const u32 sa = decode_token(top_tag, lv);
@@ -424,11 +427,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
           if (DT_OUT == LMC_DTYPE_BF16) bits = __builtin_bit_cast(unsigned short, (__bf16)val);  // v_cvt_pk_bf16_f32, RNE
           else bits = (u16)f2fp16(val);
           if (PAGED) {
-            if (active) {
-              LMC_GLOBAL u8* const row = (LMC_GLOBAL u8*)ubase + lmc_tok_off(a.dst, tdst0 + (int)(t0 + i)) * 2;
-              asm volatile("" : "+v"(off));  // keeps the zero-extension next to the store: SGPR base + 32-bit VGPR offset
-              __builtin_nontemporal_store(bits, (LMC_GLOBAL u16*)(row + off));  // written once, read by someone else later
-            }
+            const u32 olo = (u32)__builtin_amdgcn_readlane((int)(u32)tok_off2, (int)i);
+            const u32 ohi = (u32)__builtin_amdgcn_readlane((int)(u32)((unsigned long long)tok_off2 >> 32), (int)i);
+            __amdgpu_buffer_rsrc_t prow = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(ubase + (((u64)ohi << 32) | (u64)olo)), (short)0, (int)0xfffffff0u, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b16((short)bits, prow, (int)voff, 0, 2 /* nt */);
           } else {
             __builtin_amdgcn_raw_buffer_store_b16((short)bits, rsrc, (int)voff, (int)soff, 2 /* nt */);
             soff += (u32)row_step;
