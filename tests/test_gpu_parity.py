@@ -495,6 +495,43 @@ def test_corrupt_blob_is_flagged(nat, ctx):
     assert ctx.status(clear=True) == 0
 
 
+def test_fuzzed_blobs_never_fault_and_are_flagged(nat, ctx):
+    """Random damage anywhere behind the header of a multi-block blob (256 tokens: every stream refills its LDS
+    ring several times; 32- and 16-bin planes, a ragged last channel group): the decoder stays inside its
+    buffers, finishes, and either flags the blob or -- when only padding was hit -- decodes it unchanged."""
+    L, T, H, D = 2, 256, 3, 40  # C = 120: one full group stream would be 64 channels, the second has 56
+    kv = make_kv(L, T, H, D, torch.bfloat16, "randn", 5).to(DEV)
+    blobs, blob_dev, stride = encode(nat, ctx, nat.KVLayout.from_chunk(kv, "vllm"), 0, T, T, [32, 16, 17, 20])
+    hdr = nat.blob_info(blobs[0])
+    clean = torch.zeros_like(kv)
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(clean, "vllm"), 0, T)
+    torch.cuda.synchronize()
+    assert ctx.status(clear=True) == 0
+    g = torch.Generator().manual_seed(11)
+    total = len(blobs[0])
+    flagged = 0
+    for it in range(40):
+        bad = blob_dev.clone()
+        lo = hdr.off_cdf if it % 2 else hdr.off_streams
+        npos = int(torch.randint(1, 17, (1,), generator=g))
+        pos = torch.randint(lo, total, (npos,), generator=g)
+        if it % 5 == 4:  # a run of garbage instead of single bytes
+            a = int(pos[0])
+            n = min(total - a, 4096)
+            bad[a:a + n] = torch.randint(0, 256, (n,), generator=g, dtype=torch.uint8).to(DEV)
+        else:
+            bad[pos.to(DEV)] ^= torch.randint(1, 256, (npos,), generator=g, dtype=torch.uint8).to(DEV)
+        out = torch.zeros_like(kv)
+        ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+        torch.cuda.synchronize()
+        st = ctx.status(clear=True)
+        if st:
+            flagged += 1
+        else:
+            assert torch.equal(out, clean), it
+    assert flagged >= 30
+
+
 def test_full_size_llama8b_chunk_vs_oracle(nat, ctx, oracle):
     """BASELINE config 2, one full chunk: L=32, 8 KV heads x 128, T=256 bf16 (32 MiB)."""
     L, T, H, D = 32, 256, 8, 128
