@@ -227,8 +227,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   const u32 pB = wide ? *(lds_u32p)(size_t)colB_addr : (u32)*(lds_u16p)(size_t)colB_addr;
   const u32 pC = wide ? *(lds_u32p)(size_t)(col_addr + 3072u) : (u32)*(lds_u16p)(size_t)(col_addr + 3072u);
   const u32 lut_addr = (u32)(size_t)(lds_f32p)lut;
-  u32 lut_lo = lut_addr, lut_hi = lut_addr + 32u;  // LUT entries 0 and 8: in VGPRs, one v_cndmask picks between them
-  asm volatile("" : "+v"(lut_lo), "+v"(lut_hi));
+  const u32 lut_qbias = col_addr - (lut_addr << 6);  // wide: (q - lut_qbias) >> 6 = &lut[4 * quarter]
   u32 c_ffff = 0xffffu;
   asm volatile("" : "+v"(c_ffff));
   // narrow: lut[s] with s = (qa - col) >> 7 is at ((qa - col) >> 5) + &lut = (qa - lut_bias) >> 5
@@ -303,22 +302,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       // trip per token in the search, and `r` follows the symbol as the address of its LUT entry.
       u32 sl, q, r, pm;
       u64 mask;
-      // levels 1-2 as one block (the two wait states between v_cmp and the selects that read vcc are explicit)
+      // levels 1-2 as one block, both exec-predicated (no back-to-back v_cndmask on one vcc, which the issue probe
+      // tools/probes/valu_rates.py shows at a quarter of the normal rate; in this kernel the two forms time the same)
       asm("v_lshl_or_b32 %[sl], %[x], 16, %[ffff]\n\t"
-          "v_cmp_le_u32_e32 vcc, %[pB], %[sl]\n\t"
-          "s_nop 1\n\t"
-          "v_cndmask_b32_e32 %[q], %[colA], %[colB], vcc\n\t"
-          "v_cndmask_b32_e32 %[pm], %[pA], %[pC], vcc\n\t"
-          "v_cndmask_b32_e32 %[r], %[lutlo], %[luthi], vcc\n\t"
+          "v_mov_b32_e32 %[q], %[colA]\n\t"
+          "v_mov_b32_e32 %[pm], %[pA]\n\t"
+          "v_cmpx_le_u32_e32 vcc, %[pB], %[sl]\n\t"
+          "v_mov_b32_e32 %[q], %[colB]\n\t"
+          "v_mov_b32_e32 %[pm], %[pC]\n\t"
+          "s_mov_b64 exec, %[full]\n\t"
           "v_cmpx_le_u32_e32 vcc, %[pm], %[sl]\n\t"
           "v_add_u32_e32 %[q], 0x400, %[q]\n\t"
-          "v_add_u32_e32 %[r], 16, %[r]\n\t"
           "s_mov_b64 exec, %[full]"
-          : [sl] "=&v"(sl), [q] "=&v"(q), [r] "=&v"(r), [pm] "=&v"(pm)
+          : [sl] "=&v"(sl), [q] "=&v"(q), [pm] "=&v"(pm)
           : [x] "v"(x), [ffff] "v"(c_ffff), [pA] "v"(pA), [pB] "v"(pB), [pC] "v"(pC), [colA] "v"(col_addr),
-            [colB] "v"(colB_addr), [lutlo] "v"(lut_lo), [luthi] "v"(lut_hi), [full] "s"(full_exec)
+            [colB] "v"(colB_addr), [full] "s"(full_exec)
           : "vcc");
       const u32x4_t e4 = *(const __attribute__((address_space(3))) u32x4_t*)(size_t)q;
+      r = (q - lut_qbias) >> 6;  // LUT entry of the quarter's first symbol: quarter * 1024 -> quarter * 16 bytes
       u32 e0 = e4.x, e1 = e4.y, d;
       // levels 3-4 among the quarter's entries, then x = freq * (x >> 16) + (slot - start) (start is the entry's
       // upper half, freq its lower half) and the renormalisation test, as one block: no hazard padding in between
@@ -344,10 +345,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       u32 slot = x & 0xffffu;
       asm volatile("" : "+v"(slot));  // keep `slot` a plain VGPR: SDWA compares would cost a wait state each
       // q walks the column: q = &cdf[s] for the largest probed s with cdf[s] <= slot.  Two levels on register pivots,
-      const bool geB = pB <= slot;
-      const u32 pm = geB ? pC : pA;
-      u32 q = geB ? colB_addr : col_addr;
-      LMC_SEARCH_STEP(q, pm, slot, TOP * ESTRIDE);
+      u32 q, pm;
+      asm("v_mov_b32_e32 %[q], %[colA]\n\t"
+          "v_mov_b32_e32 %[pm], %[pA]\n\t"
+          "v_cmpx_le_u32_e32 vcc, %[pB], %[sl]\n\t"
+          "v_mov_b32_e32 %[q], %[colB]\n\t"
+          "v_mov_b32_e32 %[pm], %[pC]\n\t"
+          "s_mov_b64 exec, %[full]\n\t"
+          "v_cmpx_le_u32_e32 vcc, %[pm], %[sl]\n\t"
+          "v_add_u32_e32 %[q], 0x400, %[q]\n\t"  // TOP * ESTRIDE
+          "s_mov_b64 exec, %[full]"
+          : [q] "=&v"(q), [pm] "=&v"(pm)
+          : [sl] "v"(slot), [pA] "v"(pA), [pB] "v"(pB), [pC] "v"(pC), [colA] "v"(col_addr), [colB] "v"(colB_addr),
+            [full] "s"(full_exec)
+          : "vcc");
       // ... one on the column in LDS (step 4), then the five entries q .. q + 4 in ONE round trip: the last two
       // levels, the symbol's start and end are picked among them by exec-predicated moves
       {

@@ -90,6 +90,14 @@ OPS = [
     ("G 2xcnd_e32_samevcc", "v_cmp_lt_u32 vcc, {a}, {b}; s_nop 1; v_cndmask_b32 {d}, {a}, {b}, vcc; v_cndmask_b32 {e}, {b}, {a}, vcc"),
     ("G cnd_e32,add,add,add", "v_cndmask_b32 {d}, {a}, {b}, vcc; v_add_u32 {e}, {a}, {b}; v_add_u32 {e}, {a}, {b}; v_add_u32 {e}, {a}, {b}"),
     ("G cnd_e32,fma x3", "v_cndmask_b32 {d}, {a}, {b}, vcc; v_fma_f32 {e}, {a}, {b}, {c}; v_fma_f32 {e}, {a}, {b}, {c}; v_fma_f32 {e}, {a}, {b}, {c}"),
+    # exec-predicated selection (k_decode / k_cdf_encode round 2) against the compare + select form
+    ("G cmpx+mov+mov+add+smov", "v_cmpx_le_u32 vcc, {a}, {b}; v_mov_b32 {d}, {a}; v_mov_b32 {e}, {b}; v_add_u32 {d}, 8, {d}; s_mov_b64 exec, s[30:31]"),
+    ("G cmp+nop1+cnd+cnd+addc", "v_cmp_le_u32 vcc, {a}, {b}; s_nop 1; v_cndmask_b32 {d}, {a}, {b}, vcc; v_cndmask_b32 {e}, {b}, {a}, vcc; v_addc_co_u32 {d}, vcc, {d}, {d}, vcc"),
+    ("G cmpx+add+smov", "v_cmpx_le_u32 vcc, {a}, {b}; v_add_u32 {d}, 8, {d}; s_mov_b64 exec, s[30:31]"),
+    ("G cmp+nop1+cnd", "v_cmp_le_u32 vcc, {a}, {b}; s_nop 1; v_cndmask_b32 {d}, {a}, {b}, vcc"),
+    ("G mov+mov+mov+mov", "v_mov_b32 {d}, {a}; v_mov_b32 {e}, {b}; v_mov_b32 {d}, {b}; v_mov_b32 {e}, {a}"),
+    ("G dep add chain x4", "v_add_u32 {d}, {d}, {a}; v_add_u32 {d}, {d}, {b}; v_add_u32 {d}, {d}, {a}; v_add_u32 {d}, {d}, {b}"),
+    ("G dep mad chain x4", "v_mad_u32_u24 {d}, {d}, {a}, {b}; v_mad_u32_u24 {d}, {d}, {a}, {b}; v_mad_u32_u24 {d}, {d}, {a}, {b}; v_mad_u32_u24 {d}, {d}, {a}, {b}"),
     ("ds_read_b32", "ds_read_b32 {d}, {l}"),
     ("ds_read_b64", "ds_read_b64 {d2}, {l8}"),
     ("ds_read_u16", "ds_read_u16 {d}, {l}"),
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256) void k_%(name)s(unsigned long long* out, unsig
       "v_mov_b32 v4, 0\n v_mov_b32 v5, 0\n v_mov_b32 v6, 0\n v_mov_b32 v7, 0\n"
       "v_mov_b32 v16, 0\n v_mov_b32 v17, 0\n v_mov_b32 v18, 0\n v_mov_b32 v19, 0\n v_mov_b32 v20, 0\n v_mov_b32 v21, 0\n v_mov_b32 v22, 0\n v_mov_b32 v23, 0\n"
       "s_mov_b32 s20, 0x55555555\n s_mov_b32 s21, 0x33333333\n"
-      "s_mov_b64 vcc, 0x5555\n"
+      "s_mov_b64 vcc, 0x5555\n s_mov_b64 s[30:31], exec\n"
       "s_waitcnt lgkmcnt(0)\n"
       "s_memtime s[24:25]\n"
       "s_movk_i32 s23, %(iters)d\n"
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void k_%(name)s(unsigned long long* out, unsig
       : "=v"(l4), "=v"(l8)
       : "v"(l4), "v"(l8)
       : "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23",
-        "s20","s21","s22","s23","s24","s25","s26","s27","s28","s29","vcc","memory");
+        "s20","s21","s22","s23","s24","s25","s26","s27","s28","s29","s30","s31","vcc","memory");
   if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = l4;
   if (l8 == 0x12345) sink[0] = l8;
 }
