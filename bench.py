@@ -734,7 +734,8 @@ def ttft_hbm_tier(dev, kv, proxy, alone, meta):
         engine.store(toks, kv)
         side = torch.cuda.Stream(device=dev)
         whole = []
-        piped = {2: [], 4: [], 8: []}
+        from lmcache_amd.storage_backend.serde.cachegen_device import layer_ranges
+        piped = {2: [], 4: [], 8: [], (2, 6, 24): []}  # range size, or a schedule of range sizes (small ranges first)
         for r in range(6):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -748,9 +749,9 @@ def ttft_hbm_tier(dev, kv, proxy, alone, meta):
                 t0 = time.perf_counter()
                 with torch.cuda.stream(side):        # one decode launch per range of layers on a side stream ...
                     res = engine.retrieve_layerwise(toks, layers_per_launch=step)
-                for l0 in range(0, 32, step):        # ... the model's layers of a range wait for THAT range's KV only
+                for l0, l1 in layer_ranges(L, step):  # ... the model's layers of a range wait for THAT range's KV only
                     res.wait_layer(l0)
-                    for l in range(l0, l0 + step):
+                    for l in range(l0, l1):
                         torch.mv(proxy.w[l], proxy.x, out=proxy.y)
                 torch.cuda.synchronize()
                 piped[step].append((time.perf_counter() - t0) * 1e3)
@@ -762,7 +763,7 @@ def ttft_hbm_tier(dev, kv, proxy, alone, meta):
         best = min(med, key=med.get)
         return {"retrieve_then_step_ms": round(median(whole), 3), "ratio": round(median(whole) / alone, 3),
                 "layerwise_ms": round(med[best], 3), "layerwise_ratio": round(med[best] / alone, 3),
-                "layers_per_launch": best, "layerwise_ms_by_layers_per_launch": {str(k): round(v, 3) for k, v in med.items()},
+                "layers_per_launch": best if isinstance(best, int) else list(best), "layerwise_ms_by_layers_per_launch": {str(k): round(v, 3) for k, v in med.items()},
                 "target": "<= 1.05", "reps": 5,
                 "hbm_floor_ratio": round((PROXY_BYTES + 2.66e9) / PROXY_BYTES, 3),
                 "note": "encoded chunks resident in HBM (4.2x more warm context than raw KV): retrieve = decode only; "

@@ -106,6 +106,21 @@ class EncodeJob:
     offload_issued: bool = False  # its device -> host copies are on the copy streams (the arena may be reused after them)
 
 
+def layer_ranges(L: int, layers_per_launch) -> list:
+    """[(first layer, end layer), ...] covering 0..L: one range when layers_per_launch is None / 0, ranges of a
+    fixed size for an int, and for a sequence of sizes the ranges it lists, its last size repeating."""
+    if not layers_per_launch:
+        return [(0, L)]
+    sizes = [layers_per_launch] if isinstance(layers_per_launch, int) else list(layers_per_launch)
+    out, l0, i = [], 0, 0
+    while l0 < L:
+        step = max(1, min(L - l0, int(sizes[min(i, len(sizes) - 1)])))
+        out.append((l0, l0 + step))
+        l0 += step
+        i += 1
+    return out
+
+
 @dataclass
 class DecodeJob:
     """One decode() call in flight: `done` fires after its last kernel, `status_idx` is its own status word.
@@ -304,20 +319,21 @@ class CacheGenDeviceCodec:
         """Decode blobs that live in HBM (uint8 CUDA tensors, anywhere) straight into `dst` on the current stream,
         no staging copy: the kernel takes the blob addresses from a pointer table.  With layers_per_launch the
         retrieve is cut into one launch per range of layers with an event after each (DecodeJob.layer_events): the
-        model can start on layer 0 after 1/L of the decode."""
+        model can start on layer 0 after 1/L of the decode.  layers_per_launch is a range size or a schedule of
+        range sizes whose last entry repeats, e.g. (2, 2, 4, 8, 16): small ranges first so that the model starts
+        early, large ones later (a launch of few layers does not fill the GPU, and every launch costs an event)."""
         n = len(blobs)
         if n == 0:
             return None
         L = dst.L
-        step = L if not layers_per_launch else max(1, min(L, int(layers_per_launch)))
+        ranges = layer_ranges(L, layers_per_launch)
         with self._lock, torch.cuda.device(self.device):
             cur = torch.cuda.current_stream(self.device)
             table = native.pointer_table([b.data_ptr() for b in blobs], self.device)
             bound = max(b.numel() for b in blobs)
             st = self._status.acquire()
             events = []
-            for l0 in range(0, L, step):
-                l1 = min(L, l0 + step)
+            for l0, l1 in ranges:
                 self.ctx.decode_chunks_layers(table.data_ptr(), bound, n, dst, dst_tok0, chunk_tokens, l0, l1 - l0,
                                               stream=cur.cuda_stream, status_ptr=self._status.ptr(st))
                 ev = torch.cuda.Event()

@@ -643,7 +643,8 @@ def test_hbm_cachegen_tier_and_layerwise_retrieve(oracle):
         ref, _ = host.retrieve(toks)
         for (k, v), (k1, v1) in zip(want, ref):
             assert torch.equal(k, k1) and torch.equal(v, v1)  # the same decoder whatever memory the blobs live in
-        for step, nev in ((1, 8), (3, 3), (8, 1), (100, 1)):
+        # a range size, or a schedule of range sizes (small ranges first; the last size repeats)
+        for step, nev in ((1, 8), (3, 3), (8, 1), (100, 1), ((1, 2, 5), 3), ((2,), 4), ((1, 1, 3), 4)):
             side = torch.cuda.Stream()
             with torch.cuda.stream(side):
                 r = engine.retrieve_layerwise(toks, layers_per_launch=step)

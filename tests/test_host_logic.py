@@ -46,6 +46,8 @@ def test_prefix_hash_matches_reference_and_oracle(golden_dir, oracle):
         assert got == case["hashes"], case["name"]                       # reference-generated
         assert got == oracle.prefix_hash(toks.numpy(), case["chunk_size"])  # independent C SHA-256
         assert e._prefix_hash(e._chunk_tokens(toks), 1) == case["hashes"][1:]
+        # the engine's one-conversion form gives the same chain
+        assert e._prefix_hashes_of(toks) == case["hashes"] and e._prefix_hashes_of(toks, 1) == case["hashes"][1:]
     # dtype dependence noted in SURVEY.md 8(c): int32 tokens hash differently
     e = _bare_engine(256)
     t64 = torch.arange(300, dtype=torch.int64)
@@ -280,3 +282,17 @@ def test_divmod_small_is_exact_for_every_row_length():
         e = np.arange(64 * R, dtype=np.uint32)
         q = ((e.astype(np.float32) + np.float32(0.5)) * (np.float32(1.0) / np.float32(R))).astype(np.uint32)
         assert np.array_equal(q, e // R), R
+
+
+def test_layer_range_schedules():
+    """retrieve_layerwise's layers_per_launch: a size, or a schedule whose last entry repeats."""
+    from lmcache_amd.storage_backend.serde.cachegen_device import layer_ranges
+    assert layer_ranges(32, None) == [(0, 32)] and layer_ranges(32, 0) == [(0, 32)]
+    assert layer_ranges(32, 8) == [(0, 8), (8, 16), (16, 24), (24, 32)]
+    assert layer_ranges(32, (2, 6, 24)) == [(0, 2), (2, 8), (8, 32)]
+    assert layer_ranges(32, (2, 2, 4, 8, 16)) == [(0, 2), (2, 4), (4, 8), (8, 16), (16, 32)]
+    assert layer_ranges(5, (2,)) == [(0, 2), (2, 4), (4, 5)] and layer_ranges(3, 7) == [(0, 3)]
+    for L in (1, 7, 80):
+        for sched in (1, 3, (1, 2), (4, 1), (100,)):
+            r = layer_ranges(L, sched)
+            assert r[0][0] == 0 and r[-1][1] == L and all(a[1] == b[0] for a, b in zip(r, r[1:]))
