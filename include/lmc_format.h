@@ -22,6 +22,11 @@
  *   rowpre   u16 [P+1]      rowpre[p] = sum over planes before p of R, R = bins - 1
  *   scales   u16 [P][T]     per-(plane,token) absmax, raw bits of the KV dtype
  *                           (= max_tensors_key ++ max_tensors_value)
+ *   scsum    u32 [P]        checksum of each plane's scales (v4): sum over t of (t + 1) * (bits_t + 1)
+ *                           mod 2^32 -- lmc_scale_checksum_term.  The entropy coder detects damage to the
+ *                           counts and the streams by itself (the final rANS states must come out at
+ *                           their start value); the scales are the one section it cannot see, and a
+ *                           flipped scale would silently rescale a whole token row.
  *   cdf      the per-channel symbol statistics the 16-bit CDF is a function of.  Per plane p:
  *                           [C][R_p] counts of the symbols 0 .. R_p - 1, R_p = bins - 1 being
  *                           the number of symbols the quantiser can emit (plane p starts
@@ -64,7 +69,7 @@ extern "C" {
 #endif
 
 #define LMC_BLOB_MAGIC 0x31434D4Cu /* "LMC1" */
-#define LMC_BLOB_VERSION 3u
+#define LMC_BLOB_VERSION 4u
 #define LMC_HEADER_BYTES 128u
 
 #define LMC_DTYPE_BF16 0
@@ -100,10 +105,14 @@ typedef struct lmc_blob_header {
   uint32_t off_rowpre;
   uint32_t cdf_rows;     /* rowpre[P] = sum of R over all planes */
   uint32_t count_bytes;  /* bytes per stored count: 1 (T <= 256) or 2 */
-  uint32_t reserved[11];
+  uint32_t off_scsum;    /* per-plane scale checksums */
+  uint32_t reserved[10];
 } lmc_blob_header;
 
 static inline uint32_t lmc_r16(uint32_t x) { return (x + 15u) & ~15u; }
+
+/* One term of a plane's scale checksum: token t (0-based) whose scale has the raw bits `bits`. */
+static inline uint32_t lmc_scale_checksum_term(uint32_t t, uint32_t bits) { return (t + 1u) * (bits + 1u); }
 
 /* Counts stored per channel of a plane quantised with `bins` bins: one per symbol 0 .. bins-2. */
 static inline uint32_t lmc_cdf_row(uint32_t bins) { return bins - 1u; }
@@ -125,7 +134,8 @@ static inline void lmc_blob_layout(uint32_t L, uint32_t T, uint32_t H, uint32_t 
   h->off_bins = LMC_HEADER_BYTES;
   h->off_rowpre = h->off_bins + lmc_r16(P);
   h->off_scales = h->off_rowpre + lmc_r16(2u * (P + 1u));
-  h->off_cdf = h->off_scales + lmc_r16(2u * P * T);
+  h->off_scsum = h->off_scales + lmc_r16(2u * P * T);
+  h->off_cdf = h->off_scsum + lmc_r16(4u * P);
   h->off_gend = h->off_cdf + lmc_r16(h->count_bytes * C * cdf_rows);
   h->off_streams = h->off_gend + lmc_r16(4u * P * G);
 }

@@ -105,6 +105,7 @@ int lmc_ctx_reserve(lmc_ctx* ctx, int L, int H, int D, int chunk_tokens, int max
 #define LMC_STATUS_BAD_HEADER 2u      /* decode: header / geometry / section offsets inconsistent */
 #define LMC_STATUS_BAD_STREAM 4u      /* decode: directory out of bounds, words left over, final state wrong */
 #define LMC_STATUS_LOOKBACK_TIMEOUT 8u
+#define LMC_STATUS_BAD_SCALES 16u     /* decode: a plane's scales do not match their checksum (lmc_format.h: scsum) */
 /* The context's sticky status word.  `clear` resets it. */
 int lmc_device_status(lmc_ctx* ctx, int clear);
 

@@ -162,6 +162,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   }
   // ---- dequantisation LUT; the per-token scales are fetched 64 tokens at a time inside the loop ----
   const u16* scl = reinterpret_cast<const u16*>(blob + bo.scales) + (long long)p * T;
+  if (!SYMOUT) {  // the scales are the one section whose damage the coder cannot see: check their checksum
+    const u32 want = (u32)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const u32*>(blob + bo.scsum)[p]);
+    if (scale_checksum(scl, T, lane) != want) {
+      if (lane == 0) atomicOr(a.status, LMC_ST_BAD_SCALES);
+      return;
+    }
+  }
   if (!SYMOUT && lane < 32) {
     const float Cf = (float)((int)blob[bo.bins + p] / 2 - 1);
     const float v = (float)lane - Cf;

@@ -65,7 +65,8 @@ __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, c
   for (u32 i = lane; i < bo.rowpre - bo.bins; i += 64) blob[bo.bins + i] = i < P ? a.bins.b[i] : (u8)0;
   for (u32 i = lane; i < (bo.scales - bo.rowpre) / 2; i += 64)
     reinterpret_cast<u16*>(blob + bo.rowpre)[i] = i <= P ? a.bins.rowpre[i] : (u16)0;
-  for (u32 i = bo.scales + 2u * P * T + lane; i < bo.cdf; i += 64) blob[i] = 0;
+  for (u32 i = bo.scales + 2u * P * T + lane; i < bo.scsum; i += 64) blob[i] = 0;
+  for (u32 i = bo.scsum + 4u * P + lane; i < bo.cdf; i += 64) blob[i] = 0;
   for (u32 i = bo.cdf + dev_count_bytes(T) * (u32)a.C * cdf_rows + lane; i < bo.gend; i += 64) blob[i] = 0;
   for (u32 i = bo.gend + 4u * n + lane; i < bo.streams; i += 64) blob[i] = 0;
   if (lane < 32) {
@@ -92,6 +93,7 @@ __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, c
       case 18: v = bo.rowpre; break;
       case 19: v = cdf_rows; break;
       case 20: v = dev_count_bytes(T); break;
+      case 21: v = bo.scsum; break;
       default: v = 0;
     }
     reinterpret_cast<u32*>(blob)[lane] = v;
@@ -280,7 +282,12 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
     const float rcpR = 1.0f / (float)R;
     const u32 total = (u32)min(64, a.C - g * 64) * R;
     const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
-    u8* sec = a.blobs + (long long)chunk * a.blob_stride + bo.cdf;
+    u8* const blob0 = a.blobs + (long long)chunk * a.blob_stride;
+    if (g == 0) {  // one wave per (chunk, plane): checksum of the plane's scales (written by k_quantize)
+      const u32 cs = scale_checksum(reinterpret_cast<const u16*>(blob0 + bo.scales) + (long long)p * T, T, lane);
+      if (lane == 0) reinterpret_cast<u32*>(blob0 + bo.scsum)[p] = cs;
+    }
+    u8* sec = blob0 + bo.cdf;
     const long long e0 = (long long)a.C * a.bins.rowpre[p] + (long long)g * 64 * R;
     if (dev_count_bytes(T) == 1u) {
       for (u32 e = lane; e < total; e += 64) {

@@ -495,7 +495,8 @@ int lmc_blob_info(const void* blob_h, size_t nbytes, lmc_blob_header* out) {
   lmc_blob_layout(h.num_layers, h.ntokens, h.num_heads, h.head_size, h.cdf_rows, &ref);
   if (h.nchannels != ref.nchannels || h.nplanes != ref.nplanes || h.ngroups != ref.ngroups || h.lp != ref.lp ||
       h.off_bins != ref.off_bins || h.off_rowpre != ref.off_rowpre || h.off_scales != ref.off_scales ||
-      h.off_cdf != ref.off_cdf || h.off_gend != ref.off_gend || h.off_streams != ref.off_streams)
+      h.off_scsum != ref.off_scsum || h.off_cdf != ref.off_cdf || h.off_gend != ref.off_gend ||
+      h.off_streams != ref.off_streams)
     return LMC_ERR_INVALID;
   if (h.total_bytes != h.off_streams + h.stream_bytes || h.total_bytes > nbytes) return LMC_ERR_INVALID;
   *out = h;

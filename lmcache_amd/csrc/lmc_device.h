@@ -21,6 +21,7 @@ typedef uint64_t u64;
 #define LMC_ST_BAD_HEADER LMC_STATUS_BAD_HEADER
 #define LMC_ST_BAD_STREAM LMC_STATUS_BAD_STREAM
 #define LMC_ST_LOOKBACK_TIMEOUT LMC_STATUS_LOOKBACK_TIMEOUT
+#define LMC_ST_BAD_SCALES LMC_STATUS_BAD_SCALES
 
 // Device copy of lmc_kv_layout (include/lmc_hip.h), strides in elements.
 struct KvAddr {
@@ -62,14 +63,15 @@ __device__ __forceinline__ u32 dev_count_bytes(u32 T) { return T <= 256u ? 1u : 
 
 // Section offsets of a chunk blob with T tokens (mirror of lmc_blob_layout).
 struct BlobOff {
-  u32 bins, rowpre, scales, cdf, gend, streams;
+  u32 bins, rowpre, scales, scsum, cdf, gend, streams;
 };
 __device__ __forceinline__ BlobOff lmc_blob_off(u32 P, u32 T, u32 C, u32 G, u32 cdf_rows) {
   BlobOff o;
   o.bins = LMC_HEADER_BYTES;
   o.rowpre = o.bins + ((P + 15u) & ~15u);
   o.scales = o.rowpre + ((2u * (P + 1u) + 15u) & ~15u);
-  o.cdf = o.scales + ((2u * P * T + 15u) & ~15u);
+  o.scsum = o.scales + ((2u * P * T + 15u) & ~15u);
+  o.cdf = o.scsum + ((4u * P + 15u) & ~15u);
   o.gend = o.cdf + ((dev_count_bytes(T) * C * cdf_rows + 15u) & ~15u);
   o.streams = o.gend + ((4u * P * G + 15u) & ~15u);
   return o;
@@ -143,6 +145,13 @@ __device__ __forceinline__ u32 wave_sum_u32(u32 v) {
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) v += (u32)__shfl_xor((int)v, off);
   return v;
+}
+
+// Checksum of a plane's T scales (lmc_format.h: scsum), by one wave.
+__device__ __forceinline__ u32 scale_checksum(const u16* scl, u32 T, int lane) {
+  u32 acc = 0;
+  for (u32 t = (u32)lane; t < T; t += 64) acc += (t + 1u) * ((u32)scl[t] + 1u);  // device twin of lmc_scale_checksum_term
+  return wave_sum_u32(acc);
 }
 
 __device__ __forceinline__ u32 lane_rank(u64 mask) {  // # set bits of mask below this lane

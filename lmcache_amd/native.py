@@ -58,7 +58,7 @@ class BlobHeader(ctypes.Structure):
                 ("off_bins", ctypes.c_uint32), ("off_scales", ctypes.c_uint32), ("off_cdf", ctypes.c_uint32),
                 ("off_gend", ctypes.c_uint32), ("off_streams", ctypes.c_uint32), ("stream_bytes", ctypes.c_uint32),
                 ("total_bytes", ctypes.c_uint32), ("off_rowpre", ctypes.c_uint32), ("cdf_rows", ctypes.c_uint32),
-                ("count_bytes", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 11)]
+                ("count_bytes", ctypes.c_uint32), ("off_scsum", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 10)]
 
 
 # name -> (restype, argtypes); every symbol include/lmc_hip.h declares
@@ -152,7 +152,7 @@ def group_cap_bytes(T: int) -> int:
 
 
 def blob_static_bytes(L: int, T: int, H: int, D: int, bins: Optional[Sequence[int]] = None) -> int:
-    """Bytes in front of the streams section (lmc_blob_layout): header, bins, rowpre, scales, the symbol
+    """Bytes in front of the streams section (lmc_blob_layout): header, bins, rowpre, scales, their checksums, the symbol
     counts (bins - 1 per channel, one byte each for T <= 256 else two; every plane at 32 bins when `bins` is
     None) and gend."""
     C, P = H * D, 2 * L
@@ -161,6 +161,7 @@ def blob_static_bytes(L: int, T: int, H: int, D: int, bins: Optional[Sequence[in
     off = HEADER_BYTES + r16(P)
     off += r16(2 * (P + 1))
     off += r16(2 * P * T)
+    off += r16(4 * P)
     off += r16((1 if T <= 256 else 2) * C * rows)
     off += r16(4 * P * G)
     return off
@@ -491,7 +492,7 @@ class Context:
 
 
 def describe_status(st: int) -> str:
-    names = [(1, "stream overflow"), (2, "bad blob header"), (4, "bad stream"), (8, "look-back timeout")]
+    names = [(1, "stream overflow"), (2, "bad blob header"), (4, "bad stream"), (8, "look-back timeout"), (16, "scale checksum mismatch")]
     return f"device status 0x{st:x} (" + ", ".join(n for b, n in names if st & b) + ")"
 
 

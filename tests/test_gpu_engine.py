@@ -452,7 +452,7 @@ def test_back_to_back_nonblocking_stores_keep_their_own_bytes(oracle):
 
 
 def test_corrupt_pinned_blob_is_a_miss_never_garbage(oracle):
-    """A CacheGen chunk damaged in pinned host DRAM (header, counts or streams) must not come back as KV:
+    """A CacheGen chunk damaged in pinned host DRAM (header, scales, counts or streams) must not come back as KV:
     retrieve() reports a miss and get() returns None -- each decode reports into its own status word, so the
     failure neither disappears nor shows up later as somebody else's "encode" error."""
     import ctypes
@@ -467,7 +467,8 @@ def test_corrupt_pinned_blob_is_a_miss_never_garbage(oracle):
         keys = [engine._make_key(h, fmt) for h in engine._prefix_hash(engine._chunk_tokens(toks))]
         entry = engine.engine_.dict[keys[1]]
         raw = (ctypes.c_uint8 * entry.blob.nbytes).from_address(entry.blob.ptr)
-        for where in (entry.blob.nbytes - 40, 146, entry.blob.nbytes // 2):  # final states, a row prefix, a stream
+        # final states, a row prefix, a stream, a scale (176 .. 2224: caught by the per-plane checksums), a checksum
+        for where in (entry.blob.nbytes - 40, 146, entry.blob.nbytes // 2, 200, 2230):
             old = raw[where]
             raw[where] = old ^ 0x3c
             ret, mask = engine.retrieve(toks)

@@ -489,6 +489,13 @@ def test_corrupt_blob_is_flagged(nat, ctx):
     ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
     torch.cuda.synchronize()
     assert ctx.status(clear=True) & 4
+    # a flipped scale would rescale a whole token row without the coder noticing: the per-plane checksums do
+    for where in (hdr.off_scales + 2, hdr.off_scales + 2 * T + 31, hdr.off_scsum + 5):
+        bad = blob_dev.clone()
+        bad[where] ^= 0x01
+        ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+        torch.cuda.synchronize()
+        assert ctx.status(clear=True) & 16, where
     # and the intact blob still decodes
     ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
     torch.cuda.synchronize()
@@ -512,7 +519,7 @@ def test_fuzzed_blobs_never_fault_and_are_flagged(nat, ctx):
     flagged = 0
     for it in range(40):
         bad = blob_dev.clone()
-        lo = hdr.off_cdf if it % 2 else hdr.off_streams
+        lo = (hdr.off_scales, hdr.off_cdf, hdr.off_streams)[it % 3]
         npos = int(torch.randint(1, 17, (1,), generator=g))
         pos = torch.randint(lo, total, (npos,), generator=g)
         if it % 5 == 4:  # a run of garbage instead of single bytes
