@@ -119,7 +119,7 @@ def test_blob_roundtrip_equals_quant_dequant(oracle, dtype):
 
 
 def test_blob_roundtrip_random_geometries(oracle):
-    """Format v3 end to end in the oracle over random geometries: ragged channel counts (idle lanes in the last
+    """The blob format end to end in the oracle over random geometries: ragged channel counts (idle lanes in the last
     group), bins anywhere in 4..32, chunk lengths on both sides of the one-byte / two-byte count boundary, and
     peaky data (few symbols per channel, counts that saturate)."""
     rng = np.random.default_rng(7)
@@ -144,3 +144,11 @@ def test_blob_roundtrip_random_geometries(oracle):
         assert np.array_equal(oracle.decode_blob(blob, oracle.BF16),
                               oracle.dequantize(sym, scale, code, bins, oracle.BF16)), (it, L, T, H, D)
         assert len(blob) <= oracle.blob_bound(L, T, H, D)
+        # the scales carry a per-plane checksum (format v4): a flipped scale bit, or a flipped checksum bit, fails
+        h = oracle.parse_header(blob)
+        assert h["version"] == 4 and h["off_scsum"] == h["off_scales"] + ((2 * 2 * L * T + 15) & ~15)
+        for where in (h["off_scales"] + int(rng.integers(0, 2 * 2 * L * T)), h["off_scsum"] + int(rng.integers(0, 8 * L))):
+            bad = bytearray(blob)
+            bad[where] ^= 1 << int(rng.integers(0, 8))
+            with pytest.raises(AssertionError, match="rc=-4"):
+                oracle.decode_blob(bytes(bad), oracle.BF16)
