@@ -365,12 +365,13 @@ def test_concurrent_calls_share_one_context(nat, ctx, oracle):
             st = torch.cuda.Stream()
             kv = make_kv(L, T, H, D, torch.bfloat16, "randn", seed)
             kvd = kv.to(DEV)
+            torch.cuda.current_stream().synchronize()  # the upload ran on this thread's current stream
             stride = nat.r16(nat.blob_bound(L, T, H, D))
             for it in range(6):
-                blobs = torch.zeros(stride, dtype=torch.uint8, device=DEV)
-                sizes = torch.zeros(1, dtype=torch.int32, device=DEV)
-                out = torch.zeros_like(kvd)
-                with torch.cuda.stream(st):
+                with torch.cuda.stream(st):  # the fills run on the stream that uses the buffers
+                    blobs = torch.zeros(stride, dtype=torch.uint8, device=DEV)
+                    sizes = torch.zeros(1, dtype=torch.int32, device=DEV)
+                    out = torch.zeros_like(kvd)
                     ctx.encode_chunks(nat.KVLayout.from_chunk(kvd, "vllm"), 0, T, T, bins, blobs.data_ptr(), stride,
                                       sizes.data_ptr(), stream=st.cuda_stream)
                     ctx.decode_chunks(blobs.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T,
