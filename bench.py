@@ -389,9 +389,12 @@ def main(argv=None):
     # algorithmic bytes per step (with OUR container): raw KV read once + blobs written once
     algo_bytes = raw_bytes + blob_bytes
 
-    # per-kernel HIP-event timing on the launch stream (lmc_ctx_profile)
+    # per-kernel HIP-event timing on the launch stream (lmc_ctx_profile).  At this size lmc_encode_chunks launches
+    # the fused kernel (one entry); k_quantize + k_cdf_encode is timed beside it as `encode_paths` below.
     ctx.profile(True)
-    knames = ["k_quantize", "k_cdf_encode"]
+    step()
+    torch.cuda.synchronize()
+    knames = ["k_encode_fused"] if len(ctx.profile_read()) == 1 else ["k_quantize", "k_cdf_encode"]
     ksum = np.zeros(len(knames))
     reps = max(3, min(10, args.steps))
     for _ in range(reps):
@@ -418,11 +421,12 @@ def main(argv=None):
                     "valu_busy_dominant_kernel": prof.get("valu_busy_dominant_kernel")},
                 "profile_source": prof.get("source"),
                 "note": "achieved = (raw KV read once + blob written once) per step / HIP-event time of one step "
-                        "(the whole encode job: k_quantize + k_cdf_encode) on the launch stream over the timed region; "
+                        "(the whole encode job: one k_encode_fused launch) on the launch stream over the timed region; "
                         "kernels_ms_serial = per-kernel HIP events of one job (lmc_ctx_profile); traffic and the VALU "
                         "instruction count come from the rocprofv3 PMC passes summarised in profiles/latest.json "
                         "(FETCH_SIZE doubled for the 16-B/lane streams per MI355X_MICROARCH.md)"}
     res["roofline"] = roofline
+    res["encode_paths"] = encode_paths_ab(ctx, step, stream, max(5, min(20, args.steps)))
 
     if not args.no_extras:
         extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, stream, sp, raw_bytes, blob_bytes,
@@ -439,6 +443,30 @@ def main(argv=None):
         dist.barrier()
         torch.cuda.synchronize()
         dist.destroy_process_group()
+
+
+def encode_paths_ab(ctx, step, stream, reps):
+    """The same job through both launch paths of lmc_encode_chunks (lmc_ctx_set_encode_path), back to back on the
+    launch stream: ms per 16k context."""
+    import torch
+    out = {}
+    try:
+        for name in ("fused", "two_kernels"):
+            ctx.set_encode_path(name)
+            step()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                step()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            out[name + "_ms"] = round(e0.elapsed_time(e1) / reps, 4)
+    finally:
+        ctx.set_encode_path("auto")
+    out["reps"] = reps
+    out["note"] = "default = auto: fused when chunks x planes > 4 x CUs (this workload: 4096 > 1024)"
+    return out
 
 
 def all_ranks_offload(ctx, layout, bins, dev, local_rank, world):

@@ -45,7 +45,7 @@ const char* lmc_strerror(int code);
 int lmc_last_hip_error(void);
 /* ABI version of this header. */
 int lmc_abi_version(void);
-#define LMC_ABI_VERSION 2
+#define LMC_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ */
 /* KV addressing                                                       */
@@ -115,12 +115,24 @@ int lmc_device_status(lmc_ctx* ctx, int clear);
 #define LMC_MAX_PLANES 256
 #define LMC_MAX_CHANNELS 4096
 
+/* Which kernels lmc_encode_chunks launches.  The fused kernel (one workgroup quantises, codes and places a
+ * whole (chunk, plane): k_fused.h) covers 256 < C <= 1024 channels per plane; every other geometry takes
+ * k_quantize + k_cdf_encode whatever the setting.
+ *   AUTO (default)  fused when the job has more (chunk, plane) pairs than the chip has workgroup slots
+ *                   (4 per CU), where it is the faster of the two;
+ *   TWO_KERNELS     never fused;     FUSED  fused for any job size.
+ * The blobs are byte-identical either way; the switch exists for A/B timing and for the parity tests. */
+#define LMC_ENCODE_PATH_AUTO 0
+#define LMC_ENCODE_PATH_TWO_KERNELS 1
+#define LMC_ENCODE_PATH_FUSED 2
+int lmc_ctx_set_encode_path(lmc_ctx* ctx, int path);
+
 /* Per-kernel timing of the NEXT lmc_encode_chunks / lmc_decode_chunks calls:
  * when enabled the call brackets each of its kernels with hipEvents on the
  * caller's stream.  lmc_ctx_profile_read (after the caller has synchronised
  * that stream) returns the durations in ms of the last profiled call, in
- * launch order (encode: k_quantize, k_cdf_encode [which also compacts the streams into the
- * blob]; decode: k_decode) and the number of entries written (<= cap). */
+ * launch order (encode: k_encode_fused, or k_quantize, k_cdf_encode [which also compacts the streams
+ * into the blob]; decode: k_decode) and the number of entries written (<= cap). */
 int lmc_ctx_profile(lmc_ctx* ctx, int enable);
 int lmc_ctx_profile_read(lmc_ctx* ctx, float* ms_out, int cap);
 

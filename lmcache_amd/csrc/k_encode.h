@@ -186,28 +186,13 @@ __device__ __forceinline__ u32 sym_of_token(const u32* symq, int C, int t, bool 
   return (wq >> (8 * (t & 3))) & 0xffu;
 }
 
+// One group stream (chunk, plane, 64-channel group) = global stream id `gid`, by one wave: histogram, counts
+// section, CDF table, interleaved rANS into the stream's scratch slot.  `hist` is the wave's table slice of LDS
+// (ENC_TAB_DWORDS), `ring` its staging ring (ENC_RING_DWORDS).  Returns the finished stream in `t` (ENCODE).
 template <bool QUADSYM, bool ENCODE>
-__global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
-  __shared__ __attribute__((aligned(16))) u32 lds_all[ENC_WAVES * ENC_WAVE_DWORDS];  // the staging rings, then the tables
-  const int lane = threadIdx.x & 63;
-  // everything derived from the wave id is wave-uniform: keep it in SGPRs
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long ngroups_total = (long long)a.nchunks * a.P * a.G;
-  u32* hist = lds_all + ENC_WAVES * ENC_RING_DWORDS + wave * ENC_TAB_DWORDS;  // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
+__device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long long gid, u32* hist, u16* const ring,
+                                                    int lane, PendingTile& t) {
   u16* tab = reinterpret_cast<u16*>(hist);          // [33][64] u16 CDF, written after hist is in registers
-
-  // Workgroup -> streams.  When the streams of a chunk fill whole workgroups, consecutive workgroups take the SAME
-  // position of consecutive CHUNKS (chunk = block % nchunks): the predecessors a workgroup's placement depends on
-  // (lower positions of its own chunk) were then dispatched at least nchunks workgroups earlier and have normally
-  // published their lengths by the time it looks back -- with chunk-major order they finish at the same moment
-  // and every look-back waits for the slowest of them.
-  long long gid = (long long)blockIdx.x * ENC_WAVES + wave;
-  if (ENCODE && (a.P * a.G) % ENC_WAVES == 0) {
-    const int wpc = a.P * a.G / ENC_WAVES;  // workgroups per chunk
-    const int ch = (int)(blockIdx.x % (unsigned)a.nchunks), pos = (int)(blockIdx.x / (unsigned)a.nchunks);
-    gid = ((long long)ch * wpc + pos) * ENC_WAVES + wave;
-  }
-  if (gid >= ngroups_total) return;
   const int g = (int)(gid % a.G);
   const long long pc = gid / a.G;
   const int p = (int)(pc % a.P);
@@ -337,7 +322,6 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
   // one token: renormalise (append this step's words in ascending lane order), then encode
   // The words of a step (a few dozen bytes) go to a wave-private LDS ring; whenever 128 words have gathered
   // they leave with one coalesced 256-byte store.
-  u16* const ring = reinterpret_cast<u16*>(lds_all + wave * (ENC_RING_DWORDS));
   typedef __attribute__((address_space(3))) u16* lds_u16w;
   const u32 ring_addr = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(lds_u16w)ring);
   const u64 full_exec = __builtin_amdgcn_read_exec();
@@ -434,11 +418,37 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
   const u32 padw = ((16u - (exact & 15u)) & 15u) >> 1;
   if ((u32)lane < padw) out[wcur + lane] = 0;
   if (lane == 0 && exact + 16 > a.cap) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);
+  t.chunk = chunk; t.pg = p * a.G + g; t.exact = exact; t.T = T; t.out = out;
+}
+
+template <bool QUADSYM, bool ENCODE>
+__global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
+  __shared__ __attribute__((aligned(16))) u32 lds_all[ENC_WAVES * ENC_WAVE_DWORDS];  // the staging rings, then the tables
+  const int lane = threadIdx.x & 63;
+  // everything derived from the wave id is wave-uniform: keep it in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long ngroups_total = (long long)a.nchunks * a.P * a.G;
+  u32* hist = lds_all + ENC_WAVES * ENC_RING_DWORDS + wave * ENC_TAB_DWORDS;  // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
+
+  // Workgroup -> streams.  When the streams of a chunk fill whole workgroups, consecutive workgroups take the SAME
+  // position of consecutive CHUNKS (chunk = block % nchunks): the predecessors a workgroup's placement depends on
+  // (lower positions of its own chunk) were then dispatched at least nchunks workgroups earlier and have normally
+  // published their lengths by the time it looks back -- with chunk-major order they finish at the same moment
+  // and every look-back waits for the slowest of them.
+  long long gid = (long long)blockIdx.x * ENC_WAVES + wave;
+  if (ENCODE && (a.P * a.G) % ENC_WAVES == 0) {
+    const int wpc = a.P * a.G / ENC_WAVES;  // workgroups per chunk
+    const int ch = (int)(blockIdx.x % (unsigned)a.nchunks), pos = (int)(blockIdx.x / (unsigned)a.nchunks);
+    gid = ((long long)ch * wpc + pos) * ENC_WAVES + wave;
+  }
+  if (gid >= ngroups_total) return;
+  PendingTile t;
+  encode_group_stream<QUADSYM, ENCODE>(a, gid, hist, reinterpret_cast<u16*>(lds_all + wave * (ENC_RING_DWORDS)), lane, t);
+  if (!ENCODE) return;
   // ---- compaction: where does this stream go? ------------------------------------------------------------
   const int n = a.P * a.G;
-  PendingTile t;
-  t.chunk = chunk; t.pg = p * a.G + g; t.exact = exact; t.T = T; t.out = out;
-  const u32 padded = (exact + 15u) & ~15u;
+  const int chunk = t.chunk;
+  const u32 padded = (t.exact + 15u) & ~15u;
   unsigned long long* agg = a.agg + (long long)chunk * n;
   if (n % ENC_WAVES == 0) {
     // The waves of a workgroup hold consecutive streams of one chunk: they add their lengths up in LDS and

@@ -14,6 +14,7 @@
 #include "k_copy.h"
 #include "k_decode.h"
 #include "k_encode.h"
+#include "k_fused.h"
 #include "k_quantize.h"
 
 static thread_local int g_last_hip = 0;
@@ -37,6 +38,8 @@ struct lmc_ctx {
   hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
   bool ws_used = false;
   int num_cus = 256;
+  int enc_path = LMC_ENCODE_PATH_AUTO;  // lmc_ctx_set_encode_path
+  u32 epoch = 0;                        // of the last fused launch (tags its look-back granules)
   u32* status_h = nullptr;  // pinned, device-accessible
   // optional per-kernel timing (lmc_ctx_profile)
   bool profile = false;
@@ -119,6 +122,13 @@ int lmc_ctx_profile_read(lmc_ctx* c, float* ms_out, int cap) {
   return n;
 }
 
+int lmc_ctx_set_encode_path(lmc_ctx* c, int path) {
+  if (!c || path < LMC_ENCODE_PATH_AUTO || path > LMC_ENCODE_PATH_FUSED) return LMC_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->enc_path = path;
+  return LMC_OK;
+}
+
 int lmc_device_status(lmc_ctx* c, int clear) {
   if (!c) return LMC_ERR_INVALID;
   int v = (int)__atomic_load_n(c->status_h, __ATOMIC_ACQUIRE);
@@ -177,7 +187,7 @@ static int launch_quant_dt(const QuantArgs& a, hipStream_t s) {
 #define LQ(G, N)                                                                                   \
   do {                                                                                             \
     const int per_wg = 4 * (64 / (G)), TO = (a.TQ + 1) / 2; /* row octs per plane-chunk */         \
-    dim3 grid((unsigned)((TO + per_wg - 1) / per_wg), (unsigned)a.P, nz);                          \
+    dim3 grid((unsigned)((TO + per_wg - 1) / per_wg), (unsigned)a.P, nz);                        \
     hipLaunchKernelGGL((k_quantize<G, N, DT, QUAD>), grid, dim3(256), 0, s, a);                    \
   } while (0)
   if (C <= 128) LQ(16, 1);
@@ -220,7 +230,10 @@ static int reserve_locked(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int
   int rc;
   if ((rc = ws_grow((void**)&c->sym4, &c->sym4_bytes, need_sym))) return rc;
   if ((rc = ws_grow((void**)&c->scratch, &c->scratch_bytes, need_scr))) return rc;
+  const size_t agg_before = c->agg_bytes;
   if ((rc = ws_grow((void**)&c->agg, &c->agg_bytes, 2 * need_len))) return rc;
+  // fresh granules must not look like a published value of some epoch (k_fused.h)
+  if (c->agg_bytes != agg_before) HIP_TRY(hipMemset(c->agg, 0, c->agg_bytes));
   return LMC_OK;
 }
 
@@ -297,34 +310,61 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   lmc_blob_layout((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D, bins.rowpre[P], &hl);
   const long long PG = (long long)P * G;
 
-  // Two launches for the whole job: k_quantize, then k_cdf_encode (CDF + coder + in-kernel compaction of the
-  // streams into the blobs).  Measured alternatives that lost are listed in DESIGN.md section 6.
+  EncodeArgs ea;
+  memset(&ea, 0, sizeof ea);
+  ea.sym4 = c->sym4;
+  ea.tok_begin = tok_begin; ea.tok_end = tok_end; ea.chunk_tokens = chunk_tokens; ea.nchunks = nchunks;
+  ea.P = P; ea.C = C; ea.G = G; ea.TQ = TQ;
+  ea.blobs = (u8*)blobs; ea.blob_stride = (long long)blob_stride;
+  ea.scratch = c->scratch; ea.cap = cap;
+  ea.status = job_status ? job_status : c->status_h;
+  ea.bins = bins;
+  ea.agg = c->agg; ea.sizes = sizes;
+  ea.L = L; ea.H = H; ea.D = D; ea.dtype = src->dtype;
+  u8* const scale_base = (u8*)blobs + hl.off_scales;  // off_scales does not depend on T
+
   c->pn = 0;
-  {
+  const bool fused_fits = C > 256 && C <= 1024;  // k_fused.h: the 64-lane quantise tasks, G <= FUSED_MAX_G
+  // AUTO: the fused kernel pays once its (chunk, plane) workgroups outnumber the slots of the chip (4 per CU):
+  // measured on MI355X with 64 planes, 4 / 8 / 12 / 16 / 32 / 64 chunks: fused / two-kernel time = 1.27 / 1.16 /
+  // 1.05 / 1.00 / 0.91 / 0.90 (tools/probes/encode_ab.hip)
+  const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
+                                    (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nchunks * P > 4ll * c->num_cus));
+  if (fused) {
+    // One launch: a workgroup per (chunk, plane) quantises, then codes and places its streams (k_fused.h).
+    FusedArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.src = to_addr(src); fa.e = ea;
+    fa.scale_base = scale_base; fa.scale_stride = (long long)blob_stride;
+    c->epoch = (c->epoch + 1u) & 0x3fffffffu;
+    if (!c->epoch) c->epoch = 1u;
+    fa.epoch = c->epoch;
+    const dim3 grid((unsigned)((long long)nchunks * P)), block(64 * FUSED_WAVES);
+    if ((rc = prof_mark(c, s))) return rc;
+    if (src->dtype == LMC_DTYPE_BF16) {
+      if (C <= 512) hipLaunchKernelGGL((k_encode_fused<1, LMC_DTYPE_BF16, FUSED_WAVES>), grid, block, 0, s, fa);
+      else hipLaunchKernelGGL((k_encode_fused<2, LMC_DTYPE_BF16, FUSED_WAVES>), grid, block, 0, s, fa);
+    } else {
+      if (C <= 512) hipLaunchKernelGGL((k_encode_fused<1, LMC_DTYPE_FP16, FUSED_WAVES>), grid, block, 0, s, fa);
+      else hipLaunchKernelGGL((k_encode_fused<2, LMC_DTYPE_FP16, FUSED_WAVES>), grid, block, 0, s, fa);
+    }
+    HIP_TRY(hipGetLastError());
+    if ((rc = prof_mark(c, s))) return rc;
+  } else {
+    // Two launches for the whole job: k_quantize, then k_cdf_encode (CDF + coder + in-kernel compaction of the
+    // streams into the blobs).  Measured alternatives that lost are listed in DESIGN.md section 6.
     QuantArgs qa;
     memset(&qa, 0, sizeof qa);
     qa.src = to_addr(src); qa.bins = bins;
     qa.tok_begin = tok_begin; qa.tok_end = tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = nchunks;
     qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = nchunks * P;
     qa.sym4 = c->sym4;
-    qa.scale_base = (u8*)blobs + hl.off_scales;  // off_scales does not depend on T
+    qa.scale_base = scale_base;
     qa.scale_stride = (long long)blob_stride;
     qa.agg = c->agg; qa.agg_n = (long long)nchunks * PG;  // zeroed by the quantiser: one dispatch less per job
     if ((rc = prof_mark(c, s))) return rc;
     if ((rc = launch_quant<true>(qa, s))) return rc;
     if ((rc = prof_mark(c, s))) return rc;
-
-    EncodeArgs ea;
-    memset(&ea, 0, sizeof ea);
-    ea.sym4 = qa.sym4;
-    ea.tok_begin = tok_begin; ea.tok_end = tok_end; ea.chunk_tokens = chunk_tokens; ea.nchunks = nchunks;
-    ea.P = P; ea.C = C; ea.G = G; ea.TQ = TQ;
-    ea.blobs = (u8*)blobs; ea.blob_stride = (long long)blob_stride;
-    ea.scratch = c->scratch; ea.cap = cap;
-    ea.status = job_status ? job_status : c->status_h;
-    ea.bins = bins;
-    ea.agg = c->agg; ea.sizes = sizes;
-    ea.L = L; ea.H = H; ea.D = D; ea.dtype = src->dtype;
     const long long ngroups = (long long)nchunks * PG;
     hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + ENC_WAVES - 1) / ENC_WAVES)), dim3(64 * ENC_WAVES), 0, s, ea);
     HIP_TRY(hipGetLastError());

@@ -72,6 +72,7 @@ SYMBOLS = {
     "lmc_ctx_destroy": (ctypes.c_int, [_vp]),
     "lmc_ctx_reserve": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "lmc_device_status": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lmc_ctx_set_encode_path": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmc_ctx_profile": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lmc_ctx_profile_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
     "lmc_quantize": (ctypes.c_int, [_vp, _PL, _i32, _i32, _vp, _vp, _vp, _vp]),
@@ -97,6 +98,8 @@ SYMBOLS = {
     "lmc_blob_info": (ctypes.c_int, [_vp, _sz, ctypes.POINTER(BlobHeader)]),
 }
 
+ENCODE_PATHS = {"auto": 0, "two_kernels": 1, "fused": 2}  # LMC_ENCODE_PATH_*
+
 _lib = None
 _lib_lock = threading.Lock()
 
@@ -118,7 +121,7 @@ def lib() -> ctypes.CDLL:
             for name, (res, args) in SYMBOLS.items():
                 fn = getattr(L, name)  # AttributeError if the ABI and this binding drift apart
                 fn.restype, fn.argtypes = res, args
-            if L.lmc_abi_version() != 2:
+            if L.lmc_abi_version() != 3:
                 raise NativeError("liblmc_hip.so ABI version mismatch; rebuild")
             _lib = L
     return _lib
@@ -410,6 +413,11 @@ class Context:
         st = self.status(clear=True)
         if st:
             raise NativeError(f"{what}: {describe_status(st)}")
+
+    def set_encode_path(self, path: str) -> None:
+        """Which kernels encode_chunks launches: "auto" (default), "two_kernels" (k_quantize + k_cdf_encode) or
+        "fused" (k_encode_fused; 256 < C <= 1024 only).  Blobs are byte-identical either way (include/lmc_hip.h)."""
+        check(lib().lmc_ctx_set_encode_path(self.handle, ENCODE_PATHS[path]), "lmc_ctx_set_encode_path")
 
     def profile(self, enable: bool) -> None:
         check(lib().lmc_ctx_profile(self.handle, 1 if enable else 0), "lmc_ctx_profile")

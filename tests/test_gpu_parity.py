@@ -602,3 +602,98 @@ def test_unusual_bins_and_ragged_channel_counts(nat, ctx, oracle):
         torch.cuda.synchronize()
         ctx.raise_on_status("decode")
         assert np.array_equal(bits_np(out).reshape(L, 2, T, H * D), oracle.decode_blob(ref, oracle.BF16)), (L, T, H, D, bins)
+
+
+# --------------------------------------------------------------------------
+# The two launch paths of lmc_encode_chunks (include/lmc_hip.h: lmc_ctx_set_encode_path).  Small jobs take
+# k_quantize + k_cdf_encode under the default setting, so the fused kernel is forced here; what AUTO picks at
+# full size is covered by test_full_16k_context_roundtrip_equals_reference_formula and the bench.
+def encode_with_path(nat, ctx, path, *args):
+    ctx.set_encode_path(path)
+    try:
+        return encode(nat, ctx, *args)
+    finally:
+        ctx.set_encode_path("auto")
+
+
+FUSED_SHAPES = [
+    # L, T total, chunk, H, D, dtype, kind
+    (4, 64, 64, 8, 128, torch.bfloat16, "randn"),     # C = 1024, one chunk
+    (2, 600, 256, 8, 128, torch.bfloat16, "rand"),    # three chunks, ragged tail of 88 tokens
+    (2, 236, 236, 8, 128, torch.float16, "outlier"),  # tests/test_serde.py:87-107 chunk length, fp16
+    (1, 33, 33, 5, 128, torch.bfloat16, "outlier"),   # C = 640: partial last group, partial second channel run
+    (3, 130, 50, 4, 128, torch.float16, "randn"),     # C = 512: one channel run per lane
+    (2, 9, 4, 3, 128, torch.bfloat16, "randn"),       # C = 384, chunks shorter than a row oct
+    (1, 300, 300, 8, 128, torch.bfloat16, "randn"),   # T > 256 in one chunk (two-byte counts)
+    (1, 1, 1, 8, 128, torch.bfloat16, "randn"),       # a single token
+]
+
+
+@pytest.mark.parametrize("shape", FUSED_SHAPES, ids=lambda s: f"L{s[0]}T{s[1]}c{s[2]}H{s[3]}D{s[4]}{'bf' if s[5] == torch.bfloat16 else 'fp'}")
+def test_fused_encode_equals_two_kernel_encode_and_oracle(nat, ctx, oracle, shape):
+    L, Ttot, cs, H, D, dtype, kind = shape
+    kv = make_kv(L, Ttot, H, D, dtype, kind, seed=7 * L + Ttot)
+    bins = default_bins(L)
+    lay = nat.KVLayout.from_chunk(kv.to(DEV), "vllm")
+    fused, _, _ = encode_with_path(nat, ctx, "fused", lay, 0, Ttot, cs, bins)
+    two, _, _ = encode_with_path(nat, ctx, "two_kernels", lay, 0, Ttot, cs, bins)
+    assert len(fused) == len(two) == (Ttot + cs - 1) // cs
+    for i, (bf, bt) in enumerate(zip(fused, two)):
+        t0, t1 = i * cs, min(Ttot, (i + 1) * cs)
+        b, code = oracle.torch_to_bits(kv[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
+        ref = oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+        assert bt == ref, f"two-kernel path, chunk {i}"
+        assert bf == ref, f"fused path, chunk {i}"
+
+
+def test_fused_encode_special_rows_and_repeated_jobs(nat, ctx, oracle):
+    """Zero / inf / NaN / denormal-scale rows through the fused kernel's own quantise stage, and back-to-back jobs
+    into the same workspace: the look-back granules of job n must not be taken for job n + 1's (epoch tags)."""
+    L, T, H, D = 2, 96, 8, 128
+    bins = default_bins(L)
+    g = torch.Generator().manual_seed(77)
+    for rep in range(3):
+        kv = torch.randn(L, 2, T, H, D, generator=g)
+        kv[:, :, 5 + rep] = 0.0
+        kv[0, 0, 17, 3, 11] = float("inf")
+        kv[1, 1, 40, 0, 0] = float("nan")
+        kv[:, :, 60:64] *= 1e-30
+        kv = kv.to(torch.bfloat16)
+        lay = nat.KVLayout.from_chunk(kv.to(DEV), "vllm")
+        fused, _, _ = encode_with_path(nat, ctx, "fused", lay, 0, T, 32, bins)
+        for i, blob in enumerate(fused):
+            b, code = oracle.torch_to_bits(kv[:, :, 32 * i:32 * (i + 1)].reshape(L, 2, 32, H * D))
+            assert blob == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)), f"job {rep}, chunk {i}"
+
+
+@pytest.mark.parametrize("layout", ["NBHD", "NHBD"])
+def test_fused_encode_gathers_paged_blocks(nat, ctx, oracle, layout):
+    """slot_mapping gather inside the fused kernel (LLM_Engine.rst:91-122), kv-tuple plane pointers."""
+    L, T, H, D, bs, nb = 2, 80, 8, 128, 16, 11
+    g = torch.Generator().manual_seed(31)
+    shape = (2, nb, bs, H, D) if layout == "NBHD" else (2, nb, H, bs, D)
+    caches = [torch.randn(shape, generator=g).to(torch.bfloat16).to(DEV) for _ in range(L)]
+    slots = torch.randperm(nb * bs, generator=g)[:T]
+    lay = nat.KVLayout.paged(caches, slots, bs, layout)
+    bins = default_bins(L)
+    fused, _, _ = encode_with_path(nat, ctx, "fused", lay, 0, T, 48, bins)
+    dense = torch.zeros(L, 2, T, H, D, dtype=torch.bfloat16)
+    for l in range(L):
+        c = caches[l].cpu()
+        for t, s in enumerate(slots.tolist()):
+            blk, w = divmod(s, bs)
+            dense[l, :, t] = c[:, blk, w] if layout == "NBHD" else c[:, blk, :, w]
+    for i, blob in enumerate(fused):
+        t0, t1 = 48 * i, min(T, 48 * (i + 1))
+        b, code = oracle.torch_to_bits(dense[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
+        assert blob == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)), f"chunk {i}"
+
+
+def test_fused_setting_falls_back_outside_its_geometry(nat, ctx, oracle):
+    """C = 128 and C = 4096 are outside the fused kernel's range: the setting is a preference, the job still runs."""
+    for (L, T, H, D) in ((2, 20, 1, 128), (1, 12, 32, 128)):
+        kv = make_kv(L, T, H, D, torch.bfloat16, "randn", seed=H)
+        bins = default_bins(L)
+        blobs, _, _ = encode_with_path(nat, ctx, "fused", nat.KVLayout.from_chunk(kv.to(DEV), "vllm"), 0, T, T, bins)
+        b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
+        assert blobs[0] == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))

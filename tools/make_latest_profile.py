@@ -9,14 +9,17 @@ fetch.db  --pmc FETCH_SIZE GRBM_GUI_ACTIVE
 write.db  --pmc WRITE_SIZE
 (separate passes, as MI355X_MICROARCH.md prescribes).  Only full-context dispatches (>= 4 M work-items) count.
 FETCH_SIZE is doubled for k_quantize (16 B / lane streaming loads: the guide's gfx950 correction), taken as is for
-k_cdf_encode (4 B / lane symbol loads and its own L2-hot scratch re-read).
+k_cdf_encode (4 B / lane symbol loads and its own L2-hot scratch re-read).  k_encode_fused (the default launch at
+the bench's size) mixes both kinds; its fabric reads are dominated by the 16 B / lane loads of the raw KV (the
+symbols and the scratch come back from L2), so its FETCH_SIZE is doubled too: an upper bound.
+Kernels that did not run in the profiled command are skipped.
 """
 import json
 import sqlite3
 import sys
 
-MIN_GRID = 4_000_000
-KERNELS = {"k_quantize": 2.0, "k_cdf_encode": 1.0}  # kernel name prefix -> FETCH_SIZE factor
+MIN_GRID = 2_000_000  # k_encode_fused: 4096 workgroups x 512
+KERNELS = {"k_encode_fused": 2.0, "k_quantize": 2.0, "k_cdf_encode": 1.0}  # kernel name prefix -> FETCH_SIZE factor
 
 
 def counters(path):
@@ -38,6 +41,8 @@ def main(argv):
     traffic = valu = 0.0
     dominant, dom_us = None, 0.0
     for k, factor in KERNELS.items():
+        if k not in csq or k not in cfe or k not in cwr:
+            continue
         fetch_kib = cfe[k]["FETCH_SIZE"][0]
         write_kib = cwr[k]["WRITE_SIZE"][0]
         gui, dur_ns, _ = cfe[k]["GRBM_GUI_ACTIVE"]

@@ -1,0 +1,205 @@
+// encode_ab.hip -- torch-free A/B of lmc_encode_chunks' two launch paths (lmc_ctx_set_encode_path) through the C ABI.
+//
+//   hipcc --offload-arch=gfx950 -O2 -o gpurun_out/encode_ab tools/probes/encode_ab.hip \
+//         -Iinclude -Llmcache_amd/csrc -llmc_hip -Wl,-rpath,'$ORIGIN/../lmcache_amd/csrc'
+//   ./gpurun_out/encode_ab [L H D ctx chunk dtype(0 bf16 / 1 fp16) reps dist(0 rand / 1 signed / 2 zero rows)]
+//
+// Fills a [L][2][ctx][H][D] KV with hashed pseudo-random values on the GPU, encodes it with the two-kernel path
+// and with the fused kernel, compares sizes and every blob byte on the device, and times both (HIP events over
+// `reps` back-to-back jobs, plus the per-kernel events of lmc_ctx_profile).  Starts in seconds (no Python), so
+// a kernel experiment costs a fraction of a GPU-minute.  The two-kernel path is the one the parity suite pins
+// to the oracle; byte equality with it is the fused kernel's parity.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "lmc_hip.h"
+
+#define CK(x)                                                                 \
+  do {                                                                        \
+    hipError_t e__ = (x);                                                     \
+    if (e__ != hipSuccess) {                                                  \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e__), __FILE__, __LINE__); \
+      exit(2);                                                                \
+    }                                                                         \
+  } while (0)
+#define LK(x)                                                                 \
+  do {                                                                        \
+    int r__ = (x);                                                            \
+    if (r__ != 0) {                                                           \
+      fprintf(stderr, "lmc error %d (%s) at %s:%d\n", r__, lmc_strerror(r__), __FILE__, __LINE__); \
+      exit(3);                                                                \
+    }                                                                         \
+  } while (0)
+
+__device__ inline unsigned hash32(unsigned long long i) {
+  unsigned long long z = i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned)(z >> 32);
+}
+
+// dist 0: uniform [0,1) (the bench's default); 1: uniform (-1,1); 2: like 1 with every 37th token row zero and a
+// few inf / NaN elements (the quantiser's special rows)
+__global__ void fill(unsigned short* kv, long long n, int dtype, int dist, int C) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    unsigned h = hash32((unsigned long long)i);
+    float f = (float)(h >> 8) * (1.0f / 16777216.0f);
+    if (dist >= 1) f = 2.0f * f - 1.0f;
+    if (dist == 2) {
+      const long long row = i / C;
+      if (row % 37 == 5) f = 0.0f;
+      if ((h & 0xfffff) == 7) f = __builtin_inff();
+      if ((h & 0xfffff) == 9) f = __builtin_nanf("");
+    }
+    unsigned short b;
+    if (dtype == 0) {
+      unsigned u = __float_as_uint(f);
+      b = (f != f) ? 0x7fc0 : (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    } else {
+      b = __builtin_bit_cast(unsigned short, (_Float16)f);
+    }
+    kv[i] = b;
+  }
+}
+
+__global__ void compare(const unsigned char* a, const unsigned char* b, unsigned long long stride, const unsigned* sizes,
+                        int nchunks, unsigned long long* mismatches, unsigned long long* first_bad) {
+  const int chunk = blockIdx.y;
+  const unsigned n16 = sizes[chunk] / 16;
+  const uint4* pa = (const uint4*)(a + chunk * stride);
+  const uint4* pb = (const uint4*)(b + chunk * stride);
+  unsigned long long bad = 0;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) {
+    uint4 x = pa[i], y = pb[i];
+    if (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) {
+      bad++;
+      atomicMin(first_bad, (unsigned long long)chunk * stride + 16ull * i);
+    }
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+static int plane_bins(int p, int L) {  // CacheGenConfig of the 32-layer families (cachegen_basics.py)
+  const int kv = p >= L, l = p - kv * L;
+  if (!kv) return l < 10 ? 32 : 16;
+  return l < 2 ? 32 : 16;
+}
+
+int main(int argc, char** argv) {
+  int L = 32, H = 8, D = 128, ctx_tok = 16384, chunk = 256, dtype = 0, reps = 20, dist = 0;
+  if (argc > 1) L = atoi(argv[1]);
+  if (argc > 2) H = atoi(argv[2]);
+  if (argc > 3) D = atoi(argv[3]);
+  if (argc > 4) ctx_tok = atoi(argv[4]);
+  if (argc > 5) chunk = atoi(argv[5]);
+  if (argc > 6) dtype = atoi(argv[6]);
+  if (argc > 7) reps = atoi(argv[7]);
+  if (argc > 8) dist = atoi(argv[8]);
+  const int C = H * D, P = 2 * L;
+  const int nchunks = (ctx_tok + chunk - 1) / chunk;
+  const long long nelem = (long long)P * ctx_tok * C;
+  printf("L=%d H=%d D=%d ctx=%d chunk=%d dtype=%d dist=%d: %d chunks, %.1f MB raw\n", L, H, D, ctx_tok, chunk, dtype,
+         dist, nchunks, nelem * 2 / 1e6);
+
+  unsigned short* kv;
+  CK(hipMalloc(&kv, nelem * 2));
+  fill<<<4096, 256>>>(kv, nelem, dtype, dist, C);
+  CK(hipGetLastError());
+
+  std::vector<int32_t> bins(P);
+  for (int p = 0; p < P; p++) bins[p] = plane_bins(p, L);
+
+  lmc_kv_layout lay;
+  memset(&lay, 0, sizeof lay);
+  lay.dtype = dtype == 0 ? LMC_DTYPE_BF16 : LMC_DTYPE_FP16;
+  lay.num_layers = L; lay.num_heads = H; lay.head_size = D;
+  lay.base = kv;
+  lay.stride_layer = 2ll * ctx_tok * C; lay.stride_kv = (long long)ctx_tok * C; lay.stride_token = C; lay.stride_head = D;
+
+  lmc_ctx* ctx;
+  LK(lmc_ctx_create(0, &ctx));
+  const uint64_t stride = (lmc_blob_bound(L, chunk, H, D) + 15) & ~15ull;
+  unsigned char *blob_a, *blob_b;
+  unsigned *size_a, *size_b;
+  CK(hipMalloc(&blob_a, stride * nchunks));
+  CK(hipMalloc(&blob_b, stride * nchunks));
+  CK(hipMalloc(&size_a, 4 * nchunks));
+  CK(hipMalloc(&size_b, 4 * nchunks));
+  CK(hipMemset(blob_a, 0xA5, stride * nchunks));  // different garbage: every compared byte has to be written
+  CK(hipMemset(blob_b, 0x5A, stride * nchunks));
+  unsigned* status;  // pinned job status word
+  CK(hipHostMalloc((void**)&status, 64, hipHostMallocMapped));
+  status[0] = status[1] = 0;
+  hipStream_t s;
+  CK(hipStreamCreate(&s));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+
+  const int paths[2] = {LMC_ENCODE_PATH_TWO_KERNELS, LMC_ENCODE_PATH_FUSED};
+  const char* names[2] = {"two-kernel", "fused"};
+  unsigned char* blobs[2] = {blob_a, blob_b};
+  unsigned* sizes[2] = {size_a, size_b};
+  double ms_path[2] = {0, 0};
+  for (int k = 0; k < 2; k++) {
+    LK(lmc_ctx_set_encode_path(ctx, paths[k]));
+    // the first job twice: the second run of the fused path meets the first one's granules (epoch tags)
+    for (int w = 0; w < 2; w++)
+      LK(lmc_encode_chunks(ctx, &lay, 0, ctx_tok, chunk, bins.data(), blobs[k], stride, sizes[k], status + k, s));
+    CK(hipStreamSynchronize(s));
+    CK(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; r++)
+      LK(lmc_encode_chunks(ctx, &lay, 0, ctx_tok, chunk, bins.data(), blobs[k], stride, sizes[k], status + k, s));
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms_path[k] = ms / reps;
+    LK(lmc_ctx_profile(ctx, 1));
+    float km[8] = {0};
+    double ksum[2] = {0, 0};
+    int nk = 0;
+    for (int r = 0; r < 5; r++) {
+      LK(lmc_encode_chunks(ctx, &lay, 0, ctx_tok, chunk, bins.data(), blobs[k], stride, sizes[k], status + k, s));
+      CK(hipStreamSynchronize(s));
+      nk = lmc_ctx_profile_read(ctx, km, 8);
+      for (int i = 0; i < nk && i < 2; i++) ksum[i] += km[i];
+    }
+    LK(lmc_ctx_profile(ctx, 0));
+    printf("%-10s  %.4f ms per job (%.1f GB/s raw)  kernels:", names[k], ms_path[k], nelem * 2 / ms_path[k] / 1e6);
+    for (int i = 0; i < nk && i < 2; i++) printf(" %.4f", ksum[i] / 5);
+    printf("  status=%u\n", status[k]);
+  }
+
+  // parity: sizes and bytes
+  std::vector<unsigned> ha(nchunks), hb(nchunks);
+  CK(hipMemcpy(ha.data(), size_a, 4 * nchunks, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hb.data(), size_b, 4 * nchunks, hipMemcpyDeviceToHost));
+  int size_bad = 0;
+  unsigned long long total = 0;
+  for (int i = 0; i < nchunks; i++) {
+    if (ha[i] != hb[i]) { if (size_bad < 5) printf("chunk %d: size %u vs %u\n", i, ha[i], hb[i]); size_bad++; }
+    if (ha[i] == 0 || ha[i] > stride || (ha[i] & 15)) { printf("chunk %d: implausible size %u\n", i, ha[i]); size_bad++; }
+    total += ha[i];
+  }
+  unsigned long long *mm, hmm[2] = {0, ~0ull};
+  CK(hipMalloc(&mm, 16));
+  CK(hipMemcpy(mm, hmm, 16, hipMemcpyHostToDevice));
+  compare<<<dim3(64, nchunks), 256, 0, s>>>(blob_a, blob_b, stride, size_a, nchunks, mm, mm + 1);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(s));
+  CK(hipMemcpy(hmm, mm, 16, hipMemcpyDeviceToHost));
+  printf("blobs: %.1f MB (%.2fx); size mismatches %d; 16-byte words that differ %llu", total / 1e6,
+         nelem * 2.0 / total, size_bad, hmm[0]);
+  if (hmm[0]) printf(" (first at arena offset %llu = chunk %llu + %llu)", hmm[1], hmm[1] / stride, hmm[1] % stride);
+  printf("\n");
+  const bool ok = !size_bad && !hmm[0] && !status[0] && !status[1];
+  printf("%s  fused/two-kernel time = %.3f\n", ok ? "PARITY OK" : "PARITY FAILED", ms_path[1] / ms_path[0]);
+  LK(lmc_ctx_destroy(ctx));
+  return ok ? 0 : 1;
+}
