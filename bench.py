@@ -260,6 +260,8 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dist", choices=["rand", "randn", "outlier"], default="rand",
                     help="synthetic KV distribution of the timed workload (SURVEY.md section 8d)")
+    ap.add_argument("--ramp-ms", type=float, default=250.0,
+                    help="untimed clock ramp before the warm-up steps: full steps for this many ms (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region and the roofline")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the cpu_baseline sample (0 = auto)")
@@ -322,6 +324,18 @@ def main(argv=None):
         def step():
             ctx.encode_chunks(layout, 0, CTX, CHUNK, bins, blobs.data_ptr(), stride, sizes.data_ptr(), stream=sp)
 
+    # Clock ramp, before the W warm-up steps and outside every timed region: a GPU that has just left idle runs its
+    # first ~50 ms of work below its sustained clock (tools/probes/encode_ab.hip, alternating rounds: the first 40
+    # jobs average 1.23 ms, every later round 1.185), which is longer than W + K steps of this workload.  The
+    # same full steps on the same buffers, ~0.25 s of them.
+    ramp_steps = 0
+    if not STUB and args.ramp_ms > 0:
+        t_r = time.perf_counter()
+        while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
+            for _ in range(10):
+                step()
+            sync()
+            ramp_steps += 10
     for _ in range(args.warmup):
         step()
     sync()
@@ -373,7 +387,10 @@ def main(argv=None):
                                   "(BASELINE configs[1])",
                       "layers": L, "kv_heads": H, "head_dim": D, "context_tokens": CTX, "chunk_tokens": CHUNK,
                       "chunks": nchunks, "raw_kv_bytes": raw_bytes, "sharding": f"{world} x independent contexts",
-                      "numa_node": numa}}
+                      "numa_node": numa},
+           "clock_ramp": {"untimed_steps_before_warmup": ramp_steps, "ms": args.ramp_ms,
+                          "why": "a GPU fresh out of idle runs its first ~50 ms below its sustained clock; W + K steps "
+                                 "of this workload are shorter than that (--ramp-ms 0 turns it off)"}}
     if STUB:
         res["data"] = "stub (CPU rehearsal of the launch plumbing, no kernel ran)"
         print(json.dumps(res))
@@ -451,17 +468,18 @@ def encode_paths_ab(ctx, step, stream, reps):
     import torch
     out = {}
     try:
-        for name in ("fused", "two_kernels"):
-            ctx.set_encode_path(name)
-            step()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(reps):
+        for rnd in range(2):  # alternating rounds, the second one reported: neither path gets the warmer GPU
+            for name in ("two_kernels", "fused"):
+                ctx.set_encode_path(name)
                 step()
-            e1.record(stream)
-            torch.cuda.synchronize()
-            out[name + "_ms"] = round(e0.elapsed_time(e1) / reps, 4)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(reps):
+                    step()
+                e1.record(stream)
+                torch.cuda.synchronize()
+                out[name + "_ms"] = round(e0.elapsed_time(e1) / reps, 4)
     finally:
         ctx.set_encode_path("auto")
     out["reps"] = reps

@@ -150,6 +150,8 @@ __device__ __forceinline__ u32 lookback_exclusive(unsigned long long* agg, int i
 
 // Move a finished stream from its scratch slot to offset `excl` of the chunk's streams section, record its
 // end in the directory; the chunk's last group also writes header, bins, rowpre, pads and the size word.
+// STATIC = false: the caller writes the chunk's static sections itself (k_fused.h).
+template <bool STATIC = true>
 __device__ __forceinline__ void place_stream(const EncodeArgs& a, const PendingTile& t, u32 excl, int lane) {
   const int n = a.P * a.G;
   const u32 padded = (t.exact + 15u) & ~15u;
@@ -162,7 +164,7 @@ __device__ __forceinline__ void place_stream(const EncodeArgs& a, const PendingT
   const u32 n16 = padded >> 4;
 #pragma unroll 4
   for (u32 i = lane; i < n16; i += 64) dst[i] = src[i];
-  if (t.pg == n - 1) {  // the last group knows the chunk's size: header, static sections, size word
+  if (STATIC && t.pg == n - 1) {  // the last group knows the chunk's size: header, static sections, size word
     write_blob_static(blob, bo, a, t.T, excl + padded, lane);
     if (lane == 0) a.sizes[t.chunk] = bo.streams + excl + padded;
   }

@@ -271,6 +271,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     PendingTile t;
     t.chunk = chunk; t.pg = p * a.G + g; t.exact = st_len[g]; t.T = (u32)Tc;
     t.out = reinterpret_cast<const u16*>(a.scratch + (gid0 + g) * (long long)a.cap);
-    place_stream(a, t, wg_excl + intra, lane);
+    place_stream<false>(a, t, wg_excl + intra, lane);
+  }
+  // The chunk's last plane knows the chunk's size: header, static sections, size word (kept out of the stream loop:
+  // inlined there, its loop invariants were hoisted over the loop and spilled by every wave).
+  if (p == a.P - 1 && wave == 0) {
+    const BlobOff bo = lmc_blob_off((u32)a.P, (u32)Tc, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
+    u8* blob = a.blobs + (long long)chunk * a.blob_stride;
+    write_blob_static(blob, bo, a, (u32)Tc, wg_excl + wg_total, lane);
+    if (lane == 0) a.sizes[chunk] = bo.streams + wg_excl + wg_total;
   }
 }

@@ -2,7 +2,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -o gpurun_out/encode_ab tools/probes/encode_ab.hip \
 //         -Iinclude -Llmcache_amd/csrc -llmc_hip -Wl,-rpath,'$ORIGIN/../lmcache_amd/csrc'
-//   ./gpurun_out/encode_ab [L H D ctx chunk dtype(0 bf16 / 1 fp16) reps dist(0 rand / 1 signed / 2 zero rows)]
+//   ./gpurun_out/encode_ab [L H D ctx chunk dtype(0 bf16 / 1 fp16) reps dist(0 rand / 1 signed / 2 zero rows) rounds]
 //
 // Fills a [L][2][ctx][H][D] KV with hashed pseudo-random values on the GPU, encodes it with the two-kernel path
 // and with the fused kernel, compares sizes and every blob byte on the device, and times both (HIP events over
@@ -91,7 +91,7 @@ static int plane_bins(int p, int L) {  // CacheGenConfig of the 32-layer familie
 }
 
 int main(int argc, char** argv) {
-  int L = 32, H = 8, D = 128, ctx_tok = 16384, chunk = 256, dtype = 0, reps = 20, dist = 0;
+  int L = 32, H = 8, D = 128, ctx_tok = 16384, chunk = 256, dtype = 0, reps = 20, dist = 0, rounds = 1;
   if (argc > 1) L = atoi(argv[1]);
   if (argc > 2) H = atoi(argv[2]);
   if (argc > 3) D = atoi(argv[3]);
@@ -100,6 +100,7 @@ int main(int argc, char** argv) {
   if (argc > 6) dtype = atoi(argv[6]);
   if (argc > 7) reps = atoi(argv[7]);
   if (argc > 8) dist = atoi(argv[8]);
+  if (argc > 9) rounds = atoi(argv[9]);
   const int C = H * D, P = 2 * L;
   const int nchunks = (ctx_tok + chunk - 1) / chunk;
   const long long nelem = (long long)P * ctx_tok * C;
@@ -146,34 +147,38 @@ int main(int argc, char** argv) {
   unsigned char* blobs[2] = {blob_a, blob_b};
   unsigned* sizes[2] = {size_a, size_b};
   double ms_path[2] = {0, 0};
-  for (int k = 0; k < 2; k++) {
-    LK(lmc_ctx_set_encode_path(ctx, paths[k]));
-    // the first job twice: the second run of the fused path meets the first one's granules (epoch tags)
-    for (int w = 0; w < 2; w++)
-      LK(lmc_encode_chunks(ctx, &lay, 0, ctx_tok, chunk, bins.data(), blobs[k], stride, sizes[k], status + k, s));
-    CK(hipStreamSynchronize(s));
-    CK(hipEventRecord(e0, s));
-    for (int r = 0; r < reps; r++)
-      LK(lmc_encode_chunks(ctx, &lay, 0, ctx_tok, chunk, bins.data(), blobs[k], stride, sizes[k], status + k, s));
-    CK(hipEventRecord(e1, s));
-    CK(hipStreamSynchronize(s));
-    float ms;
-    CK(hipEventElapsedTime(&ms, e0, e1));
-    ms_path[k] = ms / reps;
-    LK(lmc_ctx_profile(ctx, 1));
-    float km[8] = {0};
-    double ksum[2] = {0, 0};
-    int nk = 0;
-    for (int r = 0; r < 5; r++) {
-      LK(lmc_encode_chunks(ctx, &lay, 0, ctx_tok, chunk, bins.data(), blobs[k], stride, sizes[k], status + k, s));
+  // `rounds` alternating timing rounds (two-kernel, fused, two-kernel, ...): the first round runs on a GPU that
+  // has just left idle, so the order of a single A/B would bias it
+  for (int round = 0; round < rounds; round++) {
+    for (int k = 0; k < 2; k++) {
+      LK(lmc_ctx_set_encode_path(ctx, paths[k]));
+      // the first job twice: the second run of the fused path meets the first one's granules (epoch tags)
+      for (int w = 0; w < 2; w++)
+        LK(lmc_encode_chunks(ctx, &lay, 0, ctx_tok, chunk, bins.data(), blobs[k], stride, sizes[k], status + k, s));
       CK(hipStreamSynchronize(s));
-      nk = lmc_ctx_profile_read(ctx, km, 8);
-      for (int i = 0; i < nk && i < 2; i++) ksum[i] += km[i];
+      CK(hipEventRecord(e0, s));
+      for (int r = 0; r < reps; r++)
+        LK(lmc_encode_chunks(ctx, &lay, 0, ctx_tok, chunk, bins.data(), blobs[k], stride, sizes[k], status + k, s));
+      CK(hipEventRecord(e1, s));
+      CK(hipStreamSynchronize(s));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ms_path[k] = ms / reps;
+      LK(lmc_ctx_profile(ctx, 1));
+      float km[8] = {0};
+      double ksum[2] = {0, 0};
+      int nk = 0;
+      for (int r = 0; r < 5; r++) {
+        LK(lmc_encode_chunks(ctx, &lay, 0, ctx_tok, chunk, bins.data(), blobs[k], stride, sizes[k], status + k, s));
+        CK(hipStreamSynchronize(s));
+        nk = lmc_ctx_profile_read(ctx, km, 8);
+        for (int i = 0; i < nk && i < 2; i++) ksum[i] += km[i];
+      }
+      LK(lmc_ctx_profile(ctx, 0));
+      printf("%-10s  %.4f ms per job (%.1f GB/s raw)  kernels:", names[k], ms_path[k], nelem * 2 / ms_path[k] / 1e6);
+      for (int i = 0; i < nk && i < 2; i++) printf(" %.4f", ksum[i] / 5);
+      printf("  status=%u\n", status[k]);
     }
-    LK(lmc_ctx_profile(ctx, 0));
-    printf("%-10s  %.4f ms per job (%.1f GB/s raw)  kernels:", names[k], ms_path[k], nelem * 2 / ms_path[k] / 1e6);
-    for (int i = 0; i < nk && i < 2; i++) printf(" %.4f", ksum[i] / 5);
-    printf("  status=%u\n", status[k]);
   }
 
   // parity: sizes and bytes
