@@ -172,10 +172,18 @@ __device__ __forceinline__ void place_stream(const EncodeArgs& a, const PendingT
 
 // Symbol of token i (0..31) of a 32-token block whose workspace dwords are in w (k_quantize.h formats):
 // bytes: dword i / 4, byte i % 4;  nibbles: dword i / 8, byte (i % 8) % 4, high nibble for i % 8 >= 4.
+// v_bfe_u32 as an opaque instruction: given the builtin, the compiler merges the extraction with the table-row
+// scaling that follows into shift + and + add (3 VALU); bfe + v_lshl_add_u32 is 2.
+template <int POS, int WIDTH>
+__device__ __forceinline__ u32 bfe_op(u32 w) {
+  u32 r;
+  asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "n"(POS), "n"(WIDTH));
+  return r;
+}
 template <bool NIB, int I>
 __device__ __forceinline__ u32 sym_of_block(const u32* w) {
-  if (NIB) return __builtin_amdgcn_ubfe(w[I >> 3], 8 * (I & 3) + 4 * ((I >> 2) & 1), 4);
-  return __builtin_amdgcn_ubfe(w[I >> 2], 8 * (I & 3), 8);
+  if (NIB) return bfe_op<8 * (I & 3) + 4 * ((I >> 2) & 1), 4>(w[I >> 3]);
+  return bfe_op<8 * (I & 3), 8>(w[I >> 2]);
 }
 // ... and of an arbitrary token t of the plane-chunk column symq (stride C dwords), for the ragged ends
 template <bool NIB>
@@ -236,11 +244,11 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
       }
 #pragma unroll
       for (int j = 0; j < DPB; j++) {
-#pragma unroll
-        for (int k = 0; k < 32 / DPB; k++) {
-          const u32 sk = __builtin_amdgcn_ubfe(w[j], NIB ? 4 * k : 8 * k, NIB ? 4 : 8);  // any order will do here
+        static_for<32 / DPB>([&](auto ktag) {
+          constexpr int k = decltype(ktag)::value;
+          const u32 sk = bfe_op<(NIB ? 4 : 8) * k, NIB ? 4 : 8>(w[j]);  // any order will do here
           atomicAdd(&hrow[sk * 32], one);  // ds_add_u32 of this lane's half of the dword, bank = lane / 2
-        }
+        });
       }
 #pragma unroll
       for (int j = 0; j < DPB; j++) w[j] = wn[j];
@@ -276,18 +284,23 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
     }
     u8* sec = blob0 + bo.cdf;
     const long long e0 = (long long)a.C * a.bins.rowpre[p] + (long long)g * 64 * R;
+    // entry e = channel e / R, symbol e % R; e advances by 64 per iteration, so (channel, symbol) are stepped by
+    // (64 / R, 64 % R) with one carry instead of being divided out again
+    u32 cl, sidx, dq, dr;
+    divmod_small((u32)lane, R, rcpR, cl, sidx);
+    divmod_small(64u, R, rcpR, dq, dr);
     if (dev_count_bytes(T) == 1u) {
       for (u32 e = lane; e < total; e += 64) {
-        u32 cl, sidx;
-        divmod_small(e, R, rcpR, cl, sidx);
         sec[e0 + e] = (u8)min((u32)tab[sidx * 64 + cl], 255u);
+        sidx += dr; cl += dq;
+        if (sidx >= R) { sidx -= R; cl++; }
       }
     } else {
       u16* dst = reinterpret_cast<u16*>(sec) + e0;
       for (u32 e = lane; e < total; e += 64) {
-        u32 cl, sidx;
-        divmod_small(e, R, rcpR, cl, sidx);
         dst[e] = tab[sidx * 64 + cl];
+        sidx += dr; cl += dq;
+        if (sidx >= R) { sidx -= R; cl++; }
       }
     }
   }
@@ -300,6 +313,18 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
   const u32 T = (u32)Tc;
   // !ENCODE (lmc_calculate_cdf) has no bins: every entry is computed
   cdf_column_to_lds(hreg, T, ENCODE ? (u32)a.bins.b[p] - 1u : 33u, tab, lane);
+  if (ENCODE && nib) {
+    // Planes with <= 16 symbols use table entries 0 .. 16 only: rows 17 .. 32 get the symbols' FREQUENCIES
+    // (row 17 + s = cdf[s + 1] - cdf[s]), so that the token loop reads (start, freq) instead of (start, end)
+    // and saves the subtraction.  A lane reads back its own column: program order is enough.
+    u32 prev = tab[lane];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const u32 nxt = tab[(i + 1) * 64 + lane];
+      tab[(17 + i) * 64 + lane] = (u16)(nxt - prev);
+      prev = nxt;
+    }
+  }
   wave_lds_fence();  // columns are read by other lanes below
   if (ENCODE) {
     // nothing to write: the blob carries the counts (written above), the CDF is a function of them
@@ -366,10 +391,20 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
     constexpr int DPB = NIB ? 4 : 8;
     // ragged head of the descending walk: tokens Tc-1 .. 32*nfull (< 32 of them), one at a time
     const int nfull = Tc >> 5;
+    // second table value of a symbol: its frequency (nibble planes: row 17 + s) or the next CDF entry
+    constexpr int ROW2 = NIB ? 17 * 64 : 64;
+    auto freq_of = [&](u32 lo, u32 v2) -> u32 { return NIB ? v2 : ((v2 - lo) & 0xffffu); };
+    // the table's second value, zero-extended AT the ds_read_u16 (the empty asm keeps the compiler from sinking the
+    // extension to the use in the next iteration, where it costs a v_and per token)
+    auto second = [&](u32 srow) -> u32 {
+      u32 v2 = tab[srow * 64 + ROW2 + lane];
+      if (NIB) asm("" : "+v"(v2));
+      return v2;
+    };
     for (int t = Tc - 1; t >= nfull * 32; t--) {
       const u32 s = sym_of_token<NIB>(symq, a.C, t, active);
-      const u32 lo = tab[s * 64 + lane], hi = tab[s * 64 + 64 + lane];
-      code_token(lo, (hi - lo) & 0xffffu);
+      const u32 lo = tab[s * 64 + lane], v2 = second(s);
+      code_token(lo, freq_of(lo, v2));
     }
     // full 32-token blocks, descending; software pipelined twice over:
     //   - the next block's symbol dwords are loaded while this block is coded,
@@ -379,7 +414,7 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
 #pragma unroll
       for (int j = 0; j < DPB; j++) w[j] = active ? symq[(long long)((nfull - 1) * DPB + j) * a.C] : 0u;
       u32 sn = sym_of_block<NIB, 31>(w);
-      u32 lo_n = tab[sn * 64 + lane], hi_n = tab[sn * 64 + 64 + lane];
+      u32 lo_n = tab[sn * 64 + lane], hi_n = second(sn);
       for (int b = nfull - 1; b >= 0; b--) {
         if (b > 0) {
 #pragma unroll
@@ -387,16 +422,16 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
         }
         static_for<32>([&](auto itag) {
           constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
-          const u32 st = lo_n, f = (hi_n - lo_n) & 0xffffu;
+          const u32 st = lo_n, f = freq_of(lo_n, hi_n);
           if constexpr (i > 0) {  // entries of the next token of this block
             sn = sym_of_block<NIB, i - 1>(w);
             lo_n = tab[sn * 64 + lane];
-            hi_n = tab[sn * 64 + 64 + lane];
+            hi_n = second(sn);
           } else {
             if (b > 0) {          // ... or of the first token of the next block
               sn = sym_of_block<NIB, 31>(wn);
               lo_n = tab[sn * 64 + lane];
-              hi_n = tab[sn * 64 + 64 + lane];
+              hi_n = second(sn);
             }
           }
           code_token(st, f);
