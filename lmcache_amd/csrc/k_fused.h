@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll 1
   for (int g = wave; g < a.G; g += NW) {
     PendingTile t;
-    encode_group_stream<true, true>(a, gid0 + g, hist, ring, lane, t);
+    encode_group_stream<true, true, true>(a, gid0 + g, hist, ring, lane, t);
     if (lane == 0) st_len[g] = t.exact;
     wave_lds_fence();  // the next stream reuses this wave's LDS slices
   }
