@@ -296,3 +296,11 @@ def test_layer_range_schedules():
         for sched in (1, 3, (1, 2), (4, 1), (100,)):
             r = layer_ranges(L, sched)
             assert r[0][0] == 0 and r[-1][1] == L and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+
+
+def test_encode_path_names_follow_the_header():
+    """native.ENCODE_PATHS (what Context.set_encode_path takes) == the LMC_ENCODE_PATH_* constants of lmc_hip.h."""
+    from lmcache_amd import native
+    hdr = open(os.path.join(ROOT, "include", "lmc_hip.h")).read()
+    consts = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define LMC_ENCODE_PATH_(\w+)\s+(\d+)", hdr)}
+    assert consts == native.ENCODE_PATHS
