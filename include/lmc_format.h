@@ -49,15 +49,34 @@
  *                           zero bytes to a multiple of 16.
  *
  * Group stream = interleaved rANS over 64 adjacent channels ("lanes"),
- * 32-bit state, 16-bit renormalisation words, 16-bit probabilities:
+ * 32-bit state words, 16-bit renormalisation words:
  *
  *   [ u16 words, in the order the ENCODER emitted them ][ u32 state[64] ]
  *
  * The encoder walks tokens T-1 .. 0; at each token the lanes that must
  * renormalise append their low 16 state bits in ascending lane order.  The
  * decoder starts from the tail (states), walks tokens 0 .. T-1 and pops words
- * from the end, again in ascending lane order inside one token step.  See
- * DESIGN.md "Entropy coder" for the exact recurrences.
+ * from the end, again in ascending lane order inside one token step.
+ *
+ * header.model says which probabilities the coder runs on (v5); both are
+ * functions of the counts section alone:
+ *
+ *   LMC_MODEL_CDF16 (0)  any T.  The reference's 16-bit CDF itself:
+ *       start = cdf[s], freq = cdf[s+1] - cdf[s], total 2^16, state in
+ *       [2^16, 2^32):   emit while x >= freq << 16;
+ *       x = (x / freq << 16) + x % freq + start.
+ *   LMC_MODEL_COUNTS (1) T == 256 (the reference's chunk size).  The counts
+ *       themselves: a channel's 256 symbols give counts that sum to 2^8, so
+ *       freq = 2 * count, start = 2 * (number of smaller symbols), total 2^9
+ *       (the factor 2 keeps every frequency >= 2, which lets the encoder divide
+ *       with one multiply-high by a 32-bit reciprocal: lmc_rans_magic), state in
+ *       [2^15, 2^31):  emit while x >= freq << 22;
+ *       x = (x / freq << 9) + x % freq + start.
+ *       A channel whose 256 symbols are all equal would need count 256: it is
+ *       coded with count 255 and a count of 1 for symbol 0 (for symbol 1 if the
+ *       channel's own symbol is 0) -- lmc_counts_model.  The code length is the
+ *       channel's empirical entropy to within the 31 bits of final state.
+ * See DESIGN.md "Entropy coder" for the recurrences and their bounds.
  */
 #ifndef LMC_FORMAT_H
 #define LMC_FORMAT_H
@@ -69,7 +88,7 @@ extern "C" {
 #endif
 
 #define LMC_BLOB_MAGIC 0x31434D4Cu /* "LMC1" */
-#define LMC_BLOB_VERSION 4u
+#define LMC_BLOB_VERSION 5u
 #define LMC_HEADER_BYTES 128u
 
 #define LMC_DTYPE_BF16 0
@@ -79,7 +98,13 @@ extern "C" {
 #define LMC_MAX_BINS 32     /* torchac_cuda.calculate_cdf(sym, 32)          */
 #define LMC_LP 33           /* CDF entries per channel = max_bins + 1       */
 #define LMC_PROB_BITS 16
-#define LMC_RANS_L (1u << 16) /* lower bound of the normalised state interval */
+#define LMC_RANS_L (1u << 16) /* CDF16 model: lower bound of the normalised state interval */
+
+#define LMC_MODEL_CDF16 0u
+#define LMC_MODEL_COUNTS 1u
+#define LMC_COUNTS_T 256u          /* chunk length the counts model codes */
+#define LMC_COUNTS_BITS 9u         /* its probabilities are 2 * count out of 2^9 */
+#define LMC_COUNTS_L (1u << 15)    /* ... and its state lives in [2^15, 2^31) */
 #define LMC_CDF_SCALE (65536u - (LMC_LP - 1u)) /* 2^16 - (Lp-1), cachegen_encoder.py:117-119 */
 
 typedef struct lmc_blob_header {
@@ -106,7 +131,8 @@ typedef struct lmc_blob_header {
   uint32_t cdf_rows;     /* rowpre[P] = sum of R over all planes */
   uint32_t count_bytes;  /* bytes per stored count: 1 (T <= 256) or 2 */
   uint32_t off_scsum;    /* per-plane scale checksums */
-  uint32_t reserved[10];
+  uint32_t model;        /* LMC_MODEL_*: = lmc_model_for(ntokens) */
+  uint32_t reserved[9];
 } lmc_blob_header;
 
 static inline uint32_t lmc_r16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -118,6 +144,31 @@ static inline uint32_t lmc_scale_checksum_term(uint32_t t, uint32_t bits) { retu
 static inline uint32_t lmc_cdf_row(uint32_t bins) { return bins - 1u; }
 /* Bytes per stored count for a chunk of T tokens. */
 static inline uint32_t lmc_count_bytes(uint32_t T) { return T <= 256u ? 1u : 2u; }
+
+/* The coder model of a chunk of T tokens. */
+static inline uint32_t lmc_model_for(uint32_t T) { return T == LMC_COUNTS_T ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16; }
+
+/* LMC_MODEL_COUNTS: the counts the coder runs on, from a channel's exact counts cnt[0 .. R) (sum 256, R >= 2):
+ * themselves, except that a count of 256 becomes 255 and symbol 0 (symbol 1 if the channel's only symbol is 0)
+ * gets 1.  freq[s] = 2 * c[s], start[s] = 2 * sum of c below s. */
+static inline void lmc_counts_model(const uint32_t* cnt, uint32_t R, uint32_t* c) {
+  for (uint32_t s = 0; s < R; s++) c[s] = cnt[s];
+  for (uint32_t s = 0; s < R; s++)
+    if (cnt[s] >= LMC_COUNTS_T) { c[s] = LMC_COUNTS_T - 1u; c[s == 0u ? 1u : 0u] = 1u; break; }
+}
+
+/* Reciprocal of the frequency f = 2 * count (count 1 .. 255) for the counts model's encoder:
+ *   x / f == mulhi32(x, magic) >> shift   for every x < 2^31,
+ * magic = ceil(2^(31 + l) / f), shift = l - 1, l = ceil(log2 f) >= 1 (f is even, so l >= 1).  With
+ * e = magic * f - 2^(31 + l) < f <= 2^l the estimate exceeds x / f by x * e / (f * 2^(31 + l)) < 1 / f: its floor
+ * is the quotient.  magic lies in [2^31, 2^32). */
+static inline void lmc_rans_magic(uint32_t count, uint32_t* magic, uint32_t* shift) {
+  uint32_t f = 2u * count, l = 1u;
+  while ((1u << l) < f) l++;
+  uint64_t num = 1ull << (31u + l);
+  *magic = (uint32_t)((num + f - 1u) / f);
+  *shift = l - 1u;
+}
 
 /* Section offsets for a chunk geometry.  cdf_rows = sum over planes of lmc_cdf_row(bins[p]);
  * pass 31 * P (all planes at 32 bins) for an upper bound. */
@@ -131,6 +182,7 @@ static inline void lmc_blob_layout(uint32_t L, uint32_t T, uint32_t H, uint32_t 
   h->nchannels = C; h->nplanes = P; h->ngroups = G; h->lp = LMC_LP;
   h->cdf_rows = cdf_rows;
   h->count_bytes = lmc_count_bytes(T);
+  h->model = lmc_model_for(T);
   h->off_bins = LMC_HEADER_BYTES;
   h->off_rowpre = h->off_bins + lmc_r16(P);
   h->off_scales = h->off_rowpre + lmc_r16(2u * (P + 1u));
@@ -142,7 +194,8 @@ static inline void lmc_blob_layout(uint32_t L, uint32_t T, uint32_t H, uint32_t 
 
 /* Capacity (bytes) reserved for one group stream while encoding.  Proof that it
  * cannot overflow is in DESIGN.md ("stream bound"): every occurring symbol has
- * freq >= count*65504/T, so a lane emits <= T*log2(31)+48 bits < 8*(T+8). */
+ * freq >= count*65504/T (CDF16; counts model: exactly count/256), so a lane emits
+ * <= T*log2(31)+48 bits < 8*(T+8). */
 static inline uint32_t lmc_group_cap_bytes(uint32_t T) {
   return lmc_r16(LMC_LANES * (T + 8u));
 }

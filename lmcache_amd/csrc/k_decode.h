@@ -81,8 +81,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   const u32 T = hdw(4);
   const u32 src_dtype = hdw(2);
   const u32 cdf_rows = hdw(19);
+  const bool counts_model = hdw(22) == LMC_MODEL_COUNTS;  // wave-uniform: the coder ran on the symbol counts (T == 256)
   const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, cdf_rows);
   if (hdw(0) != LMC_BLOB_MAGIC || (hdw(1) & 0xffffu) != LMC_BLOB_VERSION || hdw(7) != (u32)a.C ||
+      hdw(22) != (T == LMC_COUNTS_T ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16) ||
       hdw(8) != (u32)a.P || hdw(15) != bo.streams || cdf_rows > 31u * (u32)a.P || hdw(20) != dev_count_bytes(T) ||
       // every section offset is a function of the fields checked above; the blob must also fit its slot
       (!SYMOUT && (T > (u32)a.chunk_tokens || (unsigned long long)hdw(17) > (unsigned long long)a.blob_stride))) {
@@ -136,15 +138,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       for (int i = 0; i < 16; i++) sum += (hreg[i] & 0xffffu) + (hreg[i] >> 16);
       const u32 deficit = T - sum;  // 0 or 1 in a well-formed blob
       if (__ballot(deficit != 0u)) {
+        if (counts_model) {
+          // the counts model codes such a channel with 255 and a count of 1 on symbol 0 -- on symbol 1 if the 255 is
+          // symbol 0's (lmc_counts_model): the missing unit goes there
+          const bool first = (hreg[0] & 0xffffu) == 255u;
+          hreg[0] += first ? (deficit & 0xffffu) << 16 : (deficit & 0xffffu);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          if ((hreg[i] & 0xffffu) == 255u) hreg[i] += deficit & 0xffffu;
-          else if ((hreg[i] >> 16) == 255u) hreg[i] += (deficit & 0xffffu) << 16;
+          for (int i = 0; i < 16; i++) {
+            if ((hreg[i] & 0xffffu) == 255u) hreg[i] += deficit & 0xffffu;
+            else if ((hreg[i] >> 16) == 255u) hreg[i] += (deficit & 0xffffu) << 16;
+          }
         }
       }
     }
     wave_lds_fence();  // the staging is dead (every lane holds its counts): the table takes its place
-    if (nsym <= 16u) {
+    if (counts_model) {
+      // LMC_MODEL_COUNTS: freq = 2 * count, start = 2 * (symbols below), total 2^9.
+      if (nsym <= 16u) {
+        // quarters of packed entries start << 23 | freq (start is even, so an entry's low 24 bits are its freq);
+        // symbols behind the last one that occurs would start at 2^9: all ones, above every search key
+        u32* tab32 = reinterpret_cast<u32*>(cdfT);
+        u32 acc = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const u32 ci = (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+          u32 ent = acc >= 256u ? 0xffffffffu : ((acc << 24) | (ci << 1));
+          if (!active) ent = ((u32)i << 24) | 2u;  // idle lanes: any strictly increasing column keeps the search in range
+          tab32[(i >> 2) * 256 + lane * 4 + (i & 3)] = ent;
+          acc += ci;
+        }
+      } else {
+        // u16 column of starts [entry][lane], entry 32 = 2^9 (a CDF out of 512: the narrow search runs on it unchanged)
+        u32 acc = 0;
+#pragma unroll
+        for (int i = 0; i <= 32; i++) {
+          cdfT[i * 64 + lane] = active ? (u16)min(2u * acc, 512u) : (u16)i;
+          if (i < 32) acc += (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+        }
+      }
+    } else if (nsym <= 16u) {
       // planes with at most 16 symbols (16 / 17 bins: most of them): 16 entries of 32 bits in four quarters,
       // tab32[quarter][lane][4], entry i = cdf[i] << 16 | (cdf[i + 1] - cdf[i]): one ds_read_b128 brings a quarter
       cdf_column_to_lds_wide(hreg, T, nsym, reinterpret_cast<u32*>(cdfT), lane);
@@ -235,13 +268,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   const u32 pC = wide ? *(lds_u32p)(size_t)(col_addr + 3072u) : (u32)*(lds_u16p)(size_t)(col_addr + 3072u);
   const u32 lut_addr = (u32)(size_t)(lds_f32p)lut;
   const u32 lut_qbias = col_addr - (lut_addr << 6);  // wide: (q - lut_qbias) >> 6 = &lut[4 * quarter]
-  u32 c_ffff = 0xffffu;
+  // low bits of a wide search key: all ones below the slot (counts model: one short of it, so that the all-ones
+  // entries of symbols behind the last occurring one stay above every key)
+  u32 c_ffff = counts_model ? 0x7ffffeu : 0xffffu;
   asm volatile("" : "+v"(c_ffff));
   // narrow: lut[s] with s = (qa - col) >> 7 is at ((qa - col) >> 5) + &lut = (qa - lut_bias) >> 5
   const u32 lut_bias = col_addr - (lut_addr << 5);
   const u64 full_exec = __builtin_amdgcn_read_exec();  // the search narrows exec and restores it from here
   const u32 ring_addr = (u32)(size_t)(lds_u16p)ring;
-  const u32 Lv = active ? LMC_RANS_L : 0u;  // idle lanes never renormalise: x < 0 is never true
+  const u32 rans_l = counts_model ? LMC_COUNTS_L : LMC_RANS_L;
+  const u32 Lv = active ? rans_l : 0u;  // idle lanes never renormalise: x < 0 is never true
 
   // destination: uniform base (SGPRs) + per-lane 32-bit byte offset
   u32 lane_off = 0;
@@ -299,9 +335,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
 #define LMC_SEARCH_STEP(q, piv, slot, STEP_BYTES)                                                   \
   asm("v_cmpx_le_u32_e32 vcc, %1, %2\n\tv_add_u32_e32 %0, %3, %0\n\ts_mov_b64 exec, %4"            \
       : "+v"(q) : "v"(piv), "v"(slot), "i"(STEP_BYTES), "s"(full_exec) : "vcc")
-  auto decode_token = [&](auto top_tag, float& lv) -> u32 {
+  auto decode_token = [&](auto top_tag, auto model_tag, float& lv) -> u32 {
     constexpr int TOP = decltype(top_tag)::value;
     constexpr bool WIDE = TOP == 4;
+    constexpr bool COUNTS = decltype(model_tag)::value;  // LMC_MODEL_COUNTS: 9-bit slots, start << 23 | freq entries
+    constexpr int KSH = COUNTS ? 23 : 16;
     if constexpr (WIDE) {
       // Planes with at most 16 symbols.  Entry i = cdf[i] << 16 | freq[i], so "cdf[i] <= slot" is one unsigned
       // compare of the whole entry with slot << 16 | 0xffff.  Levels 1-2 on the register pivots pick a quarter,
@@ -311,7 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       u64 mask;
       // levels 1-2 as one block, both exec-predicated (no back-to-back v_cndmask on one vcc, which the issue probe
       // tools/probes/valu_rates.py shows at a quarter of the normal rate; in this kernel the two forms time the same)
-      asm("v_lshl_or_b32 %[sl], %[x], 16, %[ffff]\n\t"
+      asm("v_lshl_or_b32 %[sl], %[x], %[ksh], %[ffff]\n\t"
           "v_mov_b32_e32 %[q], %[colA]\n\t"
           "v_mov_b32_e32 %[pm], %[pA]\n\t"
           "v_cmpx_le_u32_e32 vcc, %[pB], %[sl]\n\t"
@@ -323,33 +361,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
           "s_mov_b64 exec, %[full]"
           : [sl] "=&v"(sl), [q] "=&v"(q), [pm] "=&v"(pm)
           : [x] "v"(x), [ffff] "v"(c_ffff), [pA] "v"(pA), [pB] "v"(pB), [pC] "v"(pC), [colA] "v"(col_addr),
-            [colB] "v"(colB_addr), [full] "s"(full_exec)
+            [colB] "v"(colB_addr), [full] "s"(full_exec), [ksh] "n"(KSH)
           : "vcc");
       const u32x4_t e4 = *(const __attribute__((address_space(3))) u32x4_t*)(size_t)q;
       r = (q - lut_qbias) >> 6;  // LUT entry of the quarter's first symbol: quarter * 1024 -> quarter * 16 bytes
       u32 e0 = e4.x, e1 = e4.y, d;
       // levels 3-4 among the quarter's entries, then x = freq * (x >> 16) + (slot - start) (start is the entry's
       // upper half, freq its lower half) and the renormalisation test, as one block: no hazard padding in between
-      asm("v_cmpx_le_u32_e32 vcc, %[e2], %[sl]\n\t"
-          "v_mov_b32_e32 %[e0], %[e2]\n\t"
-          "v_mov_b32_e32 %[e1], %[e3]\n\t"
-          "v_add_u32_e32 %[r], 8, %[r]\n\t"
-          "s_mov_b64 exec, %[full]\n\t"
-          "v_cmpx_le_u32_e32 vcc, %[e1], %[sl]\n\t"
-          "v_mov_b32_e32 %[e0], %[e1]\n\t"
-          "v_add_u32_e32 %[r], 4, %[r]\n\t"
-          "s_mov_b64 exec, %[full]\n\t"
-          "v_sub_u32_sdwa %[d], %[x], %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
-          "v_mad_u32_u16 %[x], %[x], %[e0], %[d] op_sel:[1,0,0,0]\n\t"
-          "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
-          : [e0] "+v"(e0), [e1] "+v"(e1), [r] "+v"(r), [x] "+v"(x), [d] "=&v"(d), [m] "=&s"(mask)
-          : [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [full] "s"(full_exec), [lv] "v"(Lv)
-          : "vcc");
+      if constexpr (!COUNTS) {
+        asm("v_cmpx_le_u32_e32 vcc, %[e2], %[sl]\n\t"
+            "v_mov_b32_e32 %[e0], %[e2]\n\t"
+            "v_mov_b32_e32 %[e1], %[e3]\n\t"
+            "v_add_u32_e32 %[r], 8, %[r]\n\t"
+            "s_mov_b64 exec, %[full]\n\t"
+            "v_cmpx_le_u32_e32 vcc, %[e1], %[sl]\n\t"
+            "v_mov_b32_e32 %[e0], %[e1]\n\t"
+            "v_add_u32_e32 %[r], 4, %[r]\n\t"
+            "s_mov_b64 exec, %[full]\n\t"
+            "v_sub_u32_sdwa %[d], %[x], %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+            "v_mad_u32_u16 %[x], %[x], %[e0], %[d] op_sel:[1,0,0,0]\n\t"
+            "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
+            : [e0] "+v"(e0), [e1] "+v"(e1), [r] "+v"(r), [x] "+v"(x), [d] "=&v"(d), [m] "=&s"(mask)
+            : [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [full] "s"(full_exec), [lv] "v"(Lv)
+            : "vcc");
+      } else {
+        // the same selection; then d = slot - start = (key - entry) >> 23 (the key's low bits are >= any freq: no
+        // borrow), and x = freq * (x >> 9) + d with freq = the entry's low 24 bits (start is even)
+        asm("v_cmpx_le_u32_e32 vcc, %[e2], %[sl]\n\t"
+            "v_mov_b32_e32 %[e0], %[e2]\n\t"
+            "v_mov_b32_e32 %[e1], %[e3]\n\t"
+            "v_add_u32_e32 %[r], 8, %[r]\n\t"
+            "s_mov_b64 exec, %[full]\n\t"
+            "v_cmpx_le_u32_e32 vcc, %[e1], %[sl]\n\t"
+            "v_mov_b32_e32 %[e0], %[e1]\n\t"
+            "v_add_u32_e32 %[r], 4, %[r]\n\t"
+            "s_mov_b64 exec, %[full]\n\t"
+            "v_sub_u32_e32 %[d], %[sl], %[e0]\n\t"
+            "v_lshrrev_b32_e32 %[x], 9, %[x]\n\t"
+            "v_lshrrev_b32_e32 %[d], 23, %[d]\n\t"
+            "v_mad_u32_u24 %[x], %[x], %[e0], %[d]\n\t"
+            "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
+            : [e0] "+v"(e0), [e1] "+v"(e1), [r] "+v"(r), [x] "+v"(x), [d] "=&v"(d), [m] "=&s"(mask)
+            : [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [full] "s"(full_exec), [lv] "v"(Lv)
+            : "vcc");
+      }
       if (!SYMOUT) lv = *(lds_f32p)(size_t)r;  // issued here: back by the time the word pop below has its word
       return decode_pop(mask), r;
     } else {
       constexpr u32 ESTRIDE = 128u;  // bytes between entries of a lane's column
-      u32 slot = x & 0xffffu;
+      u32 slot = x & (COUNTS ? 0x1ffu : 0xffffu);
       asm volatile("" : "+v"(slot));  // keep `slot` a plain VGPR: SDWA compares would cost a wait state each
       // q walks the column: q = &cdf[s] for the largest probed s with cdf[s] <= slot.  Two levels on register pivots,
       u32 q, pm;
@@ -376,38 +436,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       const u32 e3 = *(lds_u16p)(size_t)(q + 3 * ESTRIDE), e4 = *(lds_u16p)(size_t)(q + 4 * ESTRIDE);
       u32 h, f, d;
       u64 mask;
-      asm("v_cmpx_le_u32_e32 vcc, %[e2], %[slot]\n\t"
-          "v_mov_b32_e32 %[e0], %[e2]\n\t"
-          "v_mov_b32_e32 %[e1], %[e3]\n\t"
-          "v_mov_b32_e32 %[e2], %[e4]\n\t"
-          "v_add_u32_e32 %[q], 0x100, %[q]\n\t"
-          "s_mov_b64 exec, %[full]\n\t"
-          "v_mov_b32_e32 %[h], %[e1]\n\t"
-          "v_cmpx_le_u32_e32 vcc, %[e1], %[slot]\n\t"
-          "v_mov_b32_e32 %[e0], %[e1]\n\t"
-          "v_mov_b32_e32 %[h], %[e2]\n\t"
-          "v_add_u32_e32 %[q], 0x80, %[q]\n\t"
-          "s_mov_b64 exec, %[full]\n\t"
-          "v_sub_u16_e32 %[f], %[h], %[e0]\n\t"       // entry 32 is 65536 stored as 0: the 16-bit difference is right
-          "v_sub_u32_e32 %[d], %[slot], %[e0]\n\t"
-          "v_mad_u32_u16 %[x], %[x], %[f], %[d] op_sel:[1,0,0,0]\n\t"
-          "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
-          : [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [q] "+v"(q), [x] "+v"(x), [h] "=&v"(h), [f] "=&v"(f),
-            [d] "=&v"(d), [m] "=&s"(mask)
-          : [e3] "v"(e3), [e4] "v"(e4), [slot] "v"(slot), [full] "s"(full_exec), [lv] "v"(Lv)
-          : "vcc");
+      if constexpr (!COUNTS) {
+        asm("v_cmpx_le_u32_e32 vcc, %[e2], %[slot]\n\t"
+            "v_mov_b32_e32 %[e0], %[e2]\n\t"
+            "v_mov_b32_e32 %[e1], %[e3]\n\t"
+            "v_mov_b32_e32 %[e2], %[e4]\n\t"
+            "v_add_u32_e32 %[q], 0x100, %[q]\n\t"
+            "s_mov_b64 exec, %[full]\n\t"
+            "v_mov_b32_e32 %[h], %[e1]\n\t"
+            "v_cmpx_le_u32_e32 vcc, %[e1], %[slot]\n\t"
+            "v_mov_b32_e32 %[e0], %[e1]\n\t"
+            "v_mov_b32_e32 %[h], %[e2]\n\t"
+            "v_add_u32_e32 %[q], 0x80, %[q]\n\t"
+            "s_mov_b64 exec, %[full]\n\t"
+            "v_sub_u16_e32 %[f], %[h], %[e0]\n\t"       // entry 32 is 65536 stored as 0: the 16-bit difference is right
+            "v_sub_u32_e32 %[d], %[slot], %[e0]\n\t"
+            "v_mad_u32_u16 %[x], %[x], %[f], %[d] op_sel:[1,0,0,0]\n\t"
+            "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
+            : [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [q] "+v"(q), [x] "+v"(x), [h] "=&v"(h), [f] "=&v"(f),
+              [d] "=&v"(d), [m] "=&s"(mask)
+            : [e3] "v"(e3), [e4] "v"(e4), [slot] "v"(slot), [full] "s"(full_exec), [lv] "v"(Lv)
+            : "vcc");
+      } else {
+        asm("v_cmpx_le_u32_e32 vcc, %[e2], %[slot]\n\t"
+            "v_mov_b32_e32 %[e0], %[e2]\n\t"
+            "v_mov_b32_e32 %[e1], %[e3]\n\t"
+            "v_mov_b32_e32 %[e2], %[e4]\n\t"
+            "v_add_u32_e32 %[q], 0x100, %[q]\n\t"
+            "s_mov_b64 exec, %[full]\n\t"
+            "v_mov_b32_e32 %[h], %[e1]\n\t"
+            "v_cmpx_le_u32_e32 vcc, %[e1], %[slot]\n\t"
+            "v_mov_b32_e32 %[e0], %[e1]\n\t"
+            "v_mov_b32_e32 %[h], %[e2]\n\t"
+            "v_add_u32_e32 %[q], 0x80, %[q]\n\t"
+            "s_mov_b64 exec, %[full]\n\t"
+            "v_sub_u16_e32 %[f], %[h], %[e0]\n\t"
+            "v_sub_u32_e32 %[d], %[slot], %[e0]\n\t"
+            "v_lshrrev_b32_e32 %[x], 9, %[x]\n\t"
+            "v_mad_u32_u24 %[x], %[x], %[f], %[d]\n\t"
+            "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
+            : [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [q] "+v"(q), [x] "+v"(x), [h] "=&v"(h), [f] "=&v"(f),
+              [d] "=&v"(d), [m] "=&s"(mask)
+            : [e3] "v"(e3), [e4] "v"(e4), [slot] "v"(slot), [full] "s"(full_exec), [lv] "v"(Lv)
+            : "vcc");
+      }
       if (!SYMOUT) lv = *(lds_f32p)(size_t)((q - lut_bias) >> 5);
       return decode_pop(mask), q;
     }
   };
 
   const u32 nskip = SYMOUT ? 0u : (tdst0 < 0 ? min(T, (u32)(-tdst0)) : 0u);  // tokens that land below dst token 0
-  auto run = [&](auto src_tag, auto top_tag) {
+  auto run = [&](auto src_tag, auto top_tag, auto model_tag) {
     constexpr bool SRC_BF16 = decltype(src_tag)::value;
     constexpr bool WIDE = decltype(top_tag)::value == 4;
     for (u32 t = 0; t < nskip; t++) {  // retrieve()'s first-chunk trim: decode, do not store
       float lv_skip;
-      (void)decode_token(top_tag, lv_skip);
+      (void)decode_token(top_tag, model_tag, lv_skip);
     }
     // !PAGED: the rows of this stream through a raw buffer descriptor: base = row of the first stored token,
     // soffset (scalar) = one stride_token further each token, voffset = the lane's channel.  The descriptor's range
@@ -434,7 +518,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       if (PAGED && !SYMOUT) tok_off2 = (t0 + (u32)lane < T) ? lmc_tok_off(a.dst, tdst0 + (int)(t0 + (u32)lane)) * 2 : 0ll;
       for (u32 i = 0; i < nt; i++) {
         float lv = 0.0f;
-        const u32 sa = decode_token(top_tag, lv);
+        const u32 sa = decode_token(top_tag, model_tag, lv);
         if (SYMOUT) {
           const u32 sym = WIDE ? (sa - lut_addr) >> 2 : (sa - col_addr) >> 7;
           if (active) *((LMC_GLOBAL int8_t*)(ubase + (u64)(t0 + i) * a.C) + lane_off) = (int8_t)sym;
@@ -458,15 +542,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       }
     }
   };
-  if (src_dtype == (u32)LMC_DTYPE_BF16) {
-    if (top == 4u) run(BoolTag<true>{}, IntTag<4>{});
-    else run(BoolTag<true>{}, IntTag<8>{});
-  } else {
-    if (top == 4u) run(BoolTag<false>{}, IntTag<4>{});
-    else run(BoolTag<false>{}, IntTag<8>{});
-  }
+  auto run_src = [&](auto src_tag) {
+    if (counts_model) {
+      if (top == 4u) run(src_tag, IntTag<4>{}, BoolTag<true>{});
+      else run(src_tag, IntTag<8>{}, BoolTag<true>{});
+    } else {
+      if (top == 4u) run(src_tag, IntTag<4>{}, BoolTag<false>{});
+      else run(src_tag, IntTag<8>{}, BoolTag<false>{});
+    }
+  };
+  if (src_dtype == (u32)LMC_DTYPE_BF16) run_src(BoolTag<true>{});
+  else run_src(BoolTag<false>{});
 
-  const bool state_bad = active && x != LMC_RANS_L;
+  const bool state_bad = active && x != rans_l;
   if (e != 0 || __ballot(state_bad)) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_STREAM);
   }

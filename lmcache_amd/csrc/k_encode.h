@@ -94,6 +94,7 @@ __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, c
       case 19: v = cdf_rows; break;
       case 20: v = dev_count_bytes(T); break;
       case 21: v = bo.scsum; break;
+      case 22: v = T == LMC_COUNTS_T ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16; break;  // lmc_model_for
       default: v = 0;
     }
     reinterpret_cast<u32*>(blob)[lane] = v;
@@ -530,66 +531,3 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
   t.chunk = chunk; t.pg = p * a.G + g; t.exact = exact; t.T = T; t.out = out;
 }
 
-template <bool QUADSYM, bool ENCODE>
-__global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
-  __shared__ __attribute__((aligned(16))) u32 lds_all[ENC_WAVES * ENC_WAVE_DWORDS];  // the staging rings, then the tables
-  const int lane = threadIdx.x & 63;
-  // everything derived from the wave id is wave-uniform: keep it in SGPRs
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long ngroups_total = (long long)a.nchunks * a.P * a.G;
-  u32* hist = lds_all + ENC_WAVES * ENC_RING_DWORDS + wave * ENC_TAB_DWORDS;  // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
-
-  // Workgroup -> streams.  When the streams of a chunk fill whole workgroups, consecutive workgroups take the SAME
-  // position of consecutive CHUNKS (chunk = block % nchunks): the predecessors a workgroup's placement depends on
-  // (lower positions of its own chunk) were then dispatched at least nchunks workgroups earlier and have normally
-  // published their lengths by the time it looks back -- with chunk-major order they finish at the same moment
-  // and every look-back waits for the slowest of them.
-  long long gid = (long long)blockIdx.x * ENC_WAVES + wave;
-  if (ENCODE && (a.P * a.G) % ENC_WAVES == 0) {
-    const int wpc = a.P * a.G / ENC_WAVES;  // workgroups per chunk
-    const int ch = (int)(blockIdx.x % (unsigned)a.nchunks), pos = (int)(blockIdx.x / (unsigned)a.nchunks);
-    gid = ((long long)ch * wpc + pos) * ENC_WAVES + wave;
-  }
-  if (gid >= ngroups_total) return;
-  PendingTile t;
-  encode_group_stream<QUADSYM, ENCODE>(a, gid, hist, reinterpret_cast<u16*>(lds_all + wave * (ENC_RING_DWORDS)), lane, t);
-  if (!ENCODE) return;
-  // ---- compaction: where does this stream go? ------------------------------------------------------------
-  const int n = a.P * a.G;
-  const int chunk = t.chunk;
-  const u32 padded = (t.exact + 15u) & ~15u;
-  unsigned long long* agg = a.agg + (long long)chunk * n;
-  if (n % ENC_WAVES == 0) {
-    // The waves of a workgroup hold consecutive streams of one chunk: they add their lengths up in LDS and
-    // ONE wave runs the look-back over workgroup-level granules -- 1/ENC_WAVES of the granules, and of the
-    // walk when a whole chunk finishes at once and nobody has an inclusive prefix yet.
-    __shared__ u32 wg_len[ENC_WAVES];
-    __shared__ u32 wg_excl;
-    if (lane == 0) wg_len[wave] = padded;
-    __syncthreads();
-    u32 intra = 0, wg_total = 0;
-#pragma unroll
-    for (int w = 0; w < ENC_WAVES; w++) {
-      const u32 l = wg_len[w];
-      intra += w < wave ? l : 0u;
-      wg_total += l;
-    }
-    if (wave == 0) {
-      const int wgi = t.pg / ENC_WAVES;
-      if (lane == 0 && wgi > 0) agg_store(agg + wgi, AGG_A, wg_total);
-      const u32 e = lookback_exclusive(agg, wgi, lane, a.status);
-      if (lane == 0) {
-        agg_store(agg + wgi, AGG_P, e + wg_total);
-        wg_excl = e;
-      }
-    }
-    __syncthreads();
-    place_stream(a, t, wg_excl + intra, lane);
-  } else {
-    // streams of a chunk do not fill whole workgroups: every wave publishes and looks back for itself
-    if (lane == 0 && t.pg > 0) agg_store(agg + t.pg, AGG_A, padded);
-    const u32 excl = lookback_exclusive(agg, t.pg, lane, a.status);
-    if (lane == 0) agg_store(agg + t.pg, AGG_P, excl + padded);
-    place_stream(a, t, excl, lane);
-  }
-}

@@ -7,9 +7,11 @@
 //            to the blob;
 //   barrier  (workgroup scope is enough: the region is written and read by waves of one CU)
 //   phase B  wave w codes the group streams w, w + FUSED_WAVES, ... exactly as k_cdf_encode does
-//            (encode_group_stream: histogram, counts, CDF, interleaved rANS) -- the symbols come back from L2;
+//            (encode_group_stream_counts: histogram, counts, table, interleaved rANS on the counts model -- this
+//            kernel takes 256-token chunks only, lmc_api.hip hands a ragged last chunk to the two-kernel path) --
+//            the symbols come back from L2;
 //   placement: ONE look-back per plane-chunk over P granules per chunk, then every wave moves its own streams.
-// Several workgroups share a CU (4.75 KiB of LDS per wave, <= 64 VGPRs: 8 waves per SIMD) and are in different
+// Several workgroups share a CU (4.6 KiB of LDS per wave + 2 KiB of reciprocals, <= 64 VGPRs: 8 waves per SIMD) and are in different
 // phases at any time, so the loads of one hide under the coding of the others.  Blobs are byte-identical to the
 // two-kernel path (same device functions; tests/test_gpu_parity.py runs both).
 //
@@ -19,7 +21,7 @@
 // Geometry: 256 < C <= 1024 channels per plane (G = 5..16 group streams, the 64-lane quantise tasks); other
 // shapes take the two-kernel path (lmc_api.hip).
 #pragma once
-#include "k_encode.h"
+#include "k_encode_counts.h"
 #include "k_quantize.h"
 
 #define FUSED_MAX_G 16
@@ -31,6 +33,14 @@ struct FusedArgs {
   u8* scale_base;
   long long scale_stride;
   u32 epoch;  // 1 .. 2^30 - 1
+  // Head start (an experiment that did NOT pay; off by default, LMC_FUSED_PRE_STEP=n switches it on).  Doubling phase A
+  // costs a whole k_quantize (+0.44 ms), as if the phases of different workgroups never overlapped; the hypothesis
+  // was lock-step generations (every CU fetches, then every CU codes).  Here the plane-chunks of every `pre_step`-th
+  // workgroup below `pre_limit` (the first generation) are quantised by a k_quantize launch in front of this kernel,
+  // so that those workgroups start coding at once and the generations run out of phase.  Measured: 1.056 ms
+  // without, 1.064-1.09 ms with pre_step 4 / 2 / 3 / 1 -- the phases were not in lock-step; what the fetch phase
+  // costs is the wave slots its waves hold while they wait.
+  u32 pre_limit, pre_step;
 };
 
 __device__ __forceinline__ void aggE_store(unsigned long long* p, unsigned long long flag, u32 epoch, u32 v) {
@@ -103,7 +113,11 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
       for (int r = 0; r < 2; r++) {
         const int t = t_first + 4 * hq + r0 + r;
         tv[r] = t < Tc;
+#if LMC_EXP_TWICE & 16  // timing experiment: every row is the chunk's first row (L2 hits instead of HBM reads)
+        const u16* rowp = pbase + (tv[r] ? lmc_tok_off(src, tok0 + (t & 7)) : 0);
+#else
         const u16* rowp = pbase + (tv[r] ? lmc_tok_off(src, tok0 + t) : 0);
+#endif
 #pragma unroll
         for (int it = 0; it < NITER; it++) {
           if (tv[r] && cval[it]) v[r][it] = ld_global_u4(rowp + coff[it]);
@@ -138,10 +152,13 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
       float factor[2];
       bool special[2];
       bool any_special = false;
+      // both row maxes are wave-uniform: one scalar branch picks the short division for the pair
+      const bool short_div = LMC_SHORT_ROW_DIV && row_div_in_range((u32)__builtin_amdgcn_readfirstlane((int)mrow[0]), DT) &&
+                             row_div_in_range((u32)__builtin_amdgcn_readfirstlane((int)mrow[1]), DT);
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         const float sf = h2f_rt(mrow[r], DT);
-        factor[r] = maxf / sf;  // IEEE fp32 division
+        factor[r] = short_div ? row_div_short(maxf, sf) : maxf / sf;  // IEEE fp32 division (lmc_device.h)
         special[r] = !(__builtin_fabsf(factor[r]) < __builtin_inff()) || !(sf < __builtin_inff());
         any_special |= special[r];
       }
@@ -200,7 +217,8 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
 template <int NITER, int DT, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_fused(FusedArgs fa) {
   const EncodeArgs& a = fa.e;
-  __shared__ __attribute__((aligned(16))) u32 lds_all[NW * ENC_WAVE_DWORDS];  // the staging rings, then the tables
+  __shared__ __attribute__((aligned(16))) u32 lds_all[NW * (ENC_RING_DWORDS + CNT_TAB_DWORDS)];  // the staging rings, then the tables
+  __shared__ __attribute__((aligned(16))) u32 rtab_lds[RTAB_DWORDS];  // reciprocals of the counts model's frequencies
   __shared__ u32 st_len[FUSED_MAX_G];  // exact byte length of the plane-chunk's group streams
   __shared__ u32 wg_excl;
   const int lane = threadIdx.x & 63;
@@ -210,15 +228,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   const int chunk = (int)(blockIdx.x % (unsigned)a.nchunks), p = (int)(blockIdx.x / (unsigned)a.nchunks);
   const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
   const int Tc = min(a.chunk_tokens, a.tok_end - tok0);
-  u32* const hist = lds_all + NW * ENC_RING_DWORDS + wave * ENC_TAB_DWORDS;  // this wave's table slice ...
+  u32* const hist = lds_all + NW * ENC_RING_DWORDS + wave * CNT_TAB_DWORDS;  // this wave's table slice ...
   u16* const ring = reinterpret_cast<u16*>(lds_all + wave * ENC_RING_DWORDS);  // ... and staging ring
 
+  rtab_to_lds(rtab_lds);  // visible to the coder waves behind the barrier that ends phase A
   // ---- phase A: quantise the plane-chunk ----------------------------------------------------------------
-  {
+  const bool head_start = blockIdx.x < fa.pre_limit && blockIdx.x % fa.pre_step == 0u;  // quantised by k_quantize already
+  if (!head_start) {
     const int bins = (int)a.bins.b[p];
     const float maxf = (float)(bins / 2 - 1);
     const bool nib = lmc_sym_nibbles(bins);
+#if LMC_EXP_TWICE & 32  // timing experiment: every workgroup of an XCD shares 4 symbol regions (stays in L2)
+    u32* const sym_pc = const_cast<u32*>(a.sym4) + (long long)(blockIdx.x % 32u) * a.TQ * a.C;
+#else
     u32* const sym_pc = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.TQ * a.C;
+#endif
     u16* const scl = reinterpret_cast<u16*>(fa.scale_base + (long long)chunk * fa.scale_stride) + (long long)p * Tc;
     const int TO = (Tc + 7) >> 3;
     const u16* const pbase = lmc_plane_base(fa.src, p);
@@ -226,6 +250,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // Waves that fetch run at raised priority: their (few) instructions go first, so the loads are out early and
     // return under the other workgroups' coding.
     __builtin_amdgcn_s_setprio(3);
+#if LMC_EXP_TWICE & 1
+#pragma unroll 1
+    for (int rep = 0; rep < 2; rep++)
+#endif
 #pragma unroll 1
     for (int oct = wave; oct < TO; oct += NW) {
       const bool q1valid = 2 * oct + 1 < a.TQ;
@@ -241,11 +269,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   __syncthreads();  // symbols and scales of the plane-chunk are visible to the workgroup
 
   // ---- phase B: code this wave's group streams -----------------------------------------------------------
+#if LMC_EXP_TWICE & 32
+  EncodeArgs a2 = a;
+  a2.sym4 = a.sym4 + ((long long)(blockIdx.x % 32u) - ((long long)chunk * a.P + p)) * a.TQ * a.C;
+#define LMC_FUSED_ENC_ARGS a2
+#else
+#define LMC_FUSED_ENC_ARGS a
+#endif
   const long long gid0 = ((long long)chunk * a.P + p) * a.G;
 #pragma unroll 1
   for (int g = wave; g < a.G; g += NW) {
     PendingTile t;
-    encode_group_stream<true, true, true>(a, gid0 + g, hist, ring, lane, t);
+    encode_group_stream_counts<LMC_COUNTS_LDSASM != 0>(LMC_FUSED_ENC_ARGS, gid0 + g, hist, ring, rtab_lds, lane, t);
     if (lane == 0) st_len[g] = t.exact;
     wave_lds_fence();  // the next stream reuses this wave's LDS slices
   }
@@ -270,8 +305,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     for (int k = 0; k < g; k++) intra += (st_len[k] + 15u) & ~15u;
     PendingTile t;
     t.chunk = chunk; t.pg = p * a.G + g; t.exact = st_len[g]; t.T = (u32)Tc;
+#if LMC_EXP_TWICE & 64
+    t.out = reinterpret_cast<const u16*>(a.scratch + ((gid0 + g) % 256) * (long long)a.cap);
+#else
     t.out = reinterpret_cast<const u16*>(a.scratch + (gid0 + g) * (long long)a.cap);
+#endif
+#if !(LMC_EXP_TWICE & 8)
     place_stream<false>(a, t, wg_excl + intra, lane);
+#endif
   }
   // The chunk's last plane knows the chunk's size: header, static sections, size word (kept out of the stream loop:
   // inlined there, its loop invariants were hoisted over the loop and spilled by every wave).

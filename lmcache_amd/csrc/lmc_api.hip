@@ -8,12 +8,13 @@
 
 #include <mutex>
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/lmc_hip.h"
 #include "k_copy.h"
 #include "k_decode.h"
-#include "k_encode.h"
+#include "k_encode_counts.h"
 #include "k_fused.h"
 #include "k_quantize.h"
 
@@ -39,6 +40,8 @@ struct lmc_ctx {
   bool ws_used = false;
   int num_cus = 256;
   int enc_path = LMC_ENCODE_PATH_AUTO;  // lmc_ctx_set_encode_path
+  int pre_step = 0;                     // fused encode: every pre_step-th workgroup of the first generation gets a head start
+                                        // (0: none -- measured 1.06 ms without, 1.07-1.09 with 2 / 3 / 4: k_fused.h)
   u32 epoch = 0;                        // of the last fused launch (tags its look-back granules)
   u32* status_h = nullptr;  // pinned, device-accessible
   // optional per-kernel timing (lmc_ctx_profile)
@@ -87,6 +90,7 @@ int lmc_ctx_create(int device, lmc_ctx** out) {
   memset(c->status_h, 0, 64);
   e = hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming);
   if (e != hipSuccess) { g_last_hip = (int)e; (void)hipHostFree(c->status_h); delete c; return LMC_ERR_HIP; }
+  if (const char* e = getenv("LMC_FUSED_PRE_STEP")) c->pre_step = atoi(e);  // A/B switch of the head start (tools/probes)
   *out = c;
   return LMC_OK;
 }
@@ -324,23 +328,81 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   u8* const scale_base = (u8*)blobs + hl.off_scales;  // off_scales does not depend on T
 
   c->pn = 0;
-  const bool fused_fits = C > 256 && C <= 1024;  // k_fused.h: the 64-lane quantise tasks, G <= FUSED_MAX_G
+  // k_fused.h codes 256-token chunks (the counts model) of 256 < C <= 1024 channels (64-lane quantise tasks, G <= 16)
+  const int nfull = (tok_end - tok_begin) / chunk_tokens;  // chunks of exactly chunk_tokens tokens; a ragged one may follow
+  const bool fused_fits = C > 256 && C <= 1024 && chunk_tokens == (int)LMC_COUNTS_T && nfull > 0;
   // AUTO: the fused kernel pays once its (chunk, plane) workgroups outnumber the slots of the chip (4 per CU):
   // measured on MI355X with 64 planes, 4 / 8 / 12 / 16 / 32 / 64 chunks: fused / two-kernel time = 1.27 / 1.16 /
   // 1.05 / 1.00 / 0.91 / 0.90 (tools/probes/encode_ab.hip)
   const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
-                                    (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nchunks * P > 4ll * c->num_cus));
+                                    (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * P > 4ll * c->num_cus));
+  // the chunks [c0, c0 + n) of the job with the two kernels: k_quantize, then k_cdf_encode (CDF or counts table +
+  // coder + in-kernel compaction of the streams into the blobs).  Measured alternatives that lost: DESIGN.md section 6.
+  auto two_kernels = [&](int c0, int n) -> int {
+    EncodeArgs e2 = ea;
+    e2.tok_begin = tok_begin + c0 * chunk_tokens; e2.nchunks = n;
+    e2.sym4 = c->sym4 + (size_t)c0 * P * TQ * C;
+    e2.blobs = (u8*)blobs + (size_t)c0 * blob_stride;
+    e2.scratch = c->scratch + (size_t)c0 * PG * cap;
+    e2.agg = c->agg + (size_t)c0 * PG;
+    e2.sizes = sizes + c0;
+    QuantArgs qa;
+    memset(&qa, 0, sizeof qa);
+    qa.src = to_addr(src); qa.bins = bins;
+    qa.tok_begin = e2.tok_begin; qa.tok_end = tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = n;
+    qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = n * P;
+    qa.sym4 = const_cast<u32*>(e2.sym4);
+    qa.scale_base = scale_base + (size_t)c0 * blob_stride;
+    qa.scale_stride = (long long)blob_stride;
+    qa.agg = e2.agg; qa.agg_n = (long long)n * PG;  // zeroed by the quantiser: one dispatch less per job
+    int r;
+    if ((r = prof_mark(c, s))) return r;
+    if ((r = launch_quant<true>(qa, s))) return r;
+    if ((r = prof_mark(c, s))) return r;
+    const long long ngroups = (long long)n * PG;
+    hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + ENC_WAVES - 1) / ENC_WAVES)), dim3(64 * ENC_WAVES), 0, s, e2);
+    HIP_TRY(hipGetLastError());
+    return prof_mark(c, s);
+  };
   if (fused) {
-    // One launch: a workgroup per (chunk, plane) quantises, then codes and places its streams (k_fused.h).
+    // One launch for the full chunks: a workgroup per (chunk, plane) quantises, then codes and places its streams.
     FusedArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.src = to_addr(src); fa.e = ea;
+    fa.e.nchunks = nfull;
+    fa.e.tok_end = tok_begin + nfull * chunk_tokens;
     fa.scale_base = scale_base; fa.scale_stride = (long long)blob_stride;
     c->epoch = (c->epoch + 1u) & 0x3fffffffu;
     if (!c->epoch) c->epoch = 1u;
     fa.epoch = c->epoch;
-    const dim3 grid((unsigned)((long long)nchunks * P)), block(64 * FUSED_WAVES);
+    const dim3 grid((unsigned)((long long)nfull * P)), block(64 * FUSED_WAVES);
     if ((rc = prof_mark(c, s))) return rc;
+    // head start (k_fused.h): with at least three generations of workgroups, every pre_step-th plane-chunk of the
+    // first generation (4 workgroups per CU) is quantised by k_quantize in front of the fused launch
+    const long long gen1 = 4ll * c->num_cus;
+    if (c->pre_step > 0 && (long long)nfull * P >= 3 * gen1) {
+      fa.pre_limit = (u32)gen1; fa.pre_step = (u32)c->pre_step;
+      QuantArgs qa;
+      memset(&qa, 0, sizeof qa);
+      qa.src = to_addr(src); qa.bins = bins;
+      qa.tok_begin = tok_begin; qa.tok_end = fa.e.tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = nfull;
+      qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = nfull * P;
+      qa.sym4 = c->sym4;
+      qa.scale_base = scale_base; qa.scale_stride = (long long)blob_stride;
+      qa.lin_step = c->pre_step;
+      const int TO = (TQ + 1) / 2;
+      const dim3 qgrid((unsigned)((TO + 3) / 4), 1u, (unsigned)((gen1 + c->pre_step - 1) / c->pre_step));
+      if (src->dtype == LMC_DTYPE_BF16) {
+        if (C <= 512) hipLaunchKernelGGL((k_quantize<64, 1, LMC_DTYPE_BF16, true>), qgrid, dim3(256), 0, s, qa);
+        else hipLaunchKernelGGL((k_quantize<64, 2, LMC_DTYPE_BF16, true>), qgrid, dim3(256), 0, s, qa);
+      } else {
+        if (C <= 512) hipLaunchKernelGGL((k_quantize<64, 1, LMC_DTYPE_FP16, true>), qgrid, dim3(256), 0, s, qa);
+        else hipLaunchKernelGGL((k_quantize<64, 2, LMC_DTYPE_FP16, true>), qgrid, dim3(256), 0, s, qa);
+      }
+      HIP_TRY(hipGetLastError());
+    } else {
+      fa.pre_limit = 0; fa.pre_step = 1;
+    }
     if (src->dtype == LMC_DTYPE_BF16) {
       if (C <= 512) hipLaunchKernelGGL((k_encode_fused<1, LMC_DTYPE_BF16, FUSED_WAVES>), grid, block, 0, s, fa);
       else hipLaunchKernelGGL((k_encode_fused<2, LMC_DTYPE_BF16, FUSED_WAVES>), grid, block, 0, s, fa);
@@ -350,25 +412,9 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     }
     HIP_TRY(hipGetLastError());
     if ((rc = prof_mark(c, s))) return rc;
+    if (nfull < nchunks && (rc = two_kernels(nfull, nchunks - nfull))) return rc;  // the ragged last chunk
   } else {
-    // Two launches for the whole job: k_quantize, then k_cdf_encode (CDF + coder + in-kernel compaction of the
-    // streams into the blobs).  Measured alternatives that lost are listed in DESIGN.md section 6.
-    QuantArgs qa;
-    memset(&qa, 0, sizeof qa);
-    qa.src = to_addr(src); qa.bins = bins;
-    qa.tok_begin = tok_begin; qa.tok_end = tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = nchunks;
-    qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = nchunks * P;
-    qa.sym4 = c->sym4;
-    qa.scale_base = scale_base;
-    qa.scale_stride = (long long)blob_stride;
-    qa.agg = c->agg; qa.agg_n = (long long)nchunks * PG;  // zeroed by the quantiser: one dispatch less per job
-    if ((rc = prof_mark(c, s))) return rc;
-    if ((rc = launch_quant<true>(qa, s))) return rc;
-    if ((rc = prof_mark(c, s))) return rc;
-    const long long ngroups = (long long)nchunks * PG;
-    hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + ENC_WAVES - 1) / ENC_WAVES)), dim3(64 * ENC_WAVES), 0, s, ea);
-    HIP_TRY(hipGetLastError());
-    if ((rc = prof_mark(c, s))) return rc;
+    if ((rc = two_kernels(0, nchunks))) return rc;
   }
 
   HIP_TRY(hipEventRecord(c->ws_free, s));
@@ -529,7 +575,9 @@ int lmc_blob_info(const void* blob_h, size_t nbytes, lmc_blob_header* out) {
   memcpy(&h, blob_h, sizeof h);
   if (h.magic != LMC_BLOB_MAGIC || h.version != LMC_BLOB_VERSION || h.header_bytes != LMC_HEADER_BYTES) return LMC_ERR_INVALID;
   if (h.num_layers == 0 || h.ntokens == 0 || h.num_heads == 0 || h.head_size == 0) return LMC_ERR_INVALID;
-  if (h.num_layers > LMC_MAX_PLANES / 2 || h.cdf_rows > 31u * 2u * h.num_layers || h.count_bytes != lmc_count_bytes(h.ntokens)) return LMC_ERR_INVALID;
+  if (h.num_layers > LMC_MAX_PLANES / 2 || h.cdf_rows > 31u * 2u * h.num_layers || h.count_bytes != lmc_count_bytes(h.ntokens) ||
+      h.model != lmc_model_for(h.ntokens))
+    return LMC_ERR_INVALID;
   lmc_blob_header ref;
   memset(&ref, 0, sizeof ref);
   lmc_blob_layout(h.num_layers, h.ntokens, h.num_heads, h.head_size, h.cdf_rows, &ref);

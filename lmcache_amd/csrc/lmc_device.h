@@ -134,6 +134,32 @@ __device__ __forceinline__ u32 f2fp16(float f) {  // v_cvt_f16_f32, RNE
   return (u32)__builtin_bit_cast(unsigned short, (_Float16)f);
 }
 
+// factor = MAX / max of a quantiser row, IEEE fp32 (the reference divides: cachegen_encoder.py:40-61).  The
+// compiler's division is 14 instructions (v_div_scale x 2, v_rcp, five fma / mul, v_div_fmas, v_div_fixup),
+// executed by every lane for a wave-uniform value.  Rows whose max lies well inside the fp32 normal range take
+//   y = rcp(max); q0 = MAX * y; r = fma(-max, q0, MAX); q = fma(r, y, q0)                      (4 instructions)
+// which tools/probes/row_div.hip checks exhaustively ON THE GPU (v_rcp_f32 is a hardware approximation) against
+// the division over every 16-bit max x MAX 1 .. 15: 0 mismatches inside row_div_in_range for bf16 and fp16
+// (profiles/r03_row_div.log; outside it -- bf16 maxes that are fp32 denormals or whose reciprocal is -- 4014 of
+// 491 520 differ, which is why the range test exists).  The test is on the row max, wave-uniform: a scalar branch;
+// zero / inf / NaN maxes fail it and keep the division.
+#ifndef LMC_SHORT_ROW_DIV
+#define LMC_SHORT_ROW_DIV 1
+#endif
+__device__ __forceinline__ bool row_div_in_range(u32 max_bits, int dtype) {
+  if (dtype == LMC_DTYPE_BF16) {
+    const u32 e = (max_bits >> 7) & 0xffu;  // bf16 carries fp32's exponent field
+    return e >= 27u && e <= 227u;           // 2^-100 .. 2^100
+  }
+  return max_bits != 0u && max_bits < 0x7c00u;  // fp16: any finite non-zero max (1 / max is a normal fp32)
+}
+__device__ __forceinline__ float row_div_short(float maxf, float sf) {
+  const float y = __builtin_amdgcn_rcpf(sf);
+  const float q0 = maxf * y;
+  const float r = __builtin_fmaf(-sf, q0, maxf);
+  return __builtin_fmaf(r, y, q0);
+}
+
 // Order this wave's LDS traffic (cross-lane hand-off inside one wave): a
 // compiler + hardware fence at wavefront scope; no workgroup barrier needed.
 __device__ __forceinline__ void wave_lds_fence() {

@@ -58,7 +58,8 @@ class BlobHeader(ctypes.Structure):
                 ("off_bins", ctypes.c_uint32), ("off_scales", ctypes.c_uint32), ("off_cdf", ctypes.c_uint32),
                 ("off_gend", ctypes.c_uint32), ("off_streams", ctypes.c_uint32), ("stream_bytes", ctypes.c_uint32),
                 ("total_bytes", ctypes.c_uint32), ("off_rowpre", ctypes.c_uint32), ("cdf_rows", ctypes.c_uint32),
-                ("count_bytes", ctypes.c_uint32), ("off_scsum", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 10)]
+                ("count_bytes", ctypes.c_uint32), ("off_scsum", ctypes.c_uint32), ("model", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32 * 9)]
 
 
 # name -> (restype, argtypes); every symbol include/lmc_hip.h declares

@@ -169,7 +169,7 @@ def encode_blob(kv_bits: np.ndarray, dtype: int, H: int, D: int, bins: np.ndarra
 def parse_header(blob: bytes) -> dict:
     names = ["dtype", "num_layers", "ntokens", "num_heads", "head_size", "nchannels", "nplanes", "ngroups",
              "lp", "off_bins", "off_scales", "off_cdf", "off_gend", "off_streams", "stream_bytes",
-             "total_bytes", "off_rowpre", "cdf_rows", "count_bytes", "off_scsum"]
+             "total_bytes", "off_rowpre", "cdf_rows", "count_bytes", "off_scsum", "model"]
     head = np.frombuffer(blob[:128], dtype=np.uint32)
     assert head[0] == 0x31434D4C, "bad magic"
     d = {n: int(v) for n, v in zip(names, head[2:2 + len(names)])}

@@ -617,15 +617,18 @@ def encode_with_path(nat, ctx, path, *args):
 
 
 FUSED_SHAPES = [
-    # L, T total, chunk, H, D, dtype, kind
-    (4, 64, 64, 8, 128, torch.bfloat16, "randn"),     # C = 1024, one chunk
-    (2, 600, 256, 8, 128, torch.bfloat16, "rand"),    # three chunks, ragged tail of 88 tokens
-    (2, 236, 236, 8, 128, torch.float16, "outlier"),  # tests/test_serde.py:87-107 chunk length, fp16
-    (1, 33, 33, 5, 128, torch.bfloat16, "outlier"),   # C = 640: partial last group, partial second channel run
-    (3, 130, 50, 4, 128, torch.float16, "randn"),     # C = 512: one channel run per lane
-    (2, 9, 4, 3, 128, torch.bfloat16, "randn"),       # C = 384, chunks shorter than a row oct
-    (1, 300, 300, 8, 128, torch.bfloat16, "randn"),   # T > 256 in one chunk (two-byte counts)
-    (1, 1, 1, 8, 128, torch.bfloat16, "randn"),       # a single token
+    # L, T total, chunk, H, D, dtype, kind.  The fused kernel takes the 256-token chunks of a job (the counts model);
+    # a ragged last chunk and every other chunk length go through k_quantize + k_cdf_encode whatever the setting.
+    (4, 256, 256, 8, 128, torch.bfloat16, "randn"),   # C = 1024, one chunk
+    (2, 600, 256, 8, 128, torch.bfloat16, "rand"),    # two fused chunks + a ragged tail of 88 tokens (two-kernel path)
+    (2, 512, 256, 8, 128, torch.float16, "outlier"),  # fp16
+    (1, 256, 256, 5, 128, torch.bfloat16, "outlier"), # C = 640: partial second channel run
+    (1, 256, 256, 5, 72, torch.bfloat16, "randn"),    # C = 360: partial last group (idle lanes in the coder)
+    (3, 768, 256, 4, 128, torch.float16, "randn"),    # C = 512: one channel run per lane
+    (2, 256, 256, 3, 128, torch.bfloat16, "randn"),   # C = 384
+    (2, 236, 236, 8, 128, torch.float16, "outlier"),  # tests/test_serde.py:87-107 chunk length: not a fused geometry
+    (1, 300, 300, 8, 128, torch.bfloat16, "randn"),   # T > 256 in one chunk (two-byte counts): not a fused geometry
+    (2, 9, 4, 3, 128, torch.bfloat16, "randn"),       # chunks shorter than a row oct: not a fused geometry
 ]
 
 
@@ -649,7 +652,7 @@ def test_fused_encode_equals_two_kernel_encode_and_oracle(nat, ctx, oracle, shap
 def test_fused_encode_special_rows_and_repeated_jobs(nat, ctx, oracle):
     """Zero / inf / NaN / denormal-scale rows through the fused kernel's own quantise stage, and back-to-back jobs
     into the same workspace: the look-back granules of job n must not be taken for job n + 1's (epoch tags)."""
-    L, T, H, D = 2, 96, 8, 128
+    L, T, H, D, cs = 2, 768, 8, 128, 256
     bins = default_bins(L)
     g = torch.Generator().manual_seed(77)
     for rep in range(3):
@@ -658,25 +661,60 @@ def test_fused_encode_special_rows_and_repeated_jobs(nat, ctx, oracle):
         kv[0, 0, 17, 3, 11] = float("inf")
         kv[1, 1, 40, 0, 0] = float("nan")
         kv[:, :, 60:64] *= 1e-30
+        kv[:, :, 300:310] = 0.0
+        kv[1, 0, 600, 2, 5] = float("-inf")
         kv = kv.to(torch.bfloat16)
         lay = nat.KVLayout.from_chunk(kv.to(DEV), "vllm")
-        fused, _, _ = encode_with_path(nat, ctx, "fused", lay, 0, T, 32, bins)
+        fused, _, _ = encode_with_path(nat, ctx, "fused", lay, 0, T, cs, bins)
         for i, blob in enumerate(fused):
-            b, code = oracle.torch_to_bits(kv[:, :, 32 * i:32 * (i + 1)].reshape(L, 2, 32, H * D))
+            b, code = oracle.torch_to_bits(kv[:, :, cs * i:cs * (i + 1)].reshape(L, 2, cs, H * D))
             assert blob == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)), f"job {rep}, chunk {i}"
+
+
+@pytest.mark.parametrize("path", ["fused", "two_kernels"])
+def test_counts_model_constant_and_sparse_channels(nat, ctx, oracle, path):
+    """LMC_MODEL_COUNTS (256-token chunks) on the channels that stress its table: channels whose 256 symbols are all
+    equal (count 256 -> 255 + 1 on a neighbour, lmc_counts_model: symbol 0 and another one), channels with a symbol
+    that occurs once (frequency 2, the smallest the reciprocal table serves), two-symbol channels; on 32-bin and
+    16-bin planes, both launch paths; blob and decode bit-exact against the oracle."""
+    L, T, H, D = 2, 512, 3, 128
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(L, 2, T, H, D, generator=g)
+    big = x.abs().amax(dim=(-1, -2), keepdim=True)
+    x[:, :, :, 0, 0:8] = 0.0                                  # the middle symbol, every token
+    x[:, :, :, 0, 8:16] = big[..., 0]                         # the top symbol, every token
+    x[:, :, :, 0, 16:24] = -big[..., 0]                       # symbol 0, every token
+    x[:, :, :, 1, 0:8] = 0.0
+    x[:, :, 100, 1, 0:8] = big[:, :, 100, 0]                  # one outlier token in a constant channel
+    x[:, :, ::2, 2, 5] = 0.0                                  # two-symbol-ish channel
+    kv = x.to(torch.bfloat16)
+    bins = [32, 16, 16, 32]
+    lay = nat.KVLayout.from_chunk(kv.to(DEV), "vllm")
+    blobs, blob_dev, stride = encode_with_path(nat, ctx, path, lay, 0, T, 256, bins)
+    out = torch.zeros(L, 2, T, H, D, dtype=torch.bfloat16, device=DEV)
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, 2, nat.KVLayout.from_chunk(out, "vllm"), 0, 256)
+    torch.cuda.synchronize()
+    ctx.raise_on_status("decode")
+    for i in range(2):
+        b, code = oracle.torch_to_bits(kv[:, :, 256 * i:256 * (i + 1)].reshape(L, 2, 256, H * D))
+        ref = oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+        assert nat.blob_info(ref).model == 1
+        assert blobs[i] == ref, f"{path}, chunk {i}"
+        assert np.array_equal(bits_np(out[:, :, 256 * i:256 * (i + 1)]).reshape(L, 2, 256, H * D),
+                              oracle.decode_blob(ref, oracle.BF16)), f"decode, chunk {i}"
 
 
 @pytest.mark.parametrize("layout", ["NBHD", "NHBD"])
 def test_fused_encode_gathers_paged_blocks(nat, ctx, oracle, layout):
     """slot_mapping gather inside the fused kernel (LLM_Engine.rst:91-122), kv-tuple plane pointers."""
-    L, T, H, D, bs, nb = 2, 80, 8, 128, 16, 11
+    L, T, H, D, bs, nb, cs = 2, 600, 8, 128, 16, 41, 256
     g = torch.Generator().manual_seed(31)
     shape = (2, nb, bs, H, D) if layout == "NBHD" else (2, nb, H, bs, D)
     caches = [torch.randn(shape, generator=g).to(torch.bfloat16).to(DEV) for _ in range(L)]
     slots = torch.randperm(nb * bs, generator=g)[:T]
     lay = nat.KVLayout.paged(caches, slots, bs, layout)
     bins = default_bins(L)
-    fused, _, _ = encode_with_path(nat, ctx, "fused", lay, 0, T, 48, bins)
+    fused, _, _ = encode_with_path(nat, ctx, "fused", lay, 0, T, cs, bins)
     dense = torch.zeros(L, 2, T, H, D, dtype=torch.bfloat16)
     for l in range(L):
         c = caches[l].cpu()
@@ -684,7 +722,7 @@ def test_fused_encode_gathers_paged_blocks(nat, ctx, oracle, layout):
             blk, w = divmod(s, bs)
             dense[l, :, t] = c[:, blk, w] if layout == "NBHD" else c[:, blk, :, w]
     for i, blob in enumerate(fused):
-        t0, t1 = 48 * i, min(T, 48 * (i + 1))
+        t0, t1 = cs * i, min(T, cs * (i + 1))
         b, code = oracle.torch_to_bits(dense[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
         assert blob == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)), f"chunk {i}"
 

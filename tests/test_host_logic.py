@@ -262,7 +262,7 @@ def test_blob_counts_section_rebuilds_the_reference_cdf(oracle, T):
     bins = np.array([32, 16, 32, 16], np.int32)
     blob = oracle.encode_blob(bits, code, H, D, bins)
     h = native.blob_info(blob)
-    assert h.version == 4 and h.count_bytes == (1 if T <= 256 else 2)
+    assert h.version == 5 and h.count_bytes == (1 if T <= 256 else 2) and h.model == (1 if T == 256 else 0)
     assert h.off_gend - h.off_cdf == native.r16(h.count_bytes * H * D * sum(int(b) - 1 for b in bins))
     assert native.blob_static_bytes(L, T, H, D, bins) == h.off_streams
     sym, _ = oracle.quantize(bits, code, bins)

@@ -146,7 +146,7 @@ def test_blob_roundtrip_random_geometries(oracle):
         assert len(blob) <= oracle.blob_bound(L, T, H, D)
         # the scales carry a per-plane checksum (format v4): a flipped scale bit, or a flipped checksum bit, fails
         h = oracle.parse_header(blob)
-        assert h["version"] == 4 and h["off_scsum"] == h["off_scales"] + ((2 * 2 * L * T + 15) & ~15)
+        assert h["version"] == 5 and h["off_scsum"] == h["off_scales"] + ((2 * 2 * L * T + 15) & ~15)
         for where in (h["off_scales"] + int(rng.integers(0, 2 * 2 * L * T)), h["off_scsum"] + int(rng.integers(0, 8 * L))):
             bad = bytearray(blob)
             bad[where] ^= 1 << int(rng.integers(0, 8))

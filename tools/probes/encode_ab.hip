@@ -203,7 +203,26 @@ int main(int argc, char** argv) {
          nelem * 2.0 / total, size_bad, hmm[0]);
   if (hmm[0]) printf(" (first at arena offset %llu = chunk %llu + %llu)", hmm[1], hmm[1] / stride, hmm[1] % stride);
   printf("\n");
-  const bool ok = !size_bad && !hmm[0] && !status[0] && !status[1];
+  // decode of the fused path's blobs straight back into a KV buffer of the same layout: time and status word only
+  // (values are checked by the GPU suite against the oracle)
+  {
+    unsigned short* out;
+    CK(hipMalloc(&out, nelem * 2));
+    lmc_kv_layout dl = lay;
+    dl.base = out;
+    status[2] = 0;
+    for (int w = 0; w < 2; w++) LK(lmc_decode_chunks(ctx, blob_b, stride, nchunks, &dl, 0, chunk, status + 2, s));
+    CK(hipStreamSynchronize(s));
+    CK(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; r++) LK(lmc_decode_chunks(ctx, blob_b, stride, nchunks, &dl, 0, chunk, status + 2, s));
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("decode      %.4f ms per job (%.1f GB/s raw)  status=%u\n", ms / reps, nelem * 2 / (ms / reps) / 1e6, status[2]);
+    CK(hipFree(out));
+  }
+  const bool ok = !size_bad && !hmm[0] && !status[0] && !status[1] && !status[2];
   printf("%s  fused/two-kernel time = %.3f\n", ok ? "PARITY OK" : "PARITY FAILED", ms_path[1] / ms_path[0]);
   LK(lmc_ctx_destroy(ctx));
   return ok ? 0 : 1;
