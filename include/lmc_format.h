@@ -28,9 +28,10 @@
  *                           their start value); the scales are the one section it cannot see, and a
  *                           flipped scale would silently rescale a whole token row.
  *   cdf      the per-channel symbol statistics the 16-bit CDF is a function of.  Per plane p:
- *                           [C][R_p] counts of the symbols 0 .. R_p - 1, R_p = bins - 1 being
- *                           the number of symbols the quantiser can emit (plane p starts
- *                           C * rowpre[p] entries in).  header.count_bytes = 1 when T <= 256:
+ *                           [R_p][C] counts of the symbols 0 .. R_p - 1 (symbol-major since v5: a
+ *                           coder lane owns a channel and reads / writes its counts with one
+ *                           coalesced access per symbol), R_p = bins - 1 being the number of
+ *                           symbols the quantiser can emit (plane p starts C * rowpre[p] entries in).  header.count_bytes = 1 when T <= 256:
  *                           one byte per count, a count of 256 stored as 255 (the counts of
  *                           a channel sum to T, so a reader adds T - sum to the entry that
  *                           reads 255); otherwise 2 (u16).  The CDF of a channel is

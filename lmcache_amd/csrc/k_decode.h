@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
 
   // ---- symbol counts of this group -> the CDF table in LDS, [entry][lane] u16 ----------------------------
   // The blob stores the counts of every channel's symbols 0 .. nsym-1 (nsym = bins - 1), one byte each for
-  // T <= 256 (lmc_format.h).  They are fetched coalesced, staged transposed in the table's own LDS, and
-  // every lane then turns its column into the CDF with the encoder's integer arithmetic.
+  // T <= 256 (lmc_format.h), symbol-major: a lane fetches its own channel's counts (coalesced rows) and turns
+  // them into its column of the table with the encoder's integer arithmetic.
   const u32 nsym = min(31u, max(3u, (u32)__builtin_amdgcn_readfirstlane((int)blob[bo.bins + p]) - 1u));
   {
     const u32 rp = (u32)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const u16*>(blob + bo.rowpre)[p]);
@@ -105,33 +105,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       if (lane == 0) atomicOr(a.status, LMC_ST_BAD_HEADER);
       return;
     }
-    const float rcpR = 1.0f / (float)nsym;
-    const u32 total = (u32)min(64, a.C - g * 64) * nsym;
-    const long long e00 = (long long)a.C * rp + (long long)g * 64 * nsym;
+    // plane p of the counts section is [nsym][C] (symbol-major): the lane reads its own channel's counts, one
+    // coalesced row per symbol, straight into registers (two counts per register)
     const bool bytes1 = dev_count_bytes(T) == 1u;  // wave-uniform
-    const u8* src8 = blob + bo.cdf + e00;
-    const u16* src16 = reinterpret_cast<const u16*>(blob + bo.cdf) + e00;
-#pragma unroll 1
-    for (u32 e0 = 0; e0 < total; e0 += 64 * 10) {  // <= 31 sweeps of 64, 10 loads in flight
-      u32 v[10];
+    const u8* const row0 = blob + bo.cdf + (long long)a.C * rp * (bytes1 ? 1 : 2);  // uniform
+    u32 cv[32];
 #pragma unroll
-      for (int i = 0; i < 10; i++) {
-        const u32 e = e0 + i * 64 + lane;
-        v[i] = e < total ? (bytes1 ? (u32)src8[e] : (u32)src16[e]) : 0u;
-      }
-#pragma unroll
-      for (int i = 0; i < 10; i++) {
-        const u32 e = e0 + i * 64 + lane;
-        u32 cl, sidx;
-        divmod_small(e, nsym, rcpR, cl, sidx);
-        if (e < total) cdfT[sidx * 64 + cl] = (u16)v[i];
-      }
+    for (int i = 0; i < 32; i++) {
+      cv[i] = 0u;
+      if ((u32)i < nsym && active)  // the first test is uniform
+        cv[i] = bytes1 ? (u32)(row0 + (long long)i * a.C)[c] : (u32)(reinterpret_cast<const u16*>(row0) + (long long)i * a.C)[c];
     }
-    for (u32 i = nsym; i < 32u; i++) cdfT[i * 64 + lane] = 0;  // symbols that cannot occur
-    wave_lds_fence();  // the staging was written transposed
     u32 hreg[16];  // this lane's 32 counts, two per register
 #pragma unroll
-    for (int i = 0; i < 16; i++) hreg[i] = (u32)cdfT[(2 * i) * 64 + lane] | ((u32)cdfT[(2 * i + 1) * 64 + lane] << 16);
+    for (int i = 0; i < 16; i++) hreg[i] = cv[2 * i] | (cv[2 * i + 1] << 16);
     if (bytes1) {  // a count of 256 was stored as 255: the counts of a channel sum to T
       u32 sum = 0;
 #pragma unroll

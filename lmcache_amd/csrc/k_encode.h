@@ -271,39 +271,26 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
     }
   }
   if (ENCODE) {
-    // The blob stores the COUNTS of every channel's symbols 0 .. R-1 (R = bins - 1; lmc_format.h): this
-    // group's [channel][R] block is contiguous, written with consecutive lanes on consecutive entries,
-    // reading the histogram transposed.  One byte per count for T <= 256 (256 saturates to 255).
+    // The blob stores the COUNTS of every channel's symbols 0 .. R-1 (R = bins - 1; lmc_format.h), symbol-major.
+    // One byte per count for T <= 256 (256 saturates to 255).
     wave_lds_fence();  // every lane's ds_add has landed
     const u32 T = (u32)Tc;
     const u32 R = (u32)a.bins.b[p] - 1u;
-    const float rcpR = 1.0f / (float)R;
-    const u32 total = (u32)min(64, a.C - g * 64) * R;
     const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
     u8* const blob0 = a.blobs + (long long)chunk * a.blob_stride;
     if (g == 0) {  // one wave per (chunk, plane): checksum of the plane's scales (written by k_quantize)
       const u32 cs = scale_checksum(reinterpret_cast<const u16*>(blob0 + bo.scales) + (long long)p * T, T, lane);
       if (lane == 0) reinterpret_cast<u32*>(blob0 + bo.scsum)[p] = cs;
     }
-    u8* sec = blob0 + bo.cdf;
-    const long long e0 = (long long)a.C * a.bins.rowpre[p] + (long long)g * 64 * R;
-    // entry e = channel e / R, symbol e % R; e advances by 64 per iteration, so (channel, symbol) are stepped by
-    // (64 / R, 64 % R) with one carry instead of being divided out again
-    u32 cl, sidx, dq, dr;
-    divmod_small((u32)lane, R, rcpR, cl, sidx);
-    divmod_small(64u, R, rcpR, dq, dr);
-    if (dev_count_bytes(T) == 1u) {
-      for (u32 e = lane; e < total; e += 64) {
-        sec[e0 + e] = (u8)min((u32)tab[sidx * 64 + cl], 255u);
-        sidx += dr; cl += dq;
-        if (sidx >= R) { sidx -= R; cl++; }
-      }
-    } else {
-      u16* dst = reinterpret_cast<u16*>(sec) + e0;
-      for (u32 e = lane; e < total; e += 64) {
-        dst[e] = tab[sidx * 64 + cl];
-        sidx += dr; cl += dq;
-        if (sidx >= R) { sidx -= R; cl++; }
+    // plane p of the counts section = [R][C] (symbol-major): a lane stores its own channel's counts, one coalesced
+    // row per symbol, reading its own column of the histogram
+    const u32 cb = dev_count_bytes(T);
+    u8* const sec_row0 = blob0 + bo.cdf + (long long)a.C * a.bins.rowpre[p] * cb;  // uniform
+    for (u32 i = 0; i < R; i++) {
+      const u32 v = tab[i * 64 + lane];
+      if (active) {
+        if (cb == 1u) (sec_row0 + (long long)i * a.C)[c] = (u8)min(v, 255u);
+        else (reinterpret_cast<u16*>(sec_row0) + (long long)i * a.C)[c] = (u16)v;
       }
     }
   }

@@ -19,8 +19,9 @@
 #include "k_encode.h"
 
 // ---- reciprocals of the frequencies 2 * count, count = 0 .. 256 ---------------------------------------------
-// entry = {magic, shift | (512 - 2 * count) << 8}: x / (2 count) = mulhi(x, magic) >> shift (v_lshrrev uses the low
-// five bits of its shift operand), and 512 - freq is the multiplier of the state update x += q * (512 - freq).
+// entry = {magic, (512 - 2 * count) | shift << 24}: x / (2 count) = mulhi(x, magic) >> shift (the shift is fetched
+// from the entry's top byte by an SDWA operand select), and 512 - freq is the multiplier of the state update
+// x += q * (512 - freq) (v_mad_u32_u24 reads the low 24 bits of its operands: no extraction either).
 #define RTAB_ENTRIES 257
 #define RTAB_DWORDS (2 * RTAB_ENTRIES + 2)  // 2064 B: a multiple of 16
 struct RansRtab {
@@ -34,7 +35,7 @@ constexpr RansRtab make_rans_rtab() {
     while ((1u << l) < f) l++;
     const u64 num = 1ull << (31u + l);
     t.v[2 * c] = (u32)((num + f - 1u) / f);   // lmc_rans_magic
-    t.v[2 * c + 1] = (l - 1u) | ((512u - f) << 8);
+    t.v[2 * c + 1] = (512u - f) | ((l - 1u) << 24);
   }
   return t;
 }
@@ -45,9 +46,10 @@ __device__ __forceinline__ void rtab_to_lds(u32* rtab_lds) {
   for (u32 i = threadIdx.x; i < RTAB_DWORDS; i += blockDim.x) rtab_lds[i] = g_rans_rtab.v[i];
 }
 
-// 1: the token loop's table reads are pipelined two deep behind the ring store (encode_group_stream_counts); 0: one deep
+// how far ahead the token loop requests its table reads (encode_group_stream_counts): 0: one token, in front of the
+// ring store; 1: entry two tokens / reciprocal one token ahead, behind the ring store; 2: four / two tokens ahead
 #ifndef LMC_COUNTS_LDSASM
-#define LMC_COUNTS_LDSASM 1
+#define LMC_COUNTS_LDSASM 2
 #endif
 
 // timing experiments (tools/probes): bit 0 the quantise phase twice, bit 1 the histogram pass twice, bit 2 the
@@ -60,24 +62,22 @@ __device__ __forceinline__ void rtab_to_lds(u32* rtab_lds) {
 
 #define CNT_TAB_DWORDS 1024  // per wave: counters, then (aliased) the table: [16][64] u32, or [32][64] u16
 
-// LDS byte address base + (field << SHIFT), field = WIDTH bits of w at bit POS, in the cheapest issue classes
-// (tools/probes/valu_rates.py: v_and / v_lshrrev / v_add issue in ~2 cycles, v_bfe / v_lshl_add / v_lshlrev /
-// SDWA forms in ~4).  Opaque asm: left to itself the compiler canonicalises to bfe + lshl_add or to a LEFT shift.
+// LDS byte address base + (field << SHIFT), field = WIDTH bits of w at bit POS, in TWO instructions whatever the
+// position (the coders are bound by the NUMBER of VALU instructions: SQ_ACTIVE_INST_VALU is 4.0 SIMD cycles per
+// instruction of any class, profiles/r03_*_pmc.md).  Opaque asm: left to itself the compiler canonicalises the
+// middle fields to shift + and + add.
 template <int POS, int WIDTH, int SHIFT>
 __device__ __forceinline__ u32 row_addr_sh(u32 w, u32 base) {
   constexpr u32 FIELD = ((1u << WIDTH) - 1u);
   u32 r;
-  if constexpr (POS < SHIFT) {
-    asm("v_and_b32_e32 %0, %2, %1\n\tv_lshl_add_u32 %0, %0, %3, %4"
-        : "=&v"(r) : "v"(w), "s"(FIELD << POS), "n"(SHIFT - POS), "v"(base));
-  } else if constexpr (POS == SHIFT) {
+  if constexpr (POS == SHIFT) {
     asm("v_and_b32_e32 %0, %2, %1\n\tv_add_u32_e32 %0, %0, %3" : "=&v"(r) : "v"(w), "s"(FIELD << SHIFT), "v"(base));
   } else if constexpr (POS + WIDTH == 32) {
     asm("v_lshrrev_b32_e32 %0, %2, %1\n\tv_lshl_add_u32 %0, %0, %3, %4"
         : "=&v"(r) : "v"(w), "n"(POS), "n"(SHIFT), "v"(base));
   } else {
-    asm("v_lshrrev_b32_e32 %0, %2, %1\n\tv_and_b32_e32 %0, %3, %0\n\tv_add_u32_e32 %0, %0, %4"
-        : "=&v"(r) : "v"(w), "n"(POS - SHIFT), "s"(FIELD << SHIFT), "v"(base));
+    asm("v_bfe_u32 %0, %1, %2, %3\n\tv_lshl_add_u32 %0, %0, %4, %5"
+        : "=&v"(r) : "v"(w), "n"(POS), "n"(WIDTH), "n"(SHIFT), "v"(base));
   }
   return r;
 }
@@ -95,7 +95,7 @@ typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
 // of LDS, `ring` its staging ring (ENC_RING_DWORDS), `rtab` the workgroup's copy of g_rans_rtab.
 // LDSASM: the token loop requests its table entries two tokens ahead and the reciprocal one token ahead, right
 // behind the step's ring store (see pass2); otherwise one token ahead, in front of it.
-template <bool LDSASM>
+template <int LDSASM>
 __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, long long gid, u32* tabmem, u16* const ring,
                                                            const u32* rtab, int lane, PendingTile& t) {
   typedef __attribute__((address_space(3))) u32* lds_u32w;
@@ -150,29 +150,22 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
 #endif
   wave_lds_fence();  // every lane's ds_add has landed
 
-  // ---- counts section of the blob (lmc_format.h): [channel][R] bytes, 256 saturating to 255 -----------------
   const u32 R = (u32)a.bins.b[p] - 1u;
   const BlobOff bo = lmc_blob_off((u32)a.P, (u32)Tc, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
   u8* const blob0 = a.blobs + (long long)chunk * a.blob_stride;
-  {
-    const float rcpR = 1.0f / (float)R;
-    const u32 total = (u32)min(64, a.C - g * 64) * R;
-    if (g == 0) {  // one wave per (chunk, plane): checksum of the plane's scales (written by the quantise stage)
-      const u32 cs = scale_checksum(reinterpret_cast<const u16*>(blob0 + bo.scales) + (long long)p * Tc, (u32)Tc, lane);
-      if (lane == 0) reinterpret_cast<u32*>(blob0 + bo.scsum)[p] = cs;
-    }
-    u8* sec = blob0 + bo.cdf;
-    const long long e0 = (long long)a.C * a.bins.rowpre[p] + (long long)g * 64 * R;
-    u32 cl, sidx, dq, dr;
-    divmod_small((u32)lane, R, rcpR, cl, sidx);
-    divmod_small(64u, R, rcpR, dq, dr);
-    for (u32 e = lane; e < total; e += 64) {
-      const u32 v = nib ? tabmem[sidx * 64 + cl] : (u32)tab16[sidx * 64 + cl];
-      sec[e0 + e] = (u8)min(v, 255u);
-      sidx += dr; cl += dq;
-      if (sidx >= R) { sidx -= R; cl++; }
-    }
+  if (g == 0) {  // one wave per (chunk, plane): checksum of the plane's scales (written by the quantise stage)
+    const u32 cs = scale_checksum(reinterpret_cast<const u16*>(blob0 + bo.scales) + (long long)p * Tc, (u32)Tc, lane);
+    if (lane == 0) reinterpret_cast<u32*>(blob0 + bo.scsum)[p] = cs;
   }
+  // counts section of the blob (lmc_format.h): plane p = [R][C] bytes, 256 saturating to 255 -- a lane stores its own
+  // channel's counts straight from its registers, one coalesced 64-byte row per symbol
+  u8* const sec_row0 = blob0 + bo.cdf + (long long)a.C * a.bins.rowpre[p];  // uniform
+  auto store_count = [&](u32 i, u32 v) {
+    if (i < R) {  // uniform
+      u8* row = sec_row0 + (long long)i * a.C;  // uniform base, lane offset c
+      if (active) row[c] = (u8)min(v, 255u);
+    }
+  };
 
   // ---- table ------------------------------------------------------------------------------------------------------
   // A channel whose 256 symbols are equal is coded with count 255 and a count of 1 on symbol 0 (symbol 1 if its own
@@ -182,6 +175,8 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
     u32 cnt[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) cnt[i] = tabmem[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 16; i++) store_count((u32)i, cnt[i]);
     u32 orv = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) orv |= cnt[i];
@@ -204,6 +199,8 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
     u32 hreg[16];  // this lane's 32 counts, two per register
 #pragma unroll
     for (int i = 0; i < 16; i++) hreg[i] = (u32)tab16[(2 * i) * 64 + lane] | ((u32)tab16[(2 * i + 1) * 64 + lane] << 16);
+#pragma unroll
+    for (int i = 0; i < 32; i++) store_count((u32)i, (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
     u32 orv = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) orv |= hreg[i];
@@ -245,30 +242,28 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
         const u32 over = wcur - flushed - 128u;  // < 64
         if ((u32)lane < over) ring[lane] = ring[ENC_RING_WORDS + lane];
       }
-      out32[(flushed >> 1) + lane] = reinterpret_cast<const u32*>(ring)[((flushed & (ENC_RING_WORDS - 1)) >> 1) + lane];
+      (out32 + (flushed >> 1))[lane] = (reinterpret_cast<const u32*>(ring) + ((flushed & (ENC_RING_WORDS - 1)) >> 1))[lane];
       flushed += 128u;
     }
   };
   // state update x += (x / f) * (512 - f) + start, the quotient by the frequency's reciprocal {m, shc}
   auto rans_put_nib = [&](u32 e, u32 m, u32 shc) {
-    u32 q, c2;
+    u32 q;
     asm("v_mul_hi_u32 %[q], %[x], %[m]\n\t"
-        "v_lshrrev_b32_e32 %[c2], 8, %[shc]\n\t"
-        "v_lshrrev_b32_e32 %[q], %[shc], %[q]\n\t"
-        "v_mad_u32_u24 %[x], %[q], %[c2], %[x]\n\t"
+        "v_lshrrev_b32_sdwa %[q], %[shc], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_mad_u32_u24 %[x], %[q], %[shc], %[x]\n\t"
         "v_add_u32_sdwa %[x], %[x], %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
-        : [x] "+v"(x), [q] "=&v"(q), [c2] "=&v"(c2)
+        : [x] "+v"(x), [q] "=&v"(q)
         : [m] "v"(m), [shc] "v"(shc), [e] "v"(e));
   };
   auto rans_put_byte = [&](u32 e, u32 m, u32 shc) {
-    u32 q, c2;
+    u32 q, st2;
     asm("v_mul_hi_u32 %[q], %[x], %[m]\n\t"
-        "v_lshrrev_b32_e32 %[c2], 8, %[shc]\n\t"
-        "v_lshrrev_b32_e32 %[q], %[shc], %[q]\n\t"
-        "v_mad_u32_u24 %[x], %[q], %[c2], %[x]\n\t"
-        "v_lshlrev_b32_sdwa %[c2], 1, %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
-        "v_add_u32_e32 %[x], %[x], %[c2]"
-        : [x] "+v"(x), [q] "=&v"(q), [c2] "=&v"(c2)
+        "v_lshrrev_b32_sdwa %[q], %[shc], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_lshlrev_b32_sdwa %[st2], 1, %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_mad_u32_u24 %[x], %[q], %[shc], %[x]\n\t"
+        "v_add_u32_e32 %[x], %[x], %[st2]"
+        : [x] "+v"(x), [q] "=&v"(q), [st2] "=&v"(st2)
         : [m] "v"(m), [shc] "v"(shc), [e] "v"(e));
   };
 
@@ -287,7 +282,7 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
     u32 w[DPB], wn[DPB];
 #pragma unroll
     for (int j = 0; j < DPB; j++) w[j] = active ? symq[(long long)((NB - 1) * DPB + j) * a.C] : 0u;
-    if constexpr (!LDSASM) {
+    if constexpr (LDSASM == 0) {
       // plain form: loads and waits left to the compiler, the entry and its reciprocal fetched a token ahead
       u32 e_n = entry_at(row_addr_cnt<NIB, 31>(w, col));
       u32x2_t r_n = rtab_of(e_n);
@@ -336,6 +331,70 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
           flush_ring();
           if constexpr (NIB) rans_put_nib(e, r.x, r.y);
           else rans_put_byte(e, r.x, r.y);
+        });
+#pragma unroll
+        for (int j = 0; j < DPB; j++) w[j] = wn[j];
+      }
+    } else if constexpr (LDSASM == 2) {
+      // Deep form of the pipeline below: the entry of a token is requested FOUR steps ahead, its reciprocal TWO (from
+      // an entry that landed two steps earlier), so the wait in front of a step's block covers requests that are two
+      // steps old and leaves the previous step's three LDS operations in flight.  The one-step distance of the form
+      // below is enough at 8 waves per SIMD; in the fused kernel the coding waves share their CU with workgroups that
+      // fetch (k_cdf_encode at half occupancy: +28 %), and there the extra distance is what hides the LDS latency.
+      u32 E0 = entry_at(row_addr_cnt<NIB, 31>(w, col));
+      u32 E1 = entry_at(row_addr_cnt<NIB, 30>(w, col));
+      u32 E2 = entry_at(row_addr_cnt<NIB, 29>(w, col));
+      u32 E3 = entry_at(row_addr_cnt<NIB, 28>(w, col));
+      u32x2_t R0 = rtab_of(E0);
+      u32x2_t R1 = rtab_of(E1);
+      for (int b = NB - 1; b >= 0; b--) {
+#pragma unroll
+        for (int j = 0; j < DPB; j++) wn[j] = (b > 0 && active) ? symq[(long long)((b - 1) * DPB + j) * a.C] : 0u;
+        static_for<32>([&](auto itag) {
+          constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
+          u32 ad4;  // row address of the token four further on (past the last block: row 0, read and never used)
+          if constexpr (i >= 4) ad4 = row_addr_cnt<NIB, i - 4>(w, col);
+          else ad4 = row_addr_cnt<NIB, 28 + i>(wn, col);
+          const u32 wbase = ring_addr + ((wcur & (ENC_RING_WORDS - 1)) << 1);  // scalar
+          u32 tt, cnt, ra;
+          if constexpr (NIB) {
+            asm volatile("v_lshrrev_b32_e32 %[ra], 20, %[e2]\n\t"
+                         "v_cmpx_ge_u32_sdwa vcc, %[x], %[e0] src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+                         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                         "s_nop 0\n\t"
+                         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                         "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
+                         "ds_write_b16 %[t], %[x]\n\t"
+                         "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                         "s_mov_b64 exec, %[full]"
+                         : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
+                         : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wbase), [full] "s"(full_exec)
+                         : "vcc", "scc", "memory");
+          } else {
+            asm volatile("v_lshlrev_b32_sdwa %[ra], 3, %[e2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                         "v_lshlrev_b32_sdwa %[t], 23, %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                         "v_cmpx_ge_u32_e32 vcc, %[x], %[t]\n\t"
+                         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                         "s_nop 0\n\t"
+                         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                         "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
+                         "ds_write_b16 %[t], %[x]\n\t"
+                         "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                         "s_mov_b64 exec, %[full]"
+                         : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
+                         : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wbase), [full] "s"(full_exec)
+                         : "vcc", "scc", "memory");
+          }
+          const u32x2_t R2 = *(const __attribute__((address_space(3))) u32x2_t*)(size_t)(rtab_addr + ra);
+          const u32 E4 = entry_at(ad4);
+          wcur += cnt;
+          flush_ring();
+          if constexpr (NIB) rans_put_nib(E0, R0.x, R0.y);
+          else rans_put_byte(E0, R0.x, R0.y);
+          E0 = E1; E1 = E2; E2 = E3; E3 = E4;
+          R0 = R1; R1 = R2;
         });
 #pragma unroll
         for (int j = 0; j < DPB; j++) w[j] = wn[j];
@@ -437,6 +496,10 @@ template <bool QUADSYM, bool ENCODE>
 __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
   __shared__ __attribute__((aligned(16))) u32 lds_all[ENC_WAVES * ENC_WAVE_DWORDS];  // the staging rings, then the tables
   __shared__ __attribute__((aligned(16))) u32 rtab_lds[ENCODE ? RTAB_DWORDS : 4];         // counts model: reciprocals
+#ifdef LMC_EXP_CDF_LDS_PAD  // timing experiment: fewer workgroups per CU (occupancy sweep of the coder)
+  __shared__ u32 lds_pad[LMC_EXP_CDF_LDS_PAD];
+  if (threadIdx.x == 0 && a.nchunks < 0) lds_pad[a.P] = 1;
+#endif
   if (ENCODE && QUADSYM) {
     rtab_to_lds(rtab_lds);
     __syncthreads();
@@ -466,7 +529,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
     const int chunk_of = (int)(gid / ((long long)a.P * a.G));
     const bool counts_model =
         min(a.chunk_tokens, a.tok_end - (a.tok_begin + chunk_of * a.chunk_tokens)) == (int)LMC_COUNTS_T;  // wave-uniform
-    if (counts_model) encode_group_stream_counts<LMC_COUNTS_LDSASM != 0>(a, gid, hist, wring, rtab_lds, lane, t);
+    if (counts_model) encode_group_stream_counts<LMC_COUNTS_LDSASM>(a, gid, hist, wring, rtab_lds, lane, t);
     else encode_group_stream<QUADSYM, ENCODE>(a, gid, hist, wring, lane, t);
   } else {
     encode_group_stream<QUADSYM, ENCODE>(a, gid, hist, wring, lane, t);

@@ -25,7 +25,15 @@
 #include "k_quantize.h"
 
 #define FUSED_MAX_G 16
+#ifndef FUSED_WAVES
 #define FUSED_WAVES 8  // waves per workgroup: 4 workgroups per CU
+#endif
+#ifndef LMC_FUSED_PRIO_A
+#define LMC_FUSED_PRIO_A 3  // wave priority while a wave fetches / quantises (phase A) ...
+#endif
+#ifndef LMC_FUSED_PRIO_B
+#define LMC_FUSED_PRIO_B 0  // ... and while it codes (phase B)
+#endif
 
 struct FusedArgs {
   KvAddr src;
@@ -137,13 +145,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
         }
         mrow[r] = max(m & 0xffffu, m >> 16);
       }
-      {
-        u32 m2 = mrow[0] | (mrow[1] << 16);
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) m2 = pk_max_u16(m2, (u32)__shfl_xor((int)m2, off));
-        mrow[0] = m2 & 0xffffu;
-        mrow[1] = m2 >> 16;
-      }
+      wave_max2_u32(mrow[0], mrow[1]);  // wave-uniform from here on
       if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -153,8 +155,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
       bool special[2];
       bool any_special = false;
       // both row maxes are wave-uniform: one scalar branch picks the short division for the pair
-      const bool short_div = LMC_SHORT_ROW_DIV && row_div_in_range((u32)__builtin_amdgcn_readfirstlane((int)mrow[0]), DT) &&
-                             row_div_in_range((u32)__builtin_amdgcn_readfirstlane((int)mrow[1]), DT);
+      const bool short_div = LMC_SHORT_ROW_DIV && row_div_in_range(mrow[0], DT) && row_div_in_range(mrow[1], DT);
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         const float sf = h2f_rt(mrow[r], DT);
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     uint4* const park = reinterpret_cast<uint4*>(hist);  // the wave's table slice is idle until phase B
     // Waves that fetch run at raised priority: their (few) instructions go first, so the loads are out early and
     // return under the other workgroups' coding.
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(LMC_FUSED_PRIO_A);
 #if LMC_EXP_TWICE & 1
 #pragma unroll 1
     for (int rep = 0; rep < 2; rep++)
@@ -264,9 +265,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         quantize_oct_fused<NITER, DT, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
                                              sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
     }
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(LMC_FUSED_PRIO_B);
   }
   __syncthreads();  // symbols and scales of the plane-chunk are visible to the workgroup
+#if LMC_EXP_TWICE & 128  // timing experiment: phase A only
+  return;
+#endif
 
   // ---- phase B: code this wave's group streams -----------------------------------------------------------
 #if LMC_EXP_TWICE & 32
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll 1
   for (int g = wave; g < a.G; g += NW) {
     PendingTile t;
-    encode_group_stream_counts<LMC_COUNTS_LDSASM != 0>(LMC_FUSED_ENC_ARGS, gid0 + g, hist, ring, rtab_lds, lane, t);
+    encode_group_stream_counts<LMC_COUNTS_LDSASM>(LMC_FUSED_ENC_ARGS, gid0 + g, hist, ring, rtab_lds, lane, t);
     if (lane == 0) st_len[g] = t.exact;
     wave_lds_fence();  // the next stream reuses this wave's LDS slices
   }

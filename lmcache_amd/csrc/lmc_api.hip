@@ -40,6 +40,7 @@ struct lmc_ctx {
   bool ws_used = false;
   int num_cus = 256;
   int enc_path = LMC_ENCODE_PATH_AUTO;  // lmc_ctx_set_encode_path
+  bool pre_all = false;
   int pre_step = 0;                     // fused encode: every pre_step-th workgroup of the first generation gets a head start
                                         // (0: none -- measured 1.06 ms without, 1.07-1.09 with 2 / 3 / 4: k_fused.h)
   u32 epoch = 0;                        // of the last fused launch (tags its look-back granules)
@@ -91,6 +92,7 @@ int lmc_ctx_create(int device, lmc_ctx** out) {
   e = hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming);
   if (e != hipSuccess) { g_last_hip = (int)e; (void)hipHostFree(c->status_h); delete c; return LMC_ERR_HIP; }
   if (const char* e = getenv("LMC_FUSED_PRE_STEP")) c->pre_step = atoi(e);  // A/B switch of the head start (tools/probes)
+  if (const char* e = getenv("LMC_FUSED_PRE_ALL")) c->pre_all = atoi(e) != 0;  // experiment: EVERY plane-chunk quantised up front
   *out = c;
   return LMC_OK;
 }
@@ -379,8 +381,8 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     if ((rc = prof_mark(c, s))) return rc;
     // head start (k_fused.h): with at least three generations of workgroups, every pre_step-th plane-chunk of the
     // first generation (4 workgroups per CU) is quantised by k_quantize in front of the fused launch
-    const long long gen1 = 4ll * c->num_cus;
-    if (c->pre_step > 0 && (long long)nfull * P >= 3 * gen1) {
+    const long long gen1 = c->pre_all ? (long long)nfull * P : 4ll * c->num_cus;
+    if (c->pre_step > 0 && (c->pre_all || (long long)nfull * P >= 3 * gen1)) {
       fa.pre_limit = (u32)gen1; fa.pre_step = (u32)c->pre_step;
       QuantArgs qa;
       memset(&qa, 0, sizeof qa);

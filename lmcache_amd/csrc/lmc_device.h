@@ -160,11 +160,54 @@ __device__ __forceinline__ float row_div_short(float maxf, float sf) {
   return __builtin_fmaf(r, y, q0);
 }
 
+// a pointer every lane holds -> an SGPR pair (so that loads through it take the scalar-base + 32-bit lane-offset form)
+__device__ __forceinline__ u64 uniform_ptr64(const void* p) {
+  const u64 v = (u64)p;
+  const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
+  const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+  return ((u64)hi << 32) | (u64)lo;
+}
+
 // Order this wave's LDS traffic (cross-lane hand-off inside one wave): a
 // compiler + hardware fence at wavefront scope; no workgroup barrier needed.
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
+}
+
+// max over the 64 lanes of a wave for TWO values at once, on the VALU's data-parallel-primitive path (no LDS round
+// trips: __shfl_xor is ds_bpermute_b32 + s_waitcnt, six of them in a row on the quantise stage's critical path):
+// quad swaps, half-row and row mirrors leave every row of 16 lanes with its maximum, row_bcast15 / row_bcast31 carry
+// it into the rows above, lane 63 holds the wave's maximum.  The two chains are interleaved so that each DPP read
+// has its two wait states behind the write of its register (one of them is the other chain's instruction).  The
+// results are wave-uniform (SGPRs).
+__device__ __forceinline__ void wave_max2_u32(u32& a, u32& b) {
+  u32 sa, sb;
+  asm("s_nop 1\n\t"
+      "v_max_u32_dpp %[a], %[a], %[a] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_u32_dpp %[b], %[b], %[b] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_u32_dpp %[a], %[a], %[a] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_u32_dpp %[b], %[b], %[b] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_u32_dpp %[a], %[a], %[a] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_u32_dpp %[b], %[b], %[b] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_u32_dpp %[a], %[a], %[a] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_u32_dpp %[b], %[b], %[b] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_u32_dpp %[a], %[a], %[a] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_max_u32_dpp %[b], %[b], %[b] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_max_u32_dpp %[a], %[a], %[a] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_max_u32_dpp %[b], %[b], %[b] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_readlane_b32 %[sa], %[a], 63\n\t"
+      "v_readlane_b32 %[sb], %[b], 63\n\t"
+      "s_nop 4"  // whatever follows may read the two SGPRs at once (the compiler does not look inside the block)
+      : [a] "+v"(a), [b] "+v"(b), [sa] "=s"(sa), [sb] "=s"(sb));
+  a = sa;
+  b = sb;
 }
 
 __device__ __forceinline__ u32 wave_sum_u32(u32 v) {

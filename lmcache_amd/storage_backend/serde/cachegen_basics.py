@@ -125,7 +125,7 @@ class CacheGenGPUEncoderOutput:
         i = np.arange(LP, dtype=np.int64)
         for p, b in enumerate(self.bins):
             R = b - 1
-            cnt = stored[C * rowpre[p]:C * rowpre[p + 1]].reshape(C, R).copy()
+            cnt = stored[C * rowpre[p]:C * rowpre[p + 1]].reshape(R, C).T.copy()  # stored symbol-major
             if dt is np.uint8:  # a count of 256 reads 255: the counts of a channel sum to T
                 short = T - cnt.sum(axis=1)
                 rows, cols = np.nonzero((cnt == 255) & (short[:, None] > 0))

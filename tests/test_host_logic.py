@@ -271,7 +271,7 @@ def test_blob_counts_section_rebuilds_the_reference_cdf(oracle, T):
     assert np.array_equal(oracle.blob_cdf(blob), want)
     assert np.array_equal(oracle.decode_blob_symbols(blob), sym)
     if T == 256:  # the saturated count is really there
-        sec = np.frombuffer(blob, np.uint8, count=H * D * 31, offset=h.off_cdf).reshape(H * D, 31)
+        sec = np.frombuffer(blob, np.uint8, count=H * D * 31, offset=h.off_cdf).reshape(31, H * D).T  # [symbol][channel]
         assert sec[5].max() == 255 and sec[5].sum() == 255
 
 
