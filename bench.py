@@ -129,7 +129,52 @@ def cpu_baseline(nchunks_sample):
            "sample": f"{nchunks_sample} chunks of 256 tokens (Llama-3-8B shape, {raw / 1e6:.0f} MB raw KV), "
                      f"oracle/lmc_oracle.c lmco_encode_blob, {workers} chunks at a time x OpenMP over planes/groups"}
     out["reference_formula"] = cpu_reference_formula(kv)
+    out["torch_serde"] = cpu_torch_serde()
     return out
+
+
+def cpu_torch_serde():
+    """The reference's own CPU serde of BASELINE configs[0]: TorchSerializer.to_bytes =
+    torch.save(t.cpu().clone().detach()) into a BytesIO, TorchDeserializer.from_bytes = torch.load
+    (lmcache/storage_backend/serde/torch_serde.py:16-31), on one config-1 chunk [32, 2, 256, 32, 128] fp16 = 128 MiB,
+    restated line for line (the reference package needs torchac_cuda / nvtx stubs to import and is not on the GPU
+    box).  One thread is what the reference's store() runs it on; N threads = N chunks serialised at once."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    t = torch.rand((32, 2, 256, 32, 128), generator=torch.Generator().manual_seed(0)).to(torch.float16)
+    raw = t.numel() * 2
+
+    def to_bytes(x):
+        with io.BytesIO() as f:
+            torch.save(x.cpu().clone().detach(), f)
+            return f.getvalue()
+
+    def from_bytes(b):
+        with io.BytesIO(b) as f:
+            return torch.load(f, weights_only=True)
+
+    blob = to_bytes(t)
+    res = {"chunk_bytes": raw, "blob_bytes": len(blob)}
+    reps, t0 = 0, time.perf_counter()
+    while reps < 5 and time.perf_counter() - t0 < 4.0:
+        to_bytes(t)
+        reps += 1
+    res["to_bytes_GBps_1_thread"] = round(raw * reps / (time.perf_counter() - t0) / 1e9, 3)
+    reps, t0 = 0, time.perf_counter()
+    while reps < 5 and time.perf_counter() - t0 < 4.0:
+        from_bytes(blob)
+        reps += 1
+    res["from_bytes_GBps_1_thread"] = round(raw * reps / (time.perf_counter() - t0) / 1e9, 3)
+    nthreads = min(len(os.sched_getaffinity(0)), 16)  # 16 x (128 MiB tensor + 128 MiB of bytes) in flight is plenty
+    with ThreadPoolExecutor(max_workers=nthreads) as pool:
+        t0 = time.perf_counter()
+        list(pool.map(lambda _: to_bytes(t), range(nthreads)))
+        dt = time.perf_counter() - t0
+    res["to_bytes_GBps_n_threads"] = round(raw * nthreads / dt / 1e9, 3)
+    res["n_threads"] = nthreads
+    res["sample"] = ("one BASELINE configs[0] chunk (fp16 [32, 2, 256, 32, 128], 134 MB): torch.save / torch.load through "
+                     "BytesIO as TorchSerializer / TorchDeserializer do; lossless, no compression (blob = raw + header)")
+    return res
 
 
 def cpu_reference_formula(kv_chunk):
@@ -198,6 +243,43 @@ class DecodeStepProxy:
             evs[i + 1].record()
         torch.cuda.synchronize()
         return [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+
+
+class ColdPrefillProxy:
+    """What a COLD 16k-token prefill costs at least: the dense GEMMs of Llama-3-8B over the whole prompt -- per layer
+    QKV [T,4096]x[4096,6144], O [T,4096]x[4096,4096], gate+up [T,4096]x[4096,28672], down [T,14336]x[14336,4096]
+    (2.29e14 FLOP over 32 layers, bf16, hipBLASLt through torch.matmul).  Attention, norms and the sampler are left
+    out (no vLLM in this image), so the cold TTFT of a real engine is larger and warm_vs_cold smaller than reported.
+    One layer's weights stand for all 32 (436 MB instead of 14 GB; they stream from HBM either way)."""
+
+    def __init__(self, dev, ntok=CTX):
+        g = torch.Generator(device=dev).manual_seed(0)
+        mk = lambda *shape: (torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+        self.x = mk(ntok, 4096)
+        self.wqkv, self.wo, self.wgu, self.wd = mk(4096, 6144), mk(4096, 4096), mk(4096, 28672), mk(14336, 4096)
+        self.flop = 32 * 2 * ntok * 4096 * (6144 + 4096 + 28672 + 14336)
+
+    def run(self):
+        x = self.x
+        for _ in range(32):
+            q = x @ self.wqkv
+            o = q[:, :4096] @ self.wo
+            gu = o @ self.wgu
+            x = (gu[:, :14336] * gu[:, 14336:]) @ self.wd
+        return x
+
+    def time_ms(self, reps=3):
+        self.run()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.run()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return median(ts)
 
 
 def time_encode(ctx, layout, ntok, chunk, bins, blobs, stride, sizes, sp, stream, reps):
@@ -379,7 +461,8 @@ def main(argv=None):
             dist.destroy_process_group()
         return
 
-    res = {"metric": "KV encode+offload GB/s per GPU (raw 16-bit KV bytes consumed; encode into HBM blobs)",
+    res = {"metric": "KV encode+offload GB/s per GPU -- value = CacheGen encode, HBM -> HBM (raw 16-bit KV bytes consumed, "
+                     "PCIe never inside value); the PCIe-inclusive encode+offload rate is offload.encode_plus_offload_GBps_raw_kv",
            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16->u8 symbols (fp32 quantise, u32 rANS)", "data": f"synthetic ({args.dist})",
@@ -625,6 +708,37 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
         retrieve = retrieve or {"error": repr(e)}
     res["offload"], res["retrieve"] = offload, retrieve
 
+    stage("store leg through the C ABI")
+    # ---- the same store leg as ONE C-ABI call (lmc_store_chunks): no Python sequencing, no host wait ---------------
+    try:
+        cap = int(blob_bytes) + (64 << 20)
+        harena = native.PinnedBuffer(cap)
+        hmeta = native.PinnedBuffer(8 * (nchunks + 1) + 4 * nchunks + 64)
+        p_offs, p_sizes, p_status = hmeta.ptr, hmeta.ptr + 8 * (nchunks + 1), hmeta.ptr + 8 * (nchunks + 1) + 4 * nchunks
+        hstatus = hmeta.tensor[8 * (nchunks + 1) + 4 * nchunks:8 * (nchunks + 1) + 4 * nchunks + 4].view(torch.int32)
+        hstatus[0] = 0
+        calls, totals = [], []
+        for r in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.store_chunks(layout, 0, CTX, CHUNK, bins, harena.ptr, cap, p_offs, p_sizes, stream=sp, status_ptr=p_status)
+            calls.append((time.perf_counter() - t0) * 1e3)
+            stream.synchronize()
+            totals.append((time.perf_counter() - t0) * 1e3)
+        used = int(hmeta.tensor[8 * nchunks:8 * (nchunks + 1)].view(torch.int64)[0])
+        res["offload_c_abi"] = {"ms_per_context": round(median(totals[1:]), 3),
+                                "store_call_returns_after_ms": round(median(calls[1:]), 3),
+                                "encode_plus_offload_GBps_raw_kv": round(raw_bytes / median(totals[1:]) / 1e6, 1),
+                                "pcie_GBps_blob": round(used / median(totals[1:]) / 1e6, 1), "host_bytes": used,
+                                "status": int(hstatus[0]), "reps": 5,
+                                "note": "lmc_store_chunks: encode in 4 parts + a device-side copy kernel per part that "
+                                        "reads the sizes on the GPU and writes the blobs, exact size, into the mapped "
+                                        "pinned arena (k_offload.h); the call returns without any host wait"}
+        harena.free()
+        hmeta.free()
+    except Exception as e:
+        res["offload_c_abi"] = {"error": repr(e)}
+
     stage("decode leg")
     # ---- decode leg: blobs in HBM -> decoded KV written straight into per-layer tensors ----------------------
     out = tuple((torch.empty_like(k), torch.empty_like(v)) for k, v in kv)
@@ -756,10 +870,55 @@ def overlap_legs(dev, kv, raw_bytes):
         assert int(mask.sum()) == CTX
         del ret
     ttft = ttft[1:]
+    # the same warm prefix cut by layers (engine.retrieve_layerwise -> lmc_load_chunks): the streams of layer range r + 1
+    # cross PCIe (one hipMemcpyAsync per contiguous plane run and blob) while range r is decoded and the model's layers
+    # of the ranges that are complete run.  Measured: no gain on this link -- a cut into R ranges is 64 x (1 + 2 R)
+    # copies of a few hundred KB instead of 64 of 8 MB, and the DMA engines lose more on the small copies than the
+    # overlap wins (a gather KERNEL reading the pinned blobs moves 41 GB/s against the DMA's 52: DESIGN.md section 5)
+    from lmcache_amd.storage_backend.serde.cachegen_device import layer_ranges
+    piped = {}
+    for lpr in (8, 16, 32):
+        ts = []
+        for r in range(reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(side):
+                lw = engine.retrieve_layerwise(last_toks, layers_per_launch=lpr)
+            for l0, l1 in layer_ranges(L, lpr):
+                lw.wait_layer(l0)
+                for l in range(l0, l1):
+                    torch.mv(proxy.w[l], proxy.x, out=proxy.y)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            lw.finish()
+            assert int(lw.ret_mask.sum()) == CTX
+            del lw
+        piped[lpr] = median(ts[1:])
+    best_lpr = min(piped, key=piped.get)
     engine.close()
+    # the metric's "vs cold": a cold 16k prefill proxy (dense GEMMs only) + the first decode step
+    try:
+        cold = ColdPrefillProxy(dev)
+        cold_ms = cold.time_ms()
+        cold_tflops = cold.flop / (cold_ms / 1e3) / 1e12
+        del cold
+    except Exception as e:
+        cold_ms, cold_tflops = None, repr(e)
+    pcie_ms = raw_bytes / 4.2 / 52e9 * 1e3
     ttft_proxy = {"retrieve_plus_one_step_ms": round(median(ttft), 3), "one_step_ms": round(alone, 3),
                   "ratio": round(median(ttft) / alone, 3), "target": "<= 1.05", "reps": reps,
-                  "pcie_floor_ms": round(0.0 + raw_bytes / 4.2 / 52e9 * 1e3, 2),
+                  "layerwise_ms": round(piped[best_lpr], 3), "layerwise_ratio": round(piped[best_lpr] / alone, 3),
+                  "layerwise_layers_per_range": best_lpr,
+                  "layerwise_ms_by_layers_per_range": {str(k): round(v, 3) for k, v in piped.items()},
+                  "layerwise_goal_ms": round(max(pcie_ms, alone) + 1.0, 3),
+                  "cold_prefill_proxy_ms": None if cold_ms is None else round(cold_ms, 2),
+                  "cold_prefill_proxy_TFLOPs": cold_tflops if cold_ms is None else round(cold_tflops, 1),
+                  "warm_vs_cold": None if cold_ms is None else round(piped[best_lpr] / (cold_ms + alone), 4),
+                  "warm_vs_cold_note": "(warm: layer-wise retrieve of the 16k prefix from pinned host DRAM + one decode "
+                                       "step) / (cold: dense-GEMM prefill proxy of the 16k prompt + one decode step); the "
+                                       "reference's published figure is this ratio on its own hardware, 0.4-0.7 s warm vs "
+                                       "2.4-2.9 s cold (docs/source/examples/measuring_improvements.rst:42-48,70-78)",
+                  "pcie_floor_ms": round(pcie_ms, 2),
                   "note": "engine.retrieve() of the warm 16k prefix from pinned host DRAM (510 MB of blobs over one PCIe "
                           "Gen5 x16 link, ~52 GB/s measured: that transfer alone is the floor shown) + one proxy step, "
                           "over one proxy step; chunk-pipelined H2D/decode, not yet layer-pipelined (DESIGN.md section 5)"}

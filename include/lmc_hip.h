@@ -45,7 +45,7 @@ const char* lmc_strerror(int code);
 int lmc_last_hip_error(void);
 /* ABI version of this header. */
 int lmc_abi_version(void);
-#define LMC_ABI_VERSION 3
+#define LMC_ABI_VERSION 4
 
 /* ------------------------------------------------------------------ */
 /* KV addressing                                                       */
@@ -106,6 +106,7 @@ int lmc_ctx_reserve(lmc_ctx* ctx, int L, int H, int D, int chunk_tokens, int max
 #define LMC_STATUS_BAD_STREAM 4u      /* decode: directory out of bounds, words left over, final state wrong */
 #define LMC_STATUS_LOOKBACK_TIMEOUT 8u
 #define LMC_STATUS_BAD_SCALES 16u     /* decode: a plane's scales do not match their checksum (lmc_format.h: scsum) */
+#define LMC_STATUS_HOST_ARENA_FULL 32u /* lmc_store_chunks: the pinned arena cannot take the job's blobs */
 /* The context's sticky status word.  `clear` resets it. */
 int lmc_device_status(lmc_ctx* ctx, int clear);
 
@@ -244,6 +245,45 @@ int lmc_pinned_alloc(size_t bytes, void** out_h);
 int lmc_pinned_free(void* ptr_h);
 /* hipMemcpyAsync on `stream`; kind: 0 = D2H, 1 = H2D, 2 = D2D. */
 int lmc_memcpy_async(void* dst, const void* src, size_t bytes, int kind, lmc_stream_t stream);
+
+/*
+ * The store leg in ONE call: encode the chunks (as lmc_encode_chunks does, into an arena the context owns) and move
+ * every blob, at its exact size, into a pinned host arena -- with no host wait anywhere: the sizes are read on the GPU
+ * by the copy kernel (k_offload.h), which also writes them, and the blobs' offsets, to pinned words for later.
+ * Stands where LMCLocalBackend.put_blocking / put_nonblocking stand (local_backend.py:82-100): `.to("cpu")` behind a
+ * device synchronisation.  A long job leaves in a few parts: the copy of part k (on a stream of the context) runs
+ * beside the encode of part k + 1; `stream` is done when everything has landed.
+ *   host_arena_h   pinned, device-mapped (lmc_pinned_alloc), host_cap bytes
+ *   offsets_h      pinned uint64 [nchunks + 1]: blob i lies at host_arena_h + offsets_h[i]; [nchunks] = bytes used
+ *   sizes_h        pinned uint32 [nchunks]: its size (0 and LMC_STATUS_HOST_ARENA_FULL if it did not fit)
+ *   job_status     pinned status word of this job (may be NULL: the context's sticky word)
+ * All three arrays are valid once `stream` has completed.
+ */
+int lmc_store_chunks(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
+                     const int32_t* bins_h, void* host_arena_h, uint64_t host_cap, uint64_t* offsets_h,
+                     uint32_t* sizes_h, uint32_t* job_status, lmc_stream_t stream);
+
+/*
+ * The retrieve leg in ONE call, cut by layers: blobs in pinned host memory -> decoded KV in `dst`.  The blobs' headers
+ * and stream directories are read by the CPU where they lie (pinned host memory: no GPU work, no wait); everything but
+ * the streams (an eighth of a blob) is copied first, then for every range of `layers_per_range` layers the streams of
+ * those layers' planes -- one contiguous run of K planes and one of V planes per blob -- go over PCIe as
+ * hipMemcpyAsyncs on two copy streams of the context, and the decode of the range (lmc_decode_chunks_layers) follows
+ * on `stream`: the transfer of range r + 1 runs beside the decode of range r and beside whatever the caller's model
+ * does with the layers that are complete.  Stands where LMCLocalBackend.get + CacheGenDeserializer.from_bytes + the
+ * engine's torch.cat stand (local_backend.py:128-144, cache_engine.py:339-381): whole chunks to the GPU first, then
+ * everything decoded, then the first layer can run.
+ *   host_blob_ptrs_h  host array [nchunks] of pinned blob addresses (16-byte aligned); read during the call only
+ *   sizes_h           host array [nchunks] of their sizes; read during the call only
+ *   range_events      NULL, or [ceil(L / layers_per_range)] events: event r is recorded on `stream` behind the decode
+ *                     of range r (the KV of its layers is complete once it has fired)
+ *   layers_per_range  0 = all layers in one range
+ * Returns LMC_ERR_INVALID, with nothing queued that could write `dst`, if a blob's header or directory does not check out.
+ * The blobs themselves must stay where they are until `stream` has completed.
+ */
+int lmc_load_chunks(lmc_ctx* ctx, const void* const* host_blob_ptrs_h, const uint32_t* sizes_h, int32_t nchunks,
+                    const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, int32_t layers_per_range,
+                    lmc_event_t* range_events, uint32_t* job_status, lmc_stream_t stream);
 
 int lmc_stream_create(lmc_stream_t* out);
 int lmc_stream_destroy(lmc_stream_t s);

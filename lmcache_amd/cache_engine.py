@@ -307,7 +307,7 @@ class LMCacheEngine:
             H, D = (shape0[3], shape0[4]) if fmt == "vllm" else (shape0[2], shape0[4])
             dst = make_dst(nret, L, H, D, dtype, dev)
             try:
-                if jobs_out is not None and getattr(self.engine_, "mode", None) == "hbm-cachegen":
+                if jobs_out is not None and getattr(self.engine_, "mode", None) in ("hbm-cachegen", "cachegen"):
                     got = self.engine_.get_kv_range(keys[:hits], dst, fmt, -extra, cs,
                                                     layers_per_launch=layers_per_launch, jobs_out=jobs_out)
                 else:
@@ -364,11 +364,18 @@ class LayerwiseRetrieval:
         if not self.layer_events:
             return
         st = stream or torch.cuda.current_stream()
+
+        def wait(ev):  # a torch event, or a native.NativeEvent recorded by lmc_load_chunks
+            if hasattr(ev, "handle"):
+                ev.wait(st.cuda_stream)
+            else:
+                st.wait_event(ev)
+
         for end, ev in self.layer_events:
             if layer < end:
-                st.wait_event(ev)
+                wait(ev)
                 return
-        st.wait_event(self.layer_events[-1][1])
+        wait(self.layer_events[-1][1])
 
     def finish(self) -> None:
         """Host-side completion: waits for the decode and raises NativeError if a blob did not check out."""

@@ -44,7 +44,23 @@ struct EncodeArgs {
   unsigned long long* agg;  // [nchunks][P*G], zeroed before the launch: flag << 62 | value
   u32* sizes;               // [nchunks] total blob bytes
   int L, H, D, dtype;       // for the header
+  // Work tickets.  The look-back of the in-kernel compaction waits for workgroups with LOWER work indices; taking
+  // the work index from blockIdx assumes the hardware starts workgroups in index order, which HIP does not
+  // promise.  Instead every workgroup draws a ticket from a device counter when it STARTS (one relaxed agent-scope
+  // atomic add by one lane) and works on item `ticket - ticket_base`: whoever holds a lower index has started
+  // already and never waits for a later one, whatever the dispatch order.  The counter is never reset: the host
+  // knows how many tickets earlier launches drew (ticket_base); launches sharing a context run on ordered streams.
+  u32* ticket;
+  u32 ticket_base;
 };
+
+// The calling workgroup's work index (see EncodeArgs::ticket); ends with a workgroup barrier.
+__device__ __forceinline__ u32 draw_ticket(u32* ticket, u32 base) {
+  __shared__ u32 wg_ticket;
+  if (threadIdx.x == 0) wg_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+  __syncthreads();
+  return wg_ticket;
+}
 
 // 64-bit {flag, value} granules of the decoupled look-back: one naturally aligned 8-byte agent-scope
 // store / load each, so the value and its flag can never be seen torn or out of order.

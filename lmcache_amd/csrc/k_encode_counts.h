@@ -515,10 +515,14 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
   // (lower positions of its own chunk) were then dispatched at least nchunks workgroups earlier and have normally
   // published their lengths by the time it looks back -- with chunk-major order they finish at the same moment
   // and every look-back waits for the slowest of them.
-  long long gid = (long long)blockIdx.x * ENC_WAVES + wave;
+  // ENCODE: the workgroup's work index is a ticket drawn at its start (EncodeArgs::ticket), so that the look-back
+  // below only ever waits for workgroups that are running already
+  u32 item = blockIdx.x;
+  if constexpr (ENCODE) item = (u32)__builtin_amdgcn_readfirstlane((int)draw_ticket(a.ticket, a.ticket_base));
+  long long gid = (long long)item * ENC_WAVES + wave;
   if (ENCODE && (a.P * a.G) % ENC_WAVES == 0) {
     const int wpc = a.P * a.G / ENC_WAVES;  // workgroups per chunk
-    const int ch = (int)(blockIdx.x % (unsigned)a.nchunks), pos = (int)(blockIdx.x / (unsigned)a.nchunks);
+    const int ch = (int)(item % (unsigned)a.nchunks), pos = (int)(item / (unsigned)a.nchunks);
     gid = ((long long)ch * wpc + pos) * ENC_WAVES + wave;
   }
   if (gid >= ngroups_total) return;

@@ -224,9 +224,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   __shared__ u32 wg_excl;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // consecutive workgroups take the same plane of consecutive chunks (see k_cdf_encode): a plane-chunk's
-  // predecessors in the look-back were dispatched at least nchunks workgroups earlier
-  const int chunk = (int)(blockIdx.x % (unsigned)a.nchunks), p = (int)(blockIdx.x / (unsigned)a.nchunks);
+  // consecutive work items are the same plane of consecutive chunks (see k_cdf_encode): a plane-chunk's predecessors
+  // in the look-back were taken at least nchunks workgroups earlier.  The item comes from a ticket, not from
+  // blockIdx (EncodeArgs::ticket): a predecessor's workgroup has started, whatever order the hardware dispatches in.
+  const u32 item = (u32)__builtin_amdgcn_readfirstlane((int)draw_ticket(a.ticket, a.ticket_base));
+  const int chunk = (int)(item % (unsigned)a.nchunks), p = (int)(item / (unsigned)a.nchunks);
   const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
   const int Tc = min(a.chunk_tokens, a.tok_end - tok0);
   u32* const hist = lds_all + NW * ENC_RING_DWORDS + wave * CNT_TAB_DWORDS;  // this wave's table slice ...
@@ -234,13 +236,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 
   rtab_to_lds(rtab_lds);  // visible to the coder waves behind the barrier that ends phase A
   // ---- phase A: quantise the plane-chunk ----------------------------------------------------------------
-  const bool head_start = blockIdx.x < fa.pre_limit && blockIdx.x % fa.pre_step == 0u;  // quantised by k_quantize already
+  const bool head_start = item < fa.pre_limit && item % fa.pre_step == 0u;  // quantised by k_quantize already
   if (!head_start) {
     const int bins = (int)a.bins.b[p];
     const float maxf = (float)(bins / 2 - 1);
     const bool nib = lmc_sym_nibbles(bins);
 #if LMC_EXP_TWICE & 32  // timing experiment: every workgroup of an XCD shares 4 symbol regions (stays in L2)
-    u32* const sym_pc = const_cast<u32*>(a.sym4) + (long long)(blockIdx.x % 32u) * a.TQ * a.C;
+    u32* const sym_pc = const_cast<u32*>(a.sym4) + (long long)(item % 32u) * a.TQ * a.C;
 #else
     u32* const sym_pc = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.TQ * a.C;
 #endif
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // ---- phase B: code this wave's group streams -----------------------------------------------------------
 #if LMC_EXP_TWICE & 32
   EncodeArgs a2 = a;
-  a2.sym4 = a.sym4 + ((long long)(blockIdx.x % 32u) - ((long long)chunk * a.P + p)) * a.TQ * a.C;
+  a2.sym4 = a.sym4 + ((long long)(item % 32u) - ((long long)chunk * a.P + p)) * a.TQ * a.C;
 #define LMC_FUSED_ENC_ARGS a2
 #else
 #define LMC_FUSED_ENC_ARGS a

@@ -16,6 +16,7 @@
 #include "k_decode.h"
 #include "k_encode_counts.h"
 #include "k_fused.h"
+#include "k_offload.h"
 #include "k_quantize.h"
 
 static thread_local int g_last_hip = 0;
@@ -44,6 +45,15 @@ struct lmc_ctx {
   int pre_step = 0;                     // fused encode: every pre_step-th workgroup of the first generation gets a head start
                                         // (0: none -- measured 1.06 ms without, 1.07-1.09 with 2 / 3 / 4: k_fused.h)
   u32 epoch = 0;                        // of the last fused launch (tags its look-back granules)
+  // store / load legs (lmc_store_chunks, lmc_load_chunks)
+  u8* store_arena = nullptr; size_t store_bytes = 0;  // blobs of the job being offloaded
+  u8* load_slots = nullptr; size_t load_bytes = 0;    // HBM slots the gather kernel fills
+  hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;  // the PCIe side of both legs (two DMA queues for the load)
+  hipEvent_t store_free = nullptr, load_free = nullptr;  // the arena / the slots may be reused behind these
+  bool store_used = false, load_used = false;
+  hipEvent_t evpool[64] = {}; int evnext = 0;         // fork / join events of the two legs (round robin)
+  u32* ticket = nullptr;                // device work-ticket counter of the coder launches (k_encode.h: EncodeArgs::ticket)
+  u32 tickets_drawn = 0;                // ... and how many tickets the launches so far have drawn (mod 2^32)
   u32* status_h = nullptr;  // pinned, device-accessible
   // optional per-kernel timing (lmc_ctx_profile)
   bool profile = false;
@@ -104,6 +114,14 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   if (c->sym4) (void)hipFree(c->sym4);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->agg) (void)hipFree(c->agg);
+  if (c->ticket) (void)hipFree(c->ticket);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  if (c->copy_stream2) { (void)hipStreamSynchronize(c->copy_stream2); (void)hipStreamDestroy(c->copy_stream2); }
+  if (c->store_arena) (void)hipFree(c->store_arena);
+  if (c->load_slots) (void)hipFree(c->load_slots);
+  if (c->store_free) (void)hipEventDestroy(c->store_free);
+  if (c->load_free) (void)hipEventDestroy(c->load_free);
+  for (int i = 0; i < 64; i++) if (c->evpool[i]) (void)hipEventDestroy(c->evpool[i]);
   if (c->ws_free) (void)hipEventDestroy(c->ws_free);
   for (int i = 0; i < 8; i++) if (c->pev[i]) (void)hipEventDestroy(c->pev[i]);
   if (c->status_h) (void)hipHostFree(c->status_h);
@@ -329,6 +347,12 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   ea.L = L; ea.H = H; ea.D = D; ea.dtype = src->dtype;
   u8* const scale_base = (u8*)blobs + hl.off_scales;  // off_scales does not depend on T
 
+  if (!c->ticket) {
+    HIP_TRY(hipMalloc((void**)&c->ticket, 64));
+    HIP_TRY(hipMemsetAsync(c->ticket, 0, 64, s));  // ordered in front of the first launch that draws from it
+    c->tickets_drawn = 0;
+  }
+  ea.ticket = c->ticket;
   c->pn = 0;
   // k_fused.h codes 256-token chunks (the counts model) of 256 < C <= 1024 channels (64-lane quantise tasks, G <= 16)
   const int nfull = (tok_end - tok_begin) / chunk_tokens;  // chunks of exactly chunk_tokens tokens; a ragged one may follow
@@ -362,7 +386,10 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     if ((r = launch_quant<true>(qa, s))) return r;
     if ((r = prof_mark(c, s))) return r;
     const long long ngroups = (long long)n * PG;
-    hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3((unsigned)((ngroups + ENC_WAVES - 1) / ENC_WAVES)), dim3(64 * ENC_WAVES), 0, s, e2);
+    const unsigned nwg = (unsigned)((ngroups + ENC_WAVES - 1) / ENC_WAVES);
+    e2.ticket_base = c->tickets_drawn;
+    c->tickets_drawn += nwg;
+    hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3(nwg), dim3(64 * ENC_WAVES), 0, s, e2);
     HIP_TRY(hipGetLastError());
     return prof_mark(c, s);
   };
@@ -378,6 +405,8 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     if (!c->epoch) c->epoch = 1u;
     fa.epoch = c->epoch;
     const dim3 grid((unsigned)((long long)nfull * P)), block(64 * FUSED_WAVES);
+    fa.e.ticket_base = c->tickets_drawn;
+    c->tickets_drawn += grid.x;
     if ((rc = prof_mark(c, s))) return rc;
     // head start (k_fused.h): with at least three generations of workgroups, every pre_step-th plane-chunk of the
     // first generation (4 workgroups per CU) is quantised by k_quantize in front of the fused launch
@@ -568,6 +597,172 @@ int lmc_event_query(lmc_event_t e) {
 int lmc_event_elapsed_ms(lmc_event_t a, lmc_event_t b, float* ms) {
   if (!ms) return LMC_ERR_INVALID;
   HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return LMC_OK;
+}
+
+// ---- store / load legs ------------------------------------------------------------------------------------
+int lmc_blob_info(const void* blob_h, size_t nbytes, lmc_blob_header* out);
+static int legs_init(lmc_ctx* c) {  // caller holds c->mu
+  if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->store_free) HIP_TRY(hipEventCreateWithFlags(&c->store_free, hipEventDisableTiming));
+  if (!c->load_free) HIP_TRY(hipEventCreateWithFlags(&c->load_free, hipEventDisableTiming));
+  return LMC_OK;
+}
+static int next_event(lmc_ctx* c, hipEvent_t* out) {  // caller holds c->mu; 64 events in rotation: a call uses <= 34
+  hipEvent_t& e = c->evpool[c->evnext];
+  c->evnext = (c->evnext + 1) % 64;
+  if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *out = e;
+  return LMC_OK;
+}
+
+int lmc_store_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
+                     const int32_t* bins_h, void* host_arena_h, uint64_t host_cap, uint64_t* offsets_h,
+                     uint32_t* sizes_h, uint32_t* job_status, lmc_stream_t stream) {
+  if (!c || !layout_ok(src) || tok_begin < 0 || tok_end <= tok_begin || chunk_tokens < 1 || chunk_tokens > 65535 ||
+      !host_arena_h || ((uintptr_t)host_arena_h & 15) || !offsets_h || !sizes_h)
+    return LMC_ERR_INVALID;
+  const int nchunks = (tok_end - tok_begin + chunk_tokens - 1) / chunk_tokens;
+  if (nchunks > 65535) return LMC_ERR_INVALID;
+  const uint64_t stride = (lmc_blob_bound((uint32_t)src->num_layers, (uint32_t)chunk_tokens, (uint32_t)src->num_heads,
+                                          (uint32_t)src->head_size) + 15) & ~(uint64_t)15;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if ((rc = legs_init(c))) return rc;
+    if (c->store_bytes < (size_t)nchunks * stride) {
+      if (c->store_used) HIP_TRY(hipEventSynchronize(c->store_free));  // growing frees the arena: this call only
+      if ((rc = ws_grow((void**)&c->store_arena, &c->store_bytes, (size_t)nchunks * stride))) return rc;
+    }
+    if (c->store_used) HIP_TRY(hipStreamWaitEvent(s, c->store_free, 0));  // the previous job's copies have read the arena
+  }
+  // a long job leaves in parts: the copy of part k runs on the context's copy stream beside the encode of part k + 1
+  const int nparts = nchunks >= 16 ? 4 : 1, per = (nchunks + nparts - 1) / nparts;
+  uint32_t* st = job_status ? job_status : c->status_h;
+  for (int c0 = 0; c0 < nchunks; c0 += per) {
+    const int c1 = c0 + per < nchunks ? c0 + per : nchunks;
+    const int t1 = tok_begin + c1 * chunk_tokens < tok_end ? tok_begin + c1 * chunk_tokens : tok_end;
+    if ((rc = lmc_encode_chunks(c, src, tok_begin + c0 * chunk_tokens, t1, chunk_tokens, bins_h, c->store_arena + (size_t)c0 * stride,
+                                stride, sizes_h + c0, job_status, stream)))
+      return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipEvent_t ev;
+    if ((rc = next_event(c, &ev))) return rc;
+    HIP_TRY(hipEventRecord(ev, s));
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, ev, 0));
+    OffloadArgs oa;
+    memset(&oa, 0, sizeof oa);
+    oa.blobs = c->store_arena; oa.stride = (long long)stride; oa.sizes_d = sizes_h; oa.nchunks = nchunks; oa.chunk0 = c0;
+    oa.host = (u8*)host_arena_h; oa.cap = host_cap; oa.offsets_h = (unsigned long long*)offsets_h; oa.sizes_h = sizes_h;
+    oa.status = st;
+    hipLaunchKernelGGL(k_offload, dim3(8, (unsigned)(c1 - c0)), dim3(256), 0, c->copy_stream, oa);
+    HIP_TRY(hipGetLastError());
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipEventRecord(c->store_free, c->copy_stream));
+  c->store_used = true;
+  HIP_TRY(hipStreamWaitEvent(s, c->store_free, 0));  // the caller's stream is done when the blobs have landed
+  return LMC_OK;
+}
+
+// Host-side view of a blob that lies in pinned host memory: checked header + section offsets (lmc_blob_info's
+// checks, without the copy-out).
+static bool host_blob_ok(const u8* b, uint32_t size, int L, int H, int D, uint32_t max_bytes, lmc_blob_header* h) {
+  if (size < sizeof(lmc_blob_header) || ((uintptr_t)b & 15)) return false;
+  memcpy(h, b, sizeof *h);
+  if (lmc_blob_info(b, size, h) != LMC_OK) return false;
+  return h->num_layers == (uint32_t)L && h->num_heads == (uint32_t)H && h->head_size == (uint32_t)D &&
+         h->total_bytes == size && h->total_bytes <= max_bytes;
+}
+
+int lmc_load_chunks(lmc_ctx* c, const void* const* host_blob_ptrs_h, const uint32_t* sizes_h, int32_t nchunks,
+                    const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, int32_t layers_per_range,
+                    lmc_event_t* range_events, uint32_t* job_status, lmc_stream_t stream) {
+  if (!c || !host_blob_ptrs_h || !sizes_h || nchunks < 1 || !layout_ok(dst) || chunk_tokens < 1 || layers_per_range < 0)
+    return LMC_ERR_INVALID;
+  const int L = dst->num_layers, H = dst->num_heads, D = dst->head_size, P = 2 * L, G = (H * D + 63) / 64;
+  if (H * D > LMC_MAX_CHANNELS) return LMC_ERR_INVALID;
+  const uint64_t stride = (lmc_blob_bound((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D) + 15) & ~(uint64_t)15;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  const int step = layers_per_range > 0 && layers_per_range < L ? layers_per_range : L;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if ((rc = legs_init(c))) return rc;
+  if (!c->copy_stream2) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
+  if (c->load_bytes < (size_t)nchunks * stride) {
+    if (c->load_used) HIP_TRY(hipEventSynchronize(c->load_free));
+    if ((rc = ws_grow((void**)&c->load_slots, &c->load_bytes, (size_t)nchunks * stride))) return rc;
+  }
+  hipStream_t cs[2] = {c->copy_stream, c->copy_stream2};  // two DMA queues (tools/probes/d2h_streams.py)
+  if (c->load_used) {  // the previous load's decodes have read the slots
+    HIP_TRY(hipStreamWaitEvent(cs[0], c->load_free, 0));
+    HIP_TRY(hipStreamWaitEvent(cs[1], c->load_free, 0));
+  }
+  // The blobs lie in pinned HOST memory: their headers, row prefixes and stream directories are read right here, by
+  // the CPU, and every contiguous run a layer range needs (lmc_format.h) becomes one hipMemcpyAsync -- no GPU work, no
+  // wait.  A blob that does not check out fails the call before anything is queued.
+  auto copy = [&](int q, size_t chunk, uint32_t lo, uint32_t hi) -> int {
+    lo &= ~15u;
+    hi = (hi + 15u) & ~15u;
+    if (hi <= lo) return LMC_OK;
+    const u8* src = (const u8*)host_blob_ptrs_h[chunk];
+    if (hi > sizes_h[chunk]) hi = sizes_h[chunk];
+    HIP_TRY(hipMemcpyAsync(c->load_slots + chunk * stride + lo, src + lo, hi - lo, hipMemcpyHostToDevice, cs[q]));
+    return LMC_OK;
+  };
+  for (int i = 0; i < nchunks; i++) {
+    lmc_blob_header h;
+    if (!host_blob_ok((const u8*)host_blob_ptrs_h[i], sizes_h[i], L, H, D, (uint32_t)(stride > 0xffffffffull ? 0xffffffffu : stride), &h))
+      return LMC_ERR_INVALID;
+    // everything but the streams first: header, bins, row prefix, scales, checksums, counts, stream directory (an
+    // eighth of the blob) -- the per-range copies below are the streams, one run per plane run
+    if ((rc = copy(i & 1, (size_t)i, 0u, h.off_streams))) return rc;
+  }
+  DecodeArgs da;
+  memset(&da, 0, sizeof da);
+  if ((rc = decode_common(c, c->load_slots, stride, nchunks, L, H, D, job_status, da))) return rc;
+  da.dst = to_addr(dst); da.dst_tok0 = dst_tok0; da.chunk_tokens = chunk_tokens;
+  int r = 0;
+  for (int l0 = 0; l0 < L; l0 += step, r++) {
+    const int n = l0 + step <= L ? step : L - l0;
+    for (int i = 0; i < nchunks; i++) {
+      const u8* b = (const u8*)host_blob_ptrs_h[i];
+      lmc_blob_header h;
+      memcpy(&h, b, sizeof h);
+      const uint32_t* gend = (const uint32_t*)(b + h.off_gend);
+      for (int kvh = 0; kvh < 2; kvh++) {  // the K planes of the layer range, then its V planes: one run each
+        const uint32_t g0 = (uint32_t)((kvh * L + l0) * G), g1 = (uint32_t)((kvh * L + l0 + n) * G);
+        const uint32_t s0 = g0 ? lmc_r16(gend[g0 - 1]) : 0u, s1 = gend[g1 - 1];
+        if (s1 < s0 || (uint64_t)h.off_streams + s1 > h.total_bytes) return LMC_ERR_INVALID;
+        if ((rc = copy((i + kvh) & 1, (size_t)i, h.off_streams + s0, h.off_streams + s1))) return rc;
+      }
+    }
+    for (int q = 0; q < 2; q++) {  // the decode of the range waits for both queues
+      hipEvent_t ev;
+      if ((rc = next_event(c, &ev))) return rc;
+      HIP_TRY(hipEventRecord(ev, cs[q]));
+      HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+    }
+    da.layer_begin = l0; da.layer_count = n;
+    const long long nstreams = (long long)nchunks * 2 * n * da.G;
+    const dim3 grid((unsigned)((nstreams + 3) / 4));
+    const bool paged = dst->slot_mapping != nullptr;
+    if (dst->dtype == LMC_DTYPE_BF16) {
+      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, true>), grid, dim3(256), 0, s, da);
+      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, false>), grid, dim3(256), 0, s, da);
+    } else {
+      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, true>), grid, dim3(256), 0, s, da);
+      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, false>), grid, dim3(256), 0, s, da);
+    }
+    HIP_TRY(hipGetLastError());
+    if (range_events && range_events[r]) HIP_TRY(hipEventRecord((hipEvent_t)range_events[r], s));
+  }
+  HIP_TRY(hipEventRecord(c->load_free, s));
+  c->load_used = true;
+  (void)P;
   return LMC_OK;
 }
 

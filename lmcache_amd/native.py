@@ -82,6 +82,8 @@ SYMBOLS = {
     "lmc_decode_chunks": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _vp, _vp]),
     "lmc_decode_chunks_layers": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _i32, _i32, _vp, _vp]),
     "lmc_decode_symbols": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "lmc_store_chunks": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
+    "lmc_load_chunks": (ctypes.c_int, [_vp, _vp, _vp, _i32, _PL, _i32, _i32, _i32, _vp, _vp, _vp]),
     "lmc_copy_kv": (ctypes.c_int, [_vp, _PL, _i32, _i32, _PL, _i32, _vp]),
     "lmc_pinned_alloc": (ctypes.c_int, [_sz, ctypes.POINTER(_vp)]),
     "lmc_pinned_free": (ctypes.c_int, [_vp]),
@@ -122,7 +124,7 @@ def lib() -> ctypes.CDLL:
             for name, (res, args) in SYMBOLS.items():
                 fn = getattr(L, name)  # AttributeError if the ABI and this binding drift apart
                 fn.restype, fn.argtypes = res, args
-            if L.lmc_abi_version() != 3:
+            if L.lmc_abi_version() != 4:
                 raise NativeError("liblmc_hip.so ABI version mismatch; rebuild")
             _lib = L
     return _lib
@@ -384,6 +386,33 @@ class PinnedBuffer:
             pass
 
 
+class NativeEvent:
+    """A hipEvent_t of the C ABI (lmc_event_*): what lmc_load_chunks records behind every range of layers.  Has the
+    two methods the Python side needs of an event: synchronize() (host) and wait(stream) (stream-side)."""
+
+    def __init__(self, timing: bool = False):
+        h = ctypes.c_void_p()
+        check(lib().lmc_event_create(ctypes.byref(h), 1 if timing else 0), "lmc_event_create")
+        self.handle = h
+
+    def synchronize(self) -> None:
+        check(lib().lmc_event_synchronize(self.handle), "lmc_event_synchronize")
+
+    def wait(self, stream_ptr: int) -> None:
+        check(lib().lmc_stream_wait_event(stream_ptr, self.handle), "lmc_stream_wait_event")
+
+    def query(self) -> bool:
+        return lib().lmc_event_query(self.handle) == 1
+
+    def __del__(self):
+        try:
+            if self.handle and not sys.is_finalizing():
+                lib().lmc_event_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class Context:
     """Owner of one lmc_ctx (per device).  Thread-safe: the C side serialises workspace use."""
 
@@ -485,6 +514,25 @@ class Context:
                                              dst_tok0, chunk_tokens, layer_begin, layer_count, status_ptr, st),
               "lmc_decode_chunks_layers")
 
+    def store_chunks(self, src: KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int, bins, host_arena_ptr: int,
+                     host_cap: int, offsets_ptr: int, sizes_ptr: int, stream: Optional[int] = None,
+                     status_ptr: Optional[int] = None) -> int:
+        """lmc_store_chunks: encode + exact-size copies into a pinned arena, no host wait.  offsets_ptr / sizes_ptr:
+        pinned uint64 [n + 1] / uint32 [n], valid once `stream` has completed."""
+        b = self._bins(bins)
+        st = current_stream_ptr(src.device) if stream is None else stream
+        check(lib().lmc_store_chunks(self.handle, ctypes.byref(src.struct), tok_begin, tok_end, chunk_tokens, b,
+                                     host_arena_ptr, host_cap, offsets_ptr, sizes_ptr, status_ptr, st), "lmc_store_chunks")
+        return (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
+
+    def load_chunks(self, host_ptrs_ptr: int, sizes_ptr: int, nchunks: int, dst: KVLayout, dst_tok0: int,
+                    chunk_tokens: int, layers_per_range: int = 0, range_events_ptr: Optional[int] = None,
+                    stream: Optional[int] = None, status_ptr: Optional[int] = None) -> None:
+        """lmc_load_chunks: blobs in pinned host memory -> decoded KV, gathered and decoded layer range by layer range."""
+        st = current_stream_ptr(dst.device) if stream is None else stream
+        check(lib().lmc_load_chunks(self.handle, host_ptrs_ptr, sizes_ptr, nchunks, ctypes.byref(dst.struct), dst_tok0,
+                                    chunk_tokens, layers_per_range, range_events_ptr, status_ptr, st), "lmc_load_chunks")
+
     def decode_symbols(self, blob: torch.Tensor, L: int, H: int, D: int, T: int, stream: Optional[int] = None
                        ) -> torch.Tensor:
         sym = torch.empty((2 * L, T, H * D), dtype=torch.int8, device=blob.device)
@@ -501,35 +549,44 @@ class Context:
 
 
 def describe_status(st: int) -> str:
-    names = [(1, "stream overflow"), (2, "bad blob header"), (4, "bad stream"), (8, "look-back timeout"), (16, "scale checksum mismatch")]
+    names = [(1, "stream overflow"), (2, "bad blob header"), (4, "bad stream"), (8, "look-back timeout"), (16, "scale checksum mismatch"),
+             (32, "host arena full")]
     return f"device status 0x{st:x} (" + ", ".join(n for b, n in names if st & b) + ")"
 
 
 class StatusWords:
     """Pool of pinned uint32 words a job's kernels report their LMC_STATUS_* bits into (one word per job, so
-    concurrent jobs never see each other's failures)."""
+    concurrent jobs never see each other's failures).  The pool grows by a block when every word is out: a caller
+    that forgets jobs (their words come back when the job objects are collected) never breaks the cache."""
+    BLOCK = 256
 
     def __init__(self, n: int = 256):
-        self._buf = PinnedBuffer(4 * n)
-        self._view = self._buf.tensor.view(torch.int32)
-        self._free = list(range(n))
+        self._blocks = []   # (PinnedBuffer, int32 view); word i lives in block i // BLOCK
+        self._free = []
         self._lock = threading.Lock()
+        self._grow()
+
+    def _grow(self) -> None:
+        buf = PinnedBuffer(4 * self.BLOCK)
+        base = len(self._blocks) * self.BLOCK
+        self._blocks.append((buf, buf.tensor.view(torch.int32)))
+        self._free.extend(range(base + self.BLOCK - 1, base - 1, -1))
 
     def acquire(self) -> int:
         with self._lock:
             if not self._free:
-                raise NativeError("more than 256 jobs in flight with unread status words")
+                self._grow()
             i = self._free.pop()
-        self._view[i] = 0
+            self._blocks[i // self.BLOCK][1][i % self.BLOCK] = 0
         return i
 
     def ptr(self, i: int) -> int:
-        return self._buf.ptr + 4 * i
+        return self._blocks[i // self.BLOCK][0].ptr + 4 * (i % self.BLOCK)
 
     def read_release(self, i: int) -> int:
         """Value of word i (the job's work must have completed) and return it to the pool."""
-        v = int(self._view[i]) & 0xffffffff
         with self._lock:
+            v = int(self._blocks[i // self.BLOCK][1][i % self.BLOCK]) & 0xffffffff
             self._free.append(i)
         return v
 

@@ -15,9 +15,20 @@ MI355X-native form -- no server process, no peer Python in the data path:
   * `set` of a key owned by rank o is a copy INTO o's arena (a peer write over xGMI), `get` a copy OUT of it
     (a peer read): hipMemcpy between mapped device pointers, the owner's process does not take part;
   * the control plane is a fixed-size directory in POSIX shared memory (/dev/shm/lmc_xgmi_<name>.dir):
-    key -> (owner, offset, size), open addressing on sha256(key), mutations under flock; a record is the
-    counterpart of the reference's 158-byte ClientMetaMessage (lmcache/protocol.py:45-47) -- no pickled
-    Python objects anywhere;
+    key -> (owner, offset, size, arena generation), open addressing on sha256(key), mutations under flock; a
+    record is the counterpart of the reference's 158-byte ClientMetaMessage (lmcache/protocol.py:45-47).  An
+    arena is exported as a fixed-layout binary record of its IPC handles (no pickled Python objects anywhere:
+    a peer parses bytes, it never executes what it reads), in a file created 0600 / O_EXCL / O_NOFOLLOW whose
+    owner is checked before it is read;
+  * the directory outlives processes, the arenas do not: every arena carries a GENERATION.  A rank that creates
+    a new arena bumps its generation in the directory header, resets its bump pointer and retires every record
+    it owned; records carry the generation of the arena their bytes live in, and a peer that meets a newer
+    generation than the mapping it holds maps the new export -- a restarted rank (or a whole restarted job on a
+    stale /dev/shm) never serves bytes of an arena that is gone;
+  * live bytes are never overwritten: `set` of a key that is present copies into a FRESH extent of the owner's
+    arena and flips the record to it when the bytes have landed (a reader that looked the key up before keeps
+    reading the old extent, which nobody touches); a second writer of a key whose first writer has not
+    published yet is a no-op (keys are content hashes, cache_engine.py:58-96: the bytes would be the same);
   * `set_device` / `get_device` / `peek` are the zero-host-hop forms LMCPipelinedRemoteBackend uses when the
     connector has them: blobs go from the encode arena to the owner's HBM and from there to the decode arena
     without touching host memory (the bytes methods of the interface bounce through the host by definition).
@@ -31,7 +42,7 @@ import fcntl
 import hashlib
 import mmap
 import os
-import pickle
+import stat
 import struct
 import time
 from typing import Dict, List, Optional, Tuple
@@ -44,14 +55,54 @@ from lmcache_amd.storage_backend.connector.base_connector import RemoteConnector
 
 logger = init_logger(__name__)
 
-_MAGIC = 0x494D4758  # "XGMI"
+_MAGIC = 0x32494D58  # "XMI2": directory layout 2 (per-rank generations; records carry one)
 _HDR = struct.Struct("<IIIIQ")        # magic, world, nslots, record bytes, arena bytes per rank
 _HDR_BYTES = 64
-_REC = struct.Struct("<IIQQQI")       # state, owner, offset, size, capacity, key length   (+ key bytes)
-_REC_BYTES = 256                      # one directory record: 36 B of fields + up to 220 B of key
+_MAX_RANKS = 64
+_USED_OFF = _HDR_BYTES                # u64 [64]: bump pointer of every rank's arena
+_GEN_OFF = _HDR_BYTES + 8 * _MAX_RANKS  # u64 [64]: generation of every rank's arena (0 = never created)
+_RECS_OFF = _HDR_BYTES + 16 * _MAX_RANKS
+_REC = struct.Struct("<IIQQQII")      # state, owner, offset, size, capacity, key length, arena generation  (+ key bytes)
+_REC_BYTES = 256                      # one directory record: 40 B of fields + up to 216 B of key
 _KEY_MAX = _REC_BYTES - _REC.size
-_EMPTY, _FULL = 0, 1
+_EMPTY, _FULL, _DEAD = 0, 1, 2        # _DEAD: a retired record (its arena is gone); probing walks past it
 SHM_DIR = "/dev/shm"
+
+# export record of a CUDA arena: magic, version, generation, device, storage bytes, storage offset, ref-counter
+# offset, event-sync flag, lengths of the three handle blobs that follow (what torch's _share_cuda_ returns)
+_XIPC_MAGIC = 0x43504958  # "XIPC"
+_XIPC = struct.Struct("<IIQiIQQQBxHHH")
+_XIPC_MAX_BLOB = 256
+
+
+def _write_private(path: str, data: bytes) -> None:
+    """Create `path` atomically with mode 0600; refuses to follow links or reuse somebody else's temp file."""
+    tmp = f"{path}.tmp{os.getpid()}"
+    try:
+        os.unlink(tmp)
+    except OSError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+    try:
+        os.write(fd, data)
+    finally:
+        os.close(fd)
+    os.replace(tmp, path)
+
+
+def _read_private(path: str, max_bytes: int) -> Optional[bytes]:
+    """Contents of a regular file that belongs to this user, or None."""
+    try:
+        fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+    except OSError:
+        return None
+    try:
+        st = os.fstat(fd)
+        if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or st.st_size > max_bytes:
+            raise PermissionError(f"{path}: not a private regular file of this user")
+        return os.read(fd, max_bytes)
+    finally:
+        os.close(fd)
 
 
 def _r256(n: int) -> int:
@@ -78,38 +129,62 @@ class XgmiConnector(RemoteConnector):
             arena_bytes = int(os.environ.get("LMC_XGMI_ARENA_MB", "4096" if self.device.type == "cuda" else "64")) << 20
         self._base = os.path.join(SHM_DIR, f"lmc_xgmi_{name}")
         self._peers: Dict[int, torch.Tensor] = {}
+        self._peer_gen: Dict[int, int] = {}   # generation of the mapping held in _peers
         self._keep = []
         # ---- directory (created by whoever comes first, under the lock of a sidecar file) -------------------
         self._lockf = open(self._base + ".lock", "a+b")
         with self._locked():
             path = self._base + ".dir"
             fresh = not os.path.exists(path) or os.path.getsize(path) == 0
+            if not fresh:  # a directory of an older layout (a stale /dev/shm) is replaced, never interpreted
+                with open(path, "rb") as f:
+                    head = f.read(_HDR.size)
+                fresh = len(head) < _HDR.size or _HDR.unpack(head)[0] != _MAGIC
             if fresh:
-                with open(path, "wb") as f:
-                    f.truncate(_HDR_BYTES + 8 * 64 + nslots * _REC_BYTES)
+                fd = os.open(path + ".new", os.O_WRONLY | os.O_CREAT | os.O_TRUNC | os.O_NOFOLLOW, 0o600)
+                with os.fdopen(fd, "wb") as f:
+                    f.truncate(_RECS_OFF + nslots * _REC_BYTES)
                     f.seek(0)
                     f.write(_HDR.pack(_MAGIC, self.world, nslots, _REC_BYTES, arena_bytes))
+                os.replace(path + ".new", path)
             self._dirf = open(path, "r+b")
             self._dir = mmap.mmap(self._dirf.fileno(), 0)
             magic, w, self.nslots, rec, self.arena_bytes = _HDR.unpack_from(self._dir, 0)
-            if magic != _MAGIC or w != self.world or rec != _REC_BYTES:
+            if magic != _MAGIC or w != self.world or rec != _REC_BYTES or self.world > _MAX_RANKS:
                 raise ValueError(f"xgmi://{name}: directory belongs to another world ({w} ranks) or version")
         # ---- this rank's arena -------------------------------------------------------------------------------
         own = _OWN_ARENAS.get((name, self.rank))
         if own is not None:
             own[1] += 1
             self._peers[self.rank] = own[0]
+            self._peer_gen[self.rank] = own[2]
             self._closed = False
             return
+        # a NEW arena: the directory may still describe an older one of this rank (a restart): next generation, bump
+        # pointer back to zero, every record this rank owned retired -- before the export becomes visible
+        with self._locked():
+            gen = struct.unpack_from("<Q", self._dir, _GEN_OFF + 8 * self.rank)[0] + 1
+            struct.pack_into("<Q", self._dir, _GEN_OFF + 8 * self.rank, gen)
+            struct.pack_into("<Q", self._dir, _USED_OFF + 8 * self.rank, 0)
+            for slot in range(self.nslots):
+                off = self._rec_off(slot)
+                state, owner = struct.unpack_from("<II", self._dir, off)
+                if state == _FULL and owner == self.rank:
+                    struct.pack_into("<I", self._dir, off, _DEAD)
         if self.device.type == "cuda":
             arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=self.device)
-            from torch.multiprocessing.reductions import reduce_tensor
-            with open(self._arena_path(self.rank) + ".tmp", "wb") as f:
-                pickle.dump(reduce_tensor(arena), f)
-            os.replace(self._arena_path(self.rank) + ".tmp", self._arena_path(self.rank))
+            (dev_index, handle, nbytes, offset, ref_handle, ref_offset, ev_handle, ev_sync) = \
+                arena.untyped_storage()._share_cuda_()
+            blobs = [bytes(handle), bytes(ref_handle), bytes(ev_handle or b"")]
+            if any(len(b) > _XIPC_MAX_BLOB for b in blobs):
+                raise RuntimeError("xgmi://: an IPC handle is longer than the export record allows")
+            rec = _XIPC.pack(_XIPC_MAGIC, 1, gen, int(dev_index), 0, int(nbytes), int(offset), int(ref_offset),
+                             1 if ev_sync else 0, *(len(b) for b in blobs)) + b"".join(blobs)
+            _write_private(self._arena_path(self.rank), rec)
         else:
-            path = self._arena_path(self.rank)
-            with open(path + ".tmp", "wb") as f:
+            path = self._arena_path(self.rank) + f".g{gen}"  # one file per generation: an old mapping stays what it was
+            fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_TRUNC | os.O_NOFOLLOW, 0o600)
+            with os.fdopen(fd, "wb") as f:
                 f.truncate(self.arena_bytes)
             os.replace(path + ".tmp", path)  # peers only ever see a fully sized file
             f = open(path, "r+b")
@@ -117,7 +192,8 @@ class XgmiConnector(RemoteConnector):
             self._keep += [f, mm]
             arena = torch.frombuffer(mm, dtype=torch.uint8)
         self._peers[self.rank] = arena
-        _OWN_ARENAS[(name, self.rank)] = [arena, 1]
+        self._peer_gen[self.rank] = gen
+        _OWN_ARENAS[(name, self.rank)] = [arena, 1, gen]
         self._closed = False
 
     # ------------------------------------------------------------------ plumbing
@@ -137,28 +213,51 @@ class XgmiConnector(RemoteConnector):
     def _locked(self):
         return XgmiConnector._Lock(self._lockf)
 
-    def _arena(self, r: int) -> torch.Tensor:
-        """Rank r's arena as a tensor this process can address (mapped on first use)."""
+    def _arena(self, r: int, gen: int) -> torch.Tensor:
+        """Generation `gen` of rank r's arena as a tensor this process can address (mapped on first use, mapped
+        again when the rank has created a newer arena since)."""
         a = self._peers.get(r)
-        if a is not None:
+        if a is not None and self._peer_gen.get(r) == gen:
             return a
-        path = self._arena_path(r)
         deadline = time.time() + 30.0
-        while not os.path.exists(path):  # the peer has not exported its arena yet
+        while True:
+            a = self._map_arena(r, gen)
+            if a is not None:
+                break
             if time.time() > deadline:
-                raise RuntimeError(f"xgmi://{self.name}: rank {r} never exported its arena")
+                raise RuntimeError(f"xgmi://{self.name}: rank {r} never exported generation {gen} of its arena")
             time.sleep(0.01)
-        if self.device.type == "cuda":
-            with open(path, "rb") as f:
-                fn, args = pickle.load(f)
-            a = fn(*args)  # HIP IPC: the peer's device memory, addressable from this process
-        else:
+        self._peers[r] = a
+        self._peer_gen[r] = gen
+        return a
+
+    def _map_arena(self, r: int, gen: int) -> Optional[torch.Tensor]:
+        if self.device.type != "cuda":
+            path = self._arena_path(r) + f".g{gen}"
+            if not os.path.exists(path):
+                return None
             f = open(path, "r+b")
             mm = mmap.mmap(f.fileno(), 0)
             self._keep += [f, mm]
-            a = torch.frombuffer(mm, dtype=torch.uint8)
-        self._peers[r] = a
-        return a
+            return torch.frombuffer(mm, dtype=torch.uint8)
+        raw = _read_private(self._arena_path(r), _XIPC.size + 3 * _XIPC_MAX_BLOB)
+        if raw is None or len(raw) < _XIPC.size:
+            return None
+        magic, ver, fgen, dev_index, _, nbytes, offset, ref_offset, ev_sync, l0, l1, l2 = _XIPC.unpack_from(raw, 0)
+        if magic != _XIPC_MAGIC or ver != 1 or max(l0, l1, l2) > _XIPC_MAX_BLOB or len(raw) != _XIPC.size + l0 + l1 + l2:
+            raise RuntimeError(f"xgmi://{self.name}: malformed arena export of rank {r}")
+        if fgen != gen:
+            return None  # the export of another generation: the rank is about to publish the one asked for
+        if nbytes < self.arena_bytes or not (0 <= dev_index < torch.cuda.device_count()):
+            raise RuntimeError(f"xgmi://{self.name}: arena export of rank {r} does not describe this store")
+        p = _XIPC.size
+        handle, ref_handle, ev_handle = raw[p:p + l0], raw[p + l0:p + l0 + l1], raw[p + l0 + l1:p + l0 + l1 + l2]
+        # HIP IPC: the peer's device memory, addressable from this process (torch's CUDA-IPC storage, opened from
+        # plain bytes -- the counterpart of rebuild_cuda_tensor without unpickling anything)
+        torch.cuda._lazy_init()
+        storage = torch.UntypedStorage._new_shared_cuda(dev_index, handle, nbytes, offset, ref_handle, ref_offset,
+                                                        ev_handle, bool(ev_sync))
+        return torch.empty(0, dtype=torch.uint8, device=f"cuda:{dev_index}").set_(storage, 0, (self.arena_bytes,), (1,))
 
     def _slot_of(self, key: str) -> Tuple[int, bytes]:
         kb = key.encode("utf-8")
@@ -167,55 +266,60 @@ class XgmiConnector(RemoteConnector):
         return int.from_bytes(hashlib.sha256(kb).digest()[8:16], "little") % self.nslots, kb
 
     def _rec_off(self, slot: int) -> int:
-        return _HDR_BYTES + 8 * 64 + slot * _REC_BYTES
+        return _RECS_OFF + slot * _REC_BYTES
 
     def _find(self, key: str) -> Tuple[Optional[tuple], int]:
         """(record fields or None, slot index where the key is / would go).  Caller holds the lock."""
         slot, kb = self._slot_of(key)
         for _ in range(self.nslots):
             off = self._rec_off(slot)
-            state, owner, offset, size, cap, klen = _REC.unpack_from(self._dir, off)
+            state, owner, offset, size, cap, klen, gen = _REC.unpack_from(self._dir, off)
             if state == _EMPTY:
                 return None, slot
-            if klen == len(kb) and self._dir[off + _REC.size:off + _REC.size + klen] == kb:
-                return (owner, offset, size, cap), slot
+            if state == _FULL and klen == len(kb) and self._dir[off + _REC.size:off + _REC.size + klen] == kb:
+                return (owner, offset, size, cap, gen), slot
             slot = (slot + 1) % self.nslots
         raise RuntimeError(f"xgmi://{self.name}: directory full ({self.nslots} keys)")
 
-    def _reserve(self, key: str, nbytes: int) -> Tuple[int, int, int]:
-        """Directory entry for `key` with room for nbytes -> (owner, offset, slot); the record is published
-        (state FULL, size) by _publish once the bytes are in place.  Caller holds the lock."""
+    def _reserve(self, key: str, nbytes: int) -> Optional[Tuple[int, int, int, int, int]]:
+        """A fresh extent of nbytes for `key` -> (owner, offset, slot, generation, capacity); the record points to it
+        (and the key becomes visible, or its new bytes do) with _publish once the bytes are in place.  None when
+        another writer holds the key unpublished.  Caller holds the lock."""
         rec, slot = self._find(key)
-        if rec is not None and rec[3] >= nbytes:  # overwrite in place: a miss until the new bytes are published
-            off = self._rec_off(slot)
-            _REC.pack_into(self._dir, off, _FULL, rec[0], rec[1], 0, rec[3], len(key.encode("utf-8")))
-            return rec[0], rec[1], slot
-        owner = owner_rank(key, self.world)
-        boff = _HDR_BYTES + 8 * owner
+        if rec is not None and rec[2] == 0:
+            return None  # being written right now
+        owner = owner_rank(key, self.world) if rec is None else rec[0]
+        gen = struct.unpack_from("<Q", self._dir, _GEN_OFF + 8 * owner)[0]
+        if gen == 0:
+            raise LookupError(owner)  # the owner has not created its arena yet: set_device waits for it
+        boff = _USED_OFF + 8 * owner
         (used,) = struct.unpack_from("<Q", self._dir, boff)
         cap = _r256(max(nbytes, 1))
         if used + cap > self.arena_bytes:
             raise RuntimeError(f"xgmi://{self.name}: the arena of rank {owner} is full ({self.arena_bytes >> 20} MiB; "
                                f"LMC_XGMI_ARENA_MB sizes it)")
         struct.pack_into("<Q", self._dir, boff, used + cap)
-        kb = key.encode("utf-8")
-        off = self._rec_off(slot)
-        # the key takes its slot now (size 0 reads as a miss) and becomes visible with _publish
-        self._dir[off + _REC.size:off + _REC.size + len(kb)] = kb
-        _REC.pack_into(self._dir, off, _FULL, owner, used, 0, cap, len(kb))
-        return owner, used, slot
+        if rec is None:  # a new key takes its slot now (size 0 reads as a miss)
+            kb = key.encode("utf-8")
+            off = self._rec_off(slot)
+            self._dir[off + _REC.size:off + _REC.size + len(kb)] = kb
+            _REC.pack_into(self._dir, off, _FULL, owner, used, 0, cap, len(kb), gen & 0xffffffff)
+        return owner, used, slot, gen, cap
 
-    def _publish(self, slot: int, nbytes: int) -> None:
+    def _publish(self, slot: int, offset: int, nbytes: int, cap: int, gen: int) -> None:
         off = self._rec_off(slot)
-        _, owner, offset, _, cap, klen = _REC.unpack_from(self._dir, off)
-        _REC.pack_into(self._dir, off, _FULL, owner, offset, nbytes, cap, klen)
+        _, owner, _, _, _, klen, _ = _REC.unpack_from(self._dir, off)
+        _REC.pack_into(self._dir, off, _FULL, owner, offset, nbytes, cap, klen, gen & 0xffffffff)
 
     def _lookup(self, key: str) -> Optional[tuple]:
         with self._locked():
             rec, _ = self._find(key)
         if rec is None or rec[2] == 0:
             return None
-        return rec
+        # a record of an arena generation that is gone (its owner restarted and has not retired it yet) is a miss
+        with self._locked():
+            cur = struct.unpack_from("<Q", self._dir, _GEN_OFF + 8 * rec[0])[0] & 0xffffffff
+        return rec if rec[4] == cur else None
 
     # ------------------------------------------------------------------ RemoteConnector
     def exists(self, key: str) -> bool:
@@ -229,15 +333,15 @@ class XgmiConnector(RemoteConnector):
         rec = self._lookup(key)
         if rec is None:
             return None
-        owner, offset, size, _ = rec
-        return self._arena(owner)[offset:offset + size].cpu().numpy().tobytes()
+        owner, offset, size, _, gen = rec
+        return self._arena(owner, gen)[offset:offset + size].cpu().numpy().tobytes()
 
     def list(self) -> List[str]:
         out = []
         with self._locked():
             for slot in range(self.nslots):
                 off = self._rec_off(slot)
-                state, _, _, size, _, klen = _REC.unpack_from(self._dir, off)
+                state, _, _, size, _, klen, _ = _REC.unpack_from(self._dir, off)
                 if state == _FULL and size:
                     out.append(bytes(self._dir[off + _REC.size:off + _REC.size + klen]).decode("utf-8"))
         return out
@@ -252,6 +356,7 @@ class XgmiConnector(RemoteConnector):
             if own[1] <= 0:
                 del _OWN_ARENAS[(self.name, self.rank)]
         self._peers.clear()
+        self._peer_gen.clear()
         try:
             self._dir.close()
             self._dirf.close()
@@ -267,7 +372,11 @@ class XgmiConnector(RemoteConnector):
 
     def unlink(self) -> None:
         """Remove the shared files of this store (the last user of a name calls it; mapped segments stay valid)."""
-        for p in [self._base + ".dir", self._base + ".lock"] + [self._arena_path(r) for r in range(self.world)]:
+        import glob
+        paths = [self._base + ".dir", self._base + ".lock"]
+        for r in range(self.world):
+            paths += [self._arena_path(r)] + glob.glob(self._arena_path(r) + ".g*")
+        for p in paths:
             try:
                 os.unlink(p)
             except OSError:
@@ -279,16 +388,27 @@ class XgmiConnector(RemoteConnector):
         owner is another GPU -- and the directory entry is published once the bytes have landed."""
         blob = blob.reshape(-1)
         n = blob.numel()
-        with self._locked():
-            owner, offset, slot = self._reserve(key, n)
-        dst = self._arena(owner)[offset:offset + n]
+        deadline = time.time() + 30.0
+        while True:
+            try:
+                with self._locked():
+                    res = self._reserve(key, n)
+                break
+            except LookupError as e:  # a peer that is still starting up
+                if time.time() > deadline:
+                    raise RuntimeError(f"xgmi://{self.name}: rank {e.args[0]} never created its arena")
+                time.sleep(0.01)
+        if res is None:
+            return  # another rank is writing this key right now: keys are content hashes, the bytes would be the same
+        owner, offset, slot, gen, cap = res
+        dst = self._arena(owner, gen)[offset:offset + n]
         dst.copy_(blob)
         if dst.is_cuda:  # the bytes must have landed before the entry becomes visible to the other ranks
             torch.cuda.current_stream(self.device).synchronize()
             if dst.device != self.device:
                 torch.cuda.current_stream(dst.device).synchronize()
         with self._locked():
-            self._publish(slot, n)
+            self._publish(slot, offset, n, cap, gen)
 
     def get_device(self, key: str) -> Optional[torch.Tensor]:
         """The blob as a uint8 tensor on THIS rank's device: a view of the own arena, or a copy out of the
@@ -296,8 +416,8 @@ class XgmiConnector(RemoteConnector):
         rec = self._lookup(key)
         if rec is None:
             return None
-        owner, offset, size, _ = rec
-        src = self._arena(owner)[offset:offset + size]
+        owner, offset, size, _, gen = rec
+        src = self._arena(owner, gen)[offset:offset + size]
         if owner == self.rank:
             return src
         out = torch.empty(size, dtype=torch.uint8, device=self.device)
@@ -309,6 +429,6 @@ class XgmiConnector(RemoteConnector):
         rec = self._lookup(key)
         if rec is None:
             return None
-        owner, offset, size, _ = rec
+        owner, offset, size, _, gen = rec
         n = min(nbytes, size)
-        return self._arena(owner)[offset:offset + n].cpu().numpy().tobytes(), size
+        return self._arena(owner, gen)[offset:offset + n].cpu().numpy().tobytes(), size

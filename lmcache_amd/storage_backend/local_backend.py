@@ -345,6 +345,13 @@ class LMCLocalBackend(LMCBackendInterface):
             return len(entries)
         if self.mode == "cachegen":
             codec = self._codec()
+            if layers_per_launch and jobs_out is not None:
+                # pinned tier cut by layers (engine.retrieve_layerwise): one lmc_load_chunks call gathers and decodes
+                # range after range; the caller's layers wait for their range's event only
+                with torch.cuda.device(dev):
+                    job = codec.decode_host_layerwise([e.blob for e in entries], dst, dst_tok0, chunk_tokens, layers_per_launch)
+                jobs_out.append((codec, job))
+                return len(entries)
             with torch.cuda.device(dev):
                 job = codec.decode([e.blob for e in entries], dst, dst_tok0, chunk_tokens)
             codec.finish_decode(job)  # this decode's event, then its own status word

@@ -104,6 +104,11 @@ class EncodeJob:
     # host-DRAM offload of range r can start while range r+1 is still being encoded: (chunk0, chunk1, event)
     parts: Optional[list] = None
     offload_issued: bool = False  # its device -> host copies are on the copy streams (the arena may be reused after them)
+    pool: Optional[native.StatusWords] = None  # where status_idx goes back to if nobody reads it (see __del__)
+
+    def __del__(self):  # a job dropped unread (an exception between launch and completion): its status word returns
+        if _return_status_word is not None:  # (module globals are gone at interpreter shutdown)
+            _return_status_word(self)
 
 
 def layer_ranges(L: int, layers_per_launch) -> list:
@@ -129,6 +134,27 @@ class DecodeJob:
     done: torch.cuda.Event
     status_idx: int
     layer_events: Optional[list] = None
+    pool: Optional[native.StatusWords] = None
+
+    def __del__(self):  # a DecodeJob / LayerwiseRetrieval nobody finished
+        if _return_status_word is not None:
+            _return_status_word(self)
+
+
+def _return_status_word(job) -> None:
+    """Give an unread status word back to its pool once the job's kernels can no longer write it."""
+    idx, pool = getattr(job, "status_idx", -1), getattr(job, "pool", None)
+    if pool is None or idx is None or idx < 0:
+        return
+    try:
+        job.done.synchronize()
+    except Exception:
+        pass
+    try:
+        pool.read_release(idx)
+    except Exception:
+        pass
+    job.status_idx = -1
 
 
 class DeviceArena:
@@ -173,6 +199,7 @@ class CacheGenDeviceCodec:
         self._enc_arena: Optional[torch.Tensor] = None
         self._dec_arena: Optional[torch.Tensor] = None
         self._size_pool: List[native.PinnedBuffer] = []      # pinned size words, one buffer per job in flight
+        self._meta_pool: List[native.PinnedBuffer] = []      # pinned pointer / size arrays of decode_host_layerwise jobs
         self._status = native.StatusWords()                  # one status word per job in flight
         self._arena_free: Optional[torch.cuda.Event] = None  # D2H of the last job that used the shared arena done
         self._dec_free: Optional[torch.cuda.Event] = None    # previous decode kernel done
@@ -212,24 +239,38 @@ class CacheGenDeviceCodec:
                     sizes = native.PinnedBuffer(4 * max(n, 256))
                 st = self._status.acquire()
                 cur = torch.cuda.current_stream(self.device)
-                if arena is self._enc_arena and self._arena_free is not None:
-                    cur.wait_event(self._arena_free)  # previous job's D2H has read the arena
-                nparts = self.encode_parts if n >= 4 * self.encode_parts else 1
-                per = (n + nparts - 1) // nparts
-                parts = []
-                for c0 in range(0, n, per):
-                    c1 = min(n, c0 + per)
-                    self.ctx.encode_chunks(src, tok_begin + c0 * chunk_tokens, min(tok_end, tok_begin + c1 * chunk_tokens),
-                                           chunk_tokens, bins, arena.data_ptr() + c0 * stride, stride,
-                                           sizes.ptr + 4 * c0, stream=cur.cuda_stream, status_ptr=self._status.ptr(st))
-                    ev = torch.cuda.Event()
-                    ev.record(cur)
-                    parts.append((c0, c1, ev))
-                done = parts[-1][2]
-            job = EncodeJob(n, stride, arena, sizes, done, (L, H, D, chunk_tokens), st, None, parts)
+                try:
+                    if arena is self._enc_arena and self._arena_free is not None:
+                        cur.wait_event(self._arena_free)  # previous job's D2H has read the arena
+                    nparts = self.encode_parts if n >= 4 * self.encode_parts else 1
+                    per = (n + nparts - 1) // nparts
+                    parts = []
+                    for c0 in range(0, n, per):
+                        c1 = min(n, c0 + per)
+                        self.ctx.encode_chunks(src, tok_begin + c0 * chunk_tokens, min(tok_end, tok_begin + c1 * chunk_tokens),
+                                               chunk_tokens, bins, arena.data_ptr() + c0 * stride, stride,
+                                               sizes.ptr + 4 * c0, stream=cur.cuda_stream, status_ptr=self._status.ptr(st))
+                        ev = torch.cuda.Event()
+                        ev.record(cur)
+                        parts.append((c0, c1, ev))
+                    done = parts[-1][2]
+                except BaseException:
+                    self._abandon_status(st, cur)
+                    self._size_pool.append(sizes)
+                    raise
+            job = EncodeJob(n, stride, arena, sizes, done, (L, H, D, chunk_tokens), st, None, parts, pool=self._status)
             if arena is self._enc_arena:
                 self._shared_job = job
             return job
+
+    def _abandon_status(self, st: int, stream) -> None:
+        """A launch sequence failed half way: whatever was queued may still write the word, so it goes back to the
+        pool only after the stream has drained (an error path: the host wait does not matter)."""
+        try:
+            stream.synchronize()
+        except Exception:
+            pass
+        self._status.read_release(st)
 
     def _check_job(self, job: EncodeJob) -> None:
         """The job's kernels have completed: read its status word (once) and raise on a device error."""
@@ -329,17 +370,66 @@ class CacheGenDeviceCodec:
         ranges = layer_ranges(L, layers_per_launch)
         with self._lock, torch.cuda.device(self.device):
             cur = torch.cuda.current_stream(self.device)
-            table = native.pointer_table([b.data_ptr() for b in blobs], self.device)
+            # the blob addresses of THIS call: any number of chunks (a 128 k-token retrieve is 512 of them), uploaded
+            # stream-ordered from pinned memory of torch's caching host allocator -- no host wait, nothing cached (the
+            # content-keyed table cache of native.pointer_table is for the few KV plane tables a serving engine
+            # hands over again and again, not for blob sets that are never seen twice)
+            table = torch.tensor([b.data_ptr() for b in blobs], dtype=torch.int64).pin_memory().to(self.device, non_blocking=True)
             bound = max(b.numel() for b in blobs)
             st = self._status.acquire()
-            events = []
-            for l0, l1 in ranges:
-                self.ctx.decode_chunks_layers(table.data_ptr(), bound, n, dst, dst_tok0, chunk_tokens, l0, l1 - l0,
-                                              stream=cur.cuda_stream, status_ptr=self._status.ptr(st))
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                events.append((l1, ev))
-            return DecodeJob(events[-1][1], st, events if layers_per_launch else None)
+            try:
+                events = []
+                for l0, l1 in ranges:
+                    self.ctx.decode_chunks_layers(table.data_ptr(), bound, n, dst, dst_tok0, chunk_tokens, l0, l1 - l0,
+                                                  stream=cur.cuda_stream, status_ptr=self._status.ptr(st))
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    events.append((l1, ev))
+            except BaseException:
+                self._abandon_status(st, cur)
+                raise
+            job = DecodeJob(events[-1][1], st, events if layers_per_launch else None, pool=self._status)
+            job._table = table  # the kernels read it: alive as long as the job
+            return job
+
+    def decode_host_layerwise(self, host_blobs: Sequence["HostBlob"], dst: native.KVLayout, dst_tok0: int,
+                              chunk_tokens: int, layers_per_range) -> Optional[DecodeJob]:
+        """Blobs in pinned host DRAM -> decoded KV, cut by layers through ONE C-ABI call (lmc_load_chunks): a gather
+        kernel pulls the bytes of a range of layers over PCIe while the previous range is decoded, an event per
+        range (DecodeJob.layer_events) lets the model start on layer 0 after 1/L of the transfer -- where decode()
+        moves whole chunks first (the first layer is complete when the last chunk has landed).
+        layers_per_range: an int (a schedule is not supported by the single call: its first entry is used)."""
+        n = len(host_blobs)
+        if n == 0:
+            return None
+        step = layers_per_range if isinstance(layers_per_range, int) else int(list(layers_per_range)[0])
+        step = max(1, min(dst.L, int(step or dst.L)))
+        ranges = layer_ranges(dst.L, step)
+        with self._lock, torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            meta = None
+            for k, b in enumerate(self._meta_pool):
+                if b.nbytes >= 12 * n:
+                    meta = self._meta_pool.pop(k)
+                    break
+            if meta is None:
+                meta = native.PinnedBuffer(12 * max(n, 256))
+            meta.tensor[:8 * n].view(torch.int64).copy_(torch.tensor([hb.ptr for hb in host_blobs], dtype=torch.int64))
+            meta.tensor[8 * n:12 * n].view(torch.int32).copy_(torch.tensor([hb.nbytes for hb in host_blobs], dtype=torch.int32))
+            events = [native.NativeEvent() for _ in ranges]
+            handles = (ctypes.c_void_p * len(events))(*[e.handle for e in events])
+            st = self._status.acquire()
+            try:
+                self.ctx.load_chunks(meta.ptr, meta.ptr + 8 * n, n, dst, dst_tok0, chunk_tokens, step,
+                                     ctypes.cast(handles, ctypes.c_void_p).value, stream=cur.cuda_stream,
+                                     status_ptr=self._status.ptr(st))
+            except BaseException:
+                self._abandon_status(st, cur)
+                self._meta_pool.append(meta)
+                raise
+            job = DecodeJob(events[-1], st, [(l1, ev) for (_, l1), ev in zip(ranges, events)], pool=self._status)
+            job._meta, job._meta_pool = meta, self._meta_pool  # the kernels read the arrays: back in the pool at finish
+            return job
 
     def _dec_slots(self, n: int, stride: int, cur) -> torch.Tensor:
         if self._dec_arena is None or self._dec_arena.numel() < n * stride:
@@ -369,50 +459,54 @@ class CacheGenDeviceCodec:
                 cur = torch.cuda.current_stream(self.device)
                 arena = self._dec_slots(n, stride, cur)
                 st = self._status.acquire()
-                if self._dec_free is not None:
-                    self.copy_stream.wait_event(self._dec_free)  # previous decode has read the slots
-                cs = self.copy_stream.cuda_stream
-                staged_off = 0
-                pageable = [hb for hb in host_blobs if not isinstance(hb, HostBlob) and not _is_dev(hb)]
-                if pageable:
-                    need = sum(native.r16(len(b)) for b in pageable)
-                    if self._stage is None or self._stage.nbytes < need:
-                        self.copy_stream.synchronize()
-                        self._stage = native.PinnedBuffer(need)
-                    else:
-                        self.copy_stream.synchronize()  # staging buffer is reused: earlier H2D must be done
-                # H2D and decode are pipelined in batches: the copy stream runs ahead, the compute stream
-                # decodes batch b as soon as its blobs have landed (one event per batch)
-                B = batch_chunks or self.decode_batch_chunks
-                last = None
-                for b0 in range(0, n, B):
-                    b1 = min(n, b0 + B)
-                    for i in range(b0, b1):
-                        hb = host_blobs[i]
-                        if _is_dev(hb):
-                            # a blob already in HBM (xgmi:// connector): a device copy on the decoding stream itself,
-                            # ordered behind whatever produced the tensor
-                            native.memcpy_async(arena.data_ptr() + i * stride, hb.data_ptr(), sizes[i], "d2d",
-                                                cur.cuda_stream)
-                            continue
-                        if isinstance(hb, HostBlob):
-                            src_ptr = hb.ptr
+                try:
+                    if self._dec_free is not None:
+                        self.copy_stream.wait_event(self._dec_free)  # previous decode has read the slots
+                    cs = self.copy_stream.cuda_stream
+                    staged_off = 0
+                    pageable = [hb for hb in host_blobs if not isinstance(hb, HostBlob) and not _is_dev(hb)]
+                    if pageable:
+                        need = sum(native.r16(len(b)) for b in pageable)
+                        if self._stage is None or self._stage.nbytes < need:
+                            self.copy_stream.synchronize()
+                            self._stage = native.PinnedBuffer(need)
                         else:
-                            data = hb if isinstance(hb, bytes) else bytes(hb)  # never mutates the caller's buffer
-                            ctypes.memmove(self._stage.ptr + staged_off, data, len(data))
-                            src_ptr = self._stage.ptr + staged_off
-                            staged_off += native.r16(len(data))
-                        native.memcpy_async(arena.data_ptr() + i * stride, src_ptr, sizes[i], "h2d", cs)
-                    ready = torch.cuda.Event()
-                    ready.record(self.copy_stream)
-                    cur.wait_event(ready)
-                    self.ctx.decode_chunks(arena.data_ptr() + b0 * stride, stride, b1 - b0, dst,
-                                           dst_tok0 + b0 * chunk_tokens, chunk_tokens, stream=cur.cuda_stream,
-                                           status_ptr=self._status.ptr(st))
-                    last = torch.cuda.Event()
-                    last.record(cur)
-                self._dec_free = last
-                return DecodeJob(last, st)
+                            self.copy_stream.synchronize()  # staging buffer is reused: earlier H2D must be done
+                    # H2D and decode are pipelined in batches: the copy stream runs ahead, the compute stream
+                    # decodes batch b as soon as its blobs have landed (one event per batch)
+                    B = batch_chunks or self.decode_batch_chunks
+                    last = None
+                    for b0 in range(0, n, B):
+                        b1 = min(n, b0 + B)
+                        for i in range(b0, b1):
+                            hb = host_blobs[i]
+                            if _is_dev(hb):
+                                # a blob already in HBM (xgmi:// connector): a device copy on the decoding stream itself,
+                                # ordered behind whatever produced the tensor
+                                native.memcpy_async(arena.data_ptr() + i * stride, hb.data_ptr(), sizes[i], "d2d",
+                                                    cur.cuda_stream)
+                                continue
+                            if isinstance(hb, HostBlob):
+                                src_ptr = hb.ptr
+                            else:
+                                data = hb if isinstance(hb, bytes) else bytes(hb)  # never mutates the caller's buffer
+                                ctypes.memmove(self._stage.ptr + staged_off, data, len(data))
+                                src_ptr = self._stage.ptr + staged_off
+                                staged_off += native.r16(len(data))
+                            native.memcpy_async(arena.data_ptr() + i * stride, src_ptr, sizes[i], "h2d", cs)
+                        ready = torch.cuda.Event()
+                        ready.record(self.copy_stream)
+                        cur.wait_event(ready)
+                        self.ctx.decode_chunks(arena.data_ptr() + b0 * stride, stride, b1 - b0, dst,
+                                               dst_tok0 + b0 * chunk_tokens, chunk_tokens, stream=cur.cuda_stream,
+                                               status_ptr=self._status.ptr(st))
+                        last = torch.cuda.Event()
+                        last.record(cur)
+                    self._dec_free = last
+                    return DecodeJob(last, st, pool=self._status)
+                except BaseException:
+                    self._abandon_status(st, cur)
+                    raise
 
     def finish_decode(self, job: Optional[DecodeJob], what: str = "CacheGen decode") -> None:
         """Wait for THIS decode (its event, not the device) and raise NativeError if a kernel flagged its blobs
@@ -420,7 +514,11 @@ class CacheGenDeviceCodec:
         if job is None:
             return
         job.done.synchronize()
-        st = self._status.read_release(job.status_idx)
+        st, job.status_idx = self._status.read_release(job.status_idx), -1
+        meta = getattr(job, "_meta", None)
+        if meta is not None:
+            job._meta_pool.append(meta)
+            job._meta = None
         if st:
             raise native.NativeError(f"{what}: " + native.describe_status(st))
 

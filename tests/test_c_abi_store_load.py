@@ -1,0 +1,103 @@
+"""lmc_store_chunks / lmc_load_chunks (include/lmc_hip.h): the host-DRAM legs of store and retrieve through the C ABI
+alone -- ctypes and raw pointers, none of the Python sequencing of serde/cachegen_device.py.  What a non-Python
+binder of liblmc_hip.so gets where the reference has LMCLocalBackend.put / get
+(lmcache/storage_backend/local_backend.py:82-100, 128-144)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from lmcache_amd import native
+    native.build()
+    return native
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import lmc_oracle
+    lmc_oracle.build()
+    return lmc_oracle
+
+
+def _bits(t):
+    return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("shape", [(4, 2148, 8, 128, 1), (2, 700, 3, 128, 0), (3, 256, 8, 128, 3)],
+                         ids=["9chunks_tail_1layer_ranges", "C384_whole", "1chunk_3layer_ranges"])
+def test_store_then_load_through_the_c_abi_only(nat, oracle, shape):
+    L, T, H, D, lpr = shape
+    cs = 256
+    n = (T + cs - 1) // cs
+    g = torch.Generator().manual_seed(T)
+    kv = torch.randn(L, 2, T, H, D, generator=g).to(torch.bfloat16)
+    kv_d = kv.to(DEV)
+    bins = [32 if l < max(1, L // 3) else 16 for l in range(L)] + [32 if l < 1 else 16 for l in range(L)]
+    ctx = nat.get_context(0)
+    bound = nat.r16(nat.blob_bound(L, cs, H, D))
+    arena = nat.PinnedBuffer(n * bound)
+    meta = nat.PinnedBuffer(8 * (n + 1) + 8 * n + 4 * n + 64)     # offsets | blob pointers | sizes | status
+    o_ptrs, o_sizes, o_status = 8 * (n + 1), 8 * (n + 1) + 8 * n, 8 * (n + 1) + 12 * n
+    offs = meta.tensor[:o_ptrs].view(torch.int64)
+    ptrs = meta.tensor[o_ptrs:o_sizes].view(torch.int64)
+    sizes = meta.tensor[o_sizes:o_status].view(torch.int32)
+    status = meta.tensor[o_status:o_status + 4].view(torch.int32)
+    status[0] = 0
+    p_offs, p_ptrs, p_sizes, p_status = meta.ptr, meta.ptr + o_ptrs, meta.ptr + o_sizes, meta.ptr + o_status
+    st = torch.cuda.Stream(device=DEV)
+    lay = nat.KVLayout.from_chunk(kv_d, "vllm")
+    # ---- store: one call, returns without waiting; everything is valid once the stream has drained -----------
+    ctx.store_chunks(lay, 0, T, cs, bins, arena.ptr, arena.nbytes, p_offs, p_sizes, stream=st.cuda_stream, status_ptr=p_status)
+    st.synchronize()
+    assert int(status[0]) == 0
+    offs_l, sizes_l = offs.tolist(), sizes.tolist()
+    assert offs_l[0] == 0 and offs_l[n] == sum(nat.r16(s) for s in sizes_l)
+    for i in range(n):
+        t0, t1 = i * cs, min(T, (i + 1) * cs)
+        blob = ctypes.string_at(arena.ptr + offs_l[i], sizes_l[i])
+        b, code = oracle.torch_to_bits(kv[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
+        assert blob == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)), f"chunk {i}"
+        assert offs_l[i + 1] == offs_l[i] + nat.r16(sizes_l[i])
+    # ---- load: gather + decode range by range; the events say when a range of layers is complete --------------
+    for i in range(n):
+        ptrs[i] = arena.ptr + offs_l[i]
+    out = torch.zeros_like(kv_d)
+    nranges = (L + lpr - 1) // lpr if lpr else 1
+    ev_handles = (ctypes.c_void_p * nranges)()
+    for r in range(nranges):
+        h = ctypes.c_void_p()
+        nat.check(nat.lib().lmc_event_create(ctypes.byref(h), 0), "lmc_event_create")
+        ev_handles[r] = h
+    ctx.load_chunks(p_ptrs, p_sizes, n, nat.KVLayout.from_chunk(out, "vllm"), 0, cs, lpr,
+                    ctypes.cast(ev_handles, ctypes.c_void_p).value, stream=st.cuda_stream, status_ptr=p_status)
+    for r in range(nranges):  # the last event implies the earlier ones; every one of them fires
+        nat.check(nat.lib().lmc_event_synchronize(ev_handles[r]), "lmc_event_synchronize")
+    st.synchronize()
+    assert int(status[0]) == 0
+    for i in range(n):
+        t0, t1 = i * cs, min(T, (i + 1) * cs)
+        b, code = oracle.torch_to_bits(kv[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
+        ref = oracle.decode_blob(oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)), oracle.BF16)
+        assert np.array_equal(_bits(out[:, :, t0:t1]).reshape(L, 2, t1 - t0, H * D), ref), f"chunk {i}"
+    for r in range(nranges):
+        nat.lib().lmc_event_destroy(ev_handles[r])
+    # ---- an arena that is too small: flagged, sizes of the blobs that did not fit read 0, nothing written past it
+    status[0] = 0
+    small = offs_l[n] - 16
+    ctx.store_chunks(lay, 0, T, cs, bins, arena.ptr, small, p_offs, p_sizes, stream=st.cuda_stream, status_ptr=p_status)
+    st.synchronize()
+    assert int(status[0]) & 32 and sizes.tolist()[-1] == 0 and all(s > 0 for s in sizes.tolist()[:-1])
+    arena.free()
+    meta.free()

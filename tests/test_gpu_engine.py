@@ -665,11 +665,21 @@ def test_hbm_cachegen_tier_and_layerwise_retrieve(oracle):
         r = engine.retrieve_layerwise(generate_tokens(300, "cuda"))
         assert r.kv == () and not r.ret_mask.any() and r.layer_events == []
         r.finish()
-        r = host.retrieve_layerwise(toks, layers_per_launch=1)  # pinned-host tier: one piece
-        assert len(r.layer_events) == 1 and int(r.ret_mask.sum()) == 600
-        r.wait_layer(0)
+        # pinned-host tier: ONE lmc_load_chunks call gathers and decodes range after range (events of the C ABI)
+        for step, nev in ((1, 8), (3, 3), (8, 1)):
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                r = host.retrieve_layerwise(toks, layers_per_launch=step)
+            assert len(r.layer_events) == nev and r.layer_events[-1][0] == nl and int(r.ret_mask.sum()) == 600
+            for l in range(nl):
+                r.wait_layer(l)
+                assert torch.equal(r.kv[l][0], want[l][0]) and torch.equal(r.kv[l][1], want[l][1])
+            r.finish()
+        r = host.retrieve_layerwise(toks, mask, layers_per_launch=2)
         r.finish()
-        assert torch.equal(r.kv[3][1], want[3][1])
+        assert int(r.ret_mask.sum()) == 400
+        for (k, v), (k1, v1) in zip(r.kv, want):
+            assert torch.equal(k, k1[200:]) and torch.equal(v, v1[200:])
         # a blob damaged in HBM: the synchronous paths report a miss, the asynchronous one raises at finish()
         keys = [engine._make_key(h, fmt) for h in engine._prefix_hash(engine._chunk_tokens(toks))]
         blob = engine.engine_.dict[keys[2]].blob

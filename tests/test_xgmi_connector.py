@@ -51,6 +51,46 @@ def test_remote_connector_contract_single_rank():
         conn.unlink()
 
 
+def test_restart_retires_the_records_of_the_old_arena():
+    """The directory file outlives the arenas.  A rank that comes back (here: close + reopen without unlink) creates
+    a new arena: the keys its old arena held must read as misses, not as garbage of the new arena, the bump pointer
+    starts again, and new stores of the same keys work."""
+    from lmcache_amd.storage_backend.connector.xgmi_connector import XgmiConnector
+    os.environ["LMC_XGMI_ARENA_MB"] = "2"
+    name = _name("gen")
+    conn = XgmiConnector(name, 1, device="cpu")
+    try:
+        keys = [f"vllm@m@1@0@{i:064x}" for i in range(8)]
+        for k in keys:
+            conn.set(k, k.encode() * 50)
+        assert all(conn.exists(k) for k in keys)
+        conn.close()
+        conn = XgmiConnector(name, 1, device="cpu")          # same store name, stale directory, NEW arena
+        assert not any(conn.exists(k) for k in keys) and conn.list() == []
+        assert all(conn.get(k) is None for k in keys)
+        for k in keys:                                        # skip-existing logic upstream now stores them again
+            conn.set(k, k.encode() * 60)
+        assert all(conn.get(k) == k.encode() * 60 for k in keys)
+        for _ in range(40):                                   # 40 x 8 x ~4 KB would overflow 2 MiB if the old bump pointer had survived
+            conn.close()
+            conn = XgmiConnector(name, 1, device="cpu")
+            for k in keys:
+                conn.set(k, os.urandom(4000))
+    finally:
+        conn.close()
+        conn.unlink()
+
+
+def test_no_pickle_in_the_connectors():
+    """Peers exchange fixed-layout binary records (directory, arena exports, SPMD exchange): nothing in the connector
+    package unpickles bytes another process wrote."""
+    d = os.path.join(ROOT, "lmcache_amd", "storage_backend", "connector")
+    for f in os.listdir(d):
+        if f.endswith(".py"):
+            src = open(os.path.join(d, f)).read()
+            assert "import pickle" not in src and "pickle.load" not in src and "pickle.dump" not in src, f
+
+
 def _rank(rank, world, name, device, q):
     sys.path.insert(0, ROOT)
     os.environ["LMC_XGMI_ARENA_MB"] = "16"
