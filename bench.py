@@ -347,7 +347,9 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region and the roofline")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the cpu_baseline sample (0 = auto)")
-    ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the xgmi:// exchange leg")
+    ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the exchange leg")
+    ap.add_argument("--exchange-transport", choices=("both", "ipc", "rccl"), default="both",
+                    help="N>1 exchange leg: HIP-IPC connector (xgmi://), RCCL batch_isend_irecv (XgmiShardStore), or both")
     args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -452,7 +454,8 @@ def main(argv=None):
     if use_dist and not STUB and not args.no_extras:
         offload_all = all_ranks_offload(ctx, layout, bins, dev, local_rank, world)
         if not args.no_exchange:
-            exchange = exchange_leg(blobs, sizes, stride, nchunks, rank, world, dev)
+            exchange = exchange_leg(blobs, sizes, stride, nchunks, rank, world, dev,
+                                    ("ipc", "rccl") if args.exchange_transport == "both" else (args.exchange_transport,))
 
     if rank != 0:
         if use_dist:
@@ -601,37 +604,72 @@ def all_ranks_offload(ctx, layout, bins, dev, local_rank, world):
             "note": "all ranks store their 16k context to their own NUMA-local pinned arena concurrently"}
 
 
-def exchange_leg(blobs, sizes, stride, nchunks, rank, world, dev):
-    """One exchange of encoded chunks between the ranks through the xgmi:// connector: every rank publishes its 64
-    chunks (blobs land in the HBM arena of the key's owner rank, a peer write over xGMI), then fetches the next
-    rank's chunks (peer reads)."""
+def exchange_leg(blobs, sizes, stride, nchunks, rank, world, dev, transports=("ipc", "rccl")):
+    """One exchange of encoded chunks between the ranks (BASELINE configs[2]'s hand-over of a context between two
+    instances), by either transport:
+      ipc   the xgmi:// connector: every rank publishes its chunks (a blob lands in the HBM arena of the key's owner
+            rank, a peer write through the HIP-IPC mapping), then fetches the next rank's chunks (peer reads);
+            one-sided, no collective;
+      rccl  xgmi_exchange.XgmiShardStore: the same routing as ONE batch_isend_irecv group per direction on the
+            process group's nccl (= RCCL) backend; SPMD.
+    Rates are blob bytes, whole job and per GPU."""
     import torch.distributed as dist
     from lmcache_amd.distributed import max_over_ranks, sum_over_ranks
-    from lmcache_amd.storage_backend.connector import CreateConnector
-    try:
-        conn = CreateConnector(f"xgmi://bench{os.environ.get('MASTER_PORT', '0')}:{world}")
-        szs = sizes.cpu().tolist()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for i in range(nchunks):
-            conn.set_device(f"bench@{world}@{rank}@{i:04x}", blobs[i * stride:i * stride + szs[i]])
+    out = {}
+    szs = sizes.cpu().tolist()
+    views = [blobs[i * stride:i * stride + szs[i]] for i in range(nchunks)]
+    tot = sum_over_ranks(float(sum(szs)), dev)
+    peer = (rank + 1) % world
+
+    def timed(fn):
         torch.cuda.synchronize()
         dist.barrier()
-        t_put = max_over_ranks(time.perf_counter() - t0, dev)
-        peer = (rank + 1) % world
         t0 = time.perf_counter()
-        got = [conn.get_device(f"bench@{world}@{peer}@{i:04x}") for i in range(nchunks)]
+        r = fn()
         torch.cuda.synchronize()
         dist.barrier()
-        t_get = max_over_ranks(time.perf_counter() - t0, dev)
-        ok = all(g is not None for g in got)
-        tot = sum_over_ranks(float(sum(szs)), dev)
-        conn.close()
+        return r, max_over_ranks(time.perf_counter() - t0, dev)
+
+    def line(t_put, t_get, ok, note):
         return {"put_GBps_blob_all_ranks": round(tot / t_put / 1e9, 1), "get_GBps_blob_all_ranks": round(tot / t_get / 1e9, 1),
-                "put_ms": round(t_put * 1e3, 2), "get_ms": round(t_get * 1e3, 2), "all_hits": ok,
-                "note": "xgmi:// connector: blobs resident in the owner rank's HBM arena, peer copies over xGMI"}
-    except Exception as e:  # informational leg
-        return {"error": repr(e)}
+                "put_GBps_blob_per_gpu": round(tot / world / t_put / 1e9, 1),
+                "get_GBps_blob_per_gpu": round(tot / world / t_get / 1e9, 1),
+                "put_ms": round(t_put * 1e3, 2), "get_ms": round(t_get * 1e3, 2), "all_hits": ok, "note": note}
+
+    if "ipc" in transports:
+        try:
+            from lmcache_amd.storage_backend.connector import CreateConnector
+            conn = CreateConnector(f"xgmi://bench{os.environ.get('MASTER_PORT', '0')}:{world}")
+            _, t_put = timed(lambda: [conn.set_device(f"bench@{world}@{rank}@{i:04x}", views[i]) for i in range(nchunks)])
+            got, t_get = timed(lambda: [conn.get_device(f"bench@{world}@{peer}@{i:04x}") for i in range(nchunks)])
+            ok = all(g is not None and g.numel() > 0 for g in got)
+            dist.barrier()
+            conn.close()
+            out["ipc"] = line(t_put, t_get, ok, "xgmi:// connector: blobs resident in the owner rank's HBM arena, peer "
+                              "copies through HIP-IPC mappings, no collective")
+        except Exception as e:  # informational leg
+            out["ipc"] = {"error": repr(e)}
+    if "rccl" in transports:
+        try:
+            from lmcache_amd.storage_backend.connector.xgmi_exchange import XgmiShardStore
+            store = XgmiShardStore(device=dev)
+            _, t_put = timed(lambda: store.exchange_put([(f"bench@{world}@{rank}@{i:04x}", views[i]) for i in range(nchunks)]))
+            got, t_get = timed(lambda: store.exchange_get([f"bench@{world}@{peer}@{i:04x}" for i in range(nchunks)]))
+            ok = all(g is not None and g.numel() == n for g, n in zip(got, _peer_sizes(szs, dev, world, peer)))
+            out["rccl"] = line(t_put, t_get, ok, "XgmiShardStore: one batch_isend_irecv group per direction on the nccl "
+                               "(= RCCL) backend, fixed-size metadata records by all_gather")
+        except Exception as e:
+            out["rccl"] = {"error": repr(e)}
+    return out
+
+
+def _peer_sizes(szs, dev, world, peer):
+    """The chunk sizes of rank `peer` (all_gather of the size lists), to check what an exchange returned."""
+    import torch.distributed as dist
+    mine = torch.tensor(szs, dtype=torch.int64, device=dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return parts[peer].cpu().tolist()
 
 
 def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, stream, sp, raw_bytes, blob_bytes,

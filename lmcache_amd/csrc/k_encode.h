@@ -168,19 +168,55 @@ __device__ __forceinline__ u32 lookback_exclusive(unsigned long long* agg, int i
 // Move a finished stream from its scratch slot to offset `excl` of the chunk's streams section, record its
 // end in the directory; the chunk's last group also writes header, bins, rowpre, pads and the size word.
 // STATIC = false: the caller writes the chunk's static sections itself (k_fused.h).
+// A finished stream from its scratch slot to its place in the blob, n16 16-byte pieces by one wave.  `dst[i] = src[i]`
+// compiles to "load, wait, store" per KiB (the pointers may alias): 9 dependent memory round trips for a typical
+// 8.6 KiB stream with the wave's slot held throughout.  Holding a batch in VGPRs instead costs the whole kernel its
+// register budget (8 pieces: 144 bytes of spills in the coder loops, measured +20 % on k_cdf_encode).  So the batch
+// lands in LDS: global_load_lds_dwordx4 (gfx950) writes lane l's 16 bytes to M0 + 16 l without a destination
+// register, four of them fill the wave's idle 4 KiB table slice, and the pieces go out from there -- 3 round trips.
+#ifndef LMC_PLACE_BATCH
+#define LMC_PLACE_BATCH 4  // KiB of LDS = loads in flight
+#endif
+#ifndef LMC_PLACE_SERIAL
+#define LMC_PLACE_SERIAL 0
+#endif
+__device__ __forceinline__ void copy_stream16(uint4* dst, const uint4* src, u32 n16_v, u32* lds4k, int lane) {
+  typedef __attribute__((address_space(1))) const void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  const u32 n16 = (u32)__builtin_amdgcn_readfirstlane((int)n16_v);  // wave-uniform: scalar loop control
+#if LMC_PLACE_SERIAL  // A/B: the round-2 loop
+#pragma unroll 4
+  for (u32 i = lane; i < n16; i += 64) dst[i] = src[i];
+  return;
+#endif
+#pragma unroll 1
+  for (u32 base = 0; base < n16; base += 64u * LMC_PLACE_BATCH) {
+#pragma unroll
+    for (int k = 0; k < LMC_PLACE_BATCH; k++) {
+      const u32 i = base + 64u * k + lane;
+      __builtin_amdgcn_global_load_lds((gptr)(src + (i < n16 ? i : n16 - 1u)), (lptr)(lds4k + 256 * k), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < LMC_PLACE_BATCH; k++) {
+      const u32 i = base + 64u * k + lane;
+      const uint4 v = *reinterpret_cast<const uint4*>(lds4k + 256 * k + 4 * lane);
+      if (i < n16) dst[i] = v;
+      asm volatile("" ::: "memory");  // one piece in registers at a time
+    }
+  }
+  wave_lds_fence();  // the slice is free for its next user
+}
+
 template <bool STATIC = true>
-__device__ __forceinline__ void place_stream(const EncodeArgs& a, const PendingTile& t, u32 excl, int lane) {
+__device__ __forceinline__ void place_stream(const EncodeArgs& a, const PendingTile& t, u32 excl, u32* lds4k, int lane) {
   const int n = a.P * a.G;
   const u32 padded = (t.exact + 15u) & ~15u;
   const BlobOff bo = lmc_blob_off((u32)a.P, t.T, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
   u8* blob = a.blobs + (long long)t.chunk * a.blob_stride;
   if (lane == 0) reinterpret_cast<u32*>(blob + bo.gend)[t.pg] = excl + t.exact;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stream stores have landed before it re-reads them
-  const uint4* src = reinterpret_cast<const uint4*>(t.out);
-  uint4* dst = reinterpret_cast<uint4*>(blob + bo.streams + excl);
-  const u32 n16 = padded >> 4;
-#pragma unroll 4
-  for (u32 i = lane; i < n16; i += 64) dst[i] = src[i];
+  copy_stream16(reinterpret_cast<uint4*>(blob + bo.streams + excl), reinterpret_cast<const uint4*>(t.out), padded >> 4, lds4k, lane);
   if (STATIC && t.pg == n - 1) {  // the last group knows the chunk's size: header, static sections, size word
     write_blob_static(blob, bo, a, t.T, excl + padded, lane);
     if (lane == 0) a.sizes[t.chunk] = bo.streams + excl + padded;

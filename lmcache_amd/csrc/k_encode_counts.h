@@ -569,12 +569,12 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
       }
     }
     __syncthreads();
-    place_stream(a, t, wg_excl + intra, lane);
+    place_stream(a, t, wg_excl + intra, hist, lane);
   } else {
     // streams of a chunk do not fill whole workgroups: every wave publishes and looks back for itself
     if (lane == 0 && t.pg > 0) agg_store(agg + t.pg, AGG_A, padded);
     const u32 excl = lookback_exclusive(agg, t.pg, lane, a.status);
     if (lane == 0) agg_store(agg + t.pg, AGG_P, excl + padded);
-    place_stream(a, t, excl, lane);
+    place_stream(a, t, excl, hist, lane);
   }
 }

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     t.out = reinterpret_cast<const u16*>(a.scratch + (gid0 + g) * (long long)a.cap);
 #endif
 #if !(LMC_EXP_TWICE & 8)
-    place_stream<false>(a, t, wg_excl + intra, lane);
+    place_stream<false>(a, t, wg_excl + intra, hist, lane);
 #endif
   }
   // The chunk's last plane knows the chunk's size: header, static sections, size word (kept out of the stream loop:

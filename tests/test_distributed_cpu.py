@@ -60,19 +60,21 @@ def test_owner_rank_is_stable():
     assert whole_job_rate([2.0, 2.0], 0.5) == 8.0
 
 
-def _exchange_worker(rank, world, port, q):
+def _exchange_worker(rank, world, port, q, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":  # RCCL: one GPU per rank (tests/test_gpu_exchange.py)
+        torch.cuda.set_device(rank % torch.cuda.device_count())
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from lmcache_amd.storage_backend.connector.xgmi_exchange import XgmiShardStore
     store = XgmiShardStore()
-    assert store.device.type == "cpu" and store.world == world
+    assert store.device.type == ("cuda" if backend == "nccl" else "cpu") and store.world == world
 
     def blob_of(key):  # deterministic, ragged sizes
         g = torch.Generator().manual_seed(sum(key.encode()))
         n = 1000 + (sum(key.encode()) * 37) % 5000
-        return torch.randint(0, 256, (n,), dtype=torch.uint8, generator=g)
+        return torch.randint(0, 256, (n,), dtype=torch.uint8, generator=g).to(store.device)
 
     keys = [f"vllm@m@{world}@{r}@{i:04x}" for r in range(world) for i in range(6)]
     mine = [k for k in keys if k.split("@")[3] == str(rank)]
@@ -102,10 +104,10 @@ def _exchange_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _run_world(target, world, port):
+def _run_world(target, world, port, *extra):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + extra) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

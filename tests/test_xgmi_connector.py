@@ -97,8 +97,10 @@ def _rank(rank, world, name, device, q):
     from lmcache_amd.distributed import owner_rank
     from lmcache_amd.storage_backend.connector.xgmi_connector import XgmiConnector
     try:
+        if device == "cuda:rank":                  # one GPU per rank when the box has them, else both ranks on GPU 0
+            device = f"cuda:{rank % torch.cuda.device_count()}"
         if device != "cpu":
-            torch.cuda.set_device(0)
+            torch.cuda.set_device(torch.device(device))
         conn = XgmiConnector(name, world, rank=rank, device=device)
         mine = {f"vllm@m@{world}@{rank}@{i:04x}": bytes([rank * 16 + (i % 16)]) * (3000 + 100 * i) for i in range(12)}
         for i, (k, b) in enumerate(mine.items()):
@@ -164,3 +166,11 @@ def test_two_ranks_share_one_store_hip_ipc():
     """The same exchange with the arenas in HBM, mapped across the two processes through HIP IPC handles (both ranks
     on the one GPU of the test box): peer writes on set, peer reads on get."""
     _two_ranks("cuda:0")
+
+
+@pytest.mark.gpu
+def test_two_ranks_two_devices_hip_ipc():
+    """One GPU per rank: the peer arena is another device's HBM, reached over xGMI through the IPC mapping."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the one-GPU form of this test is test_two_ranks_share_one_store_hip_ipc)")
+    _two_ranks("cuda:rank")
