@@ -908,11 +908,12 @@ def overlap_legs(dev, kv, raw_bytes):
         assert int(mask.sum()) == CTX
         del ret
     ttft = ttft[1:]
-    # the same warm prefix cut by layers (engine.retrieve_layerwise -> lmc_load_chunks): the streams of layer range r + 1
-    # cross PCIe (one hipMemcpyAsync per contiguous plane run and blob) while range r is decoded and the model's layers
-    # of the ranges that are complete run.  Measured: no gain on this link -- a cut into R ranges is 64 x (1 + 2 R)
-    # copies of a few hundred KB instead of 64 of 8 MB, and the DMA engines lose more on the small copies than the
-    # overlap wins (a gather KERNEL reading the pinned blobs moves 41 GB/s against the DMA's 52: DESIGN.md section 5)
+    # the same warm prefix cut by layers (engine.retrieve_layerwise -> lmc_load_chunks): the 64 blobs cross PCIe whole
+    # (one hipMemcpyAsync each, two DMA queues), then one decode launch per layer range, each with its event: the model's
+    # layers of the ranges that are complete run beside the decode of the later ones.  Cutting the TRANSFER by layer
+    # ranges as well was measured and lost: 64 x (1 + 2 R) copies of a few hundred KB instead of 64 of 8 MB cost 14.0 ms
+    # (R = 4) against 9.8 ms, and a gather KERNEL reading the pinned blobs moves 41 GB/s against the DMA's 52
+    # 
     from lmcache_amd.storage_backend.serde.cachegen_device import layer_ranges
     piped = {}
     for lpr in (8, 16, 32):
@@ -959,7 +960,9 @@ def overlap_legs(dev, kv, raw_bytes):
                   "pcie_floor_ms": round(pcie_ms, 2),
                   "note": "engine.retrieve() of the warm 16k prefix from pinned host DRAM (510 MB of blobs over one PCIe "
                           "Gen5 x16 link, ~52 GB/s measured: that transfer alone is the floor shown) + one proxy step, "
-                          "over one proxy step; chunk-pipelined H2D/decode, not yet layer-pipelined (DESIGN.md section 5)"}
+                          "over one proxy step.  retrieve_plus_one_step_ms: chunk-pipelined H2D/decode, then the step; layerwise_ms: "
+                          "whole-blob H2D, then one decode launch + event per layer range with the proxy's layers behind "
+                          "each event (DESIGN.md section 5)"}
     # the same question for the tier that can meet the target: encoded chunks resident in HBM (local_device="cuda",
     # local_serde="cachegen"), retrieved layer by layer on a side stream while the model's layers run
     ttft_proxy["hbm_tier"] = ttft_hbm_tier(dev, kv, proxy, alone, meta)

@@ -265,20 +265,21 @@ int lmc_store_chunks(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin, 
 
 /*
  * The retrieve leg in ONE call, cut by layers: blobs in pinned host memory -> decoded KV in `dst`.  The blobs' headers
- * and stream directories are read by the CPU where they lie (pinned host memory: no GPU work, no wait); everything but
- * the streams (an eighth of a blob) is copied first, then for every range of `layers_per_range` layers the streams of
- * those layers' planes -- one contiguous run of K planes and one of V planes per blob -- go over PCIe as
- * hipMemcpyAsyncs on two copy streams of the context, and the decode of the range (lmc_decode_chunks_layers) follows
- * on `stream`: the transfer of range r + 1 runs beside the decode of range r and beside whatever the caller's model
- * does with the layers that are complete.  Stands where LMCLocalBackend.get + CacheGenDeserializer.from_bytes + the
- * engine's torch.cat stand (local_backend.py:128-144, cache_engine.py:339-381): whole chunks to the GPU first, then
- * everything decoded, then the first layer can run.
+ * are checked by the CPU where they lie (pinned host memory: no GPU work, no wait), every blob goes over PCIe as one
+ * hipMemcpyAsync (two copy streams of the context), and behind the transfer the decode runs as one launch per range of
+ * `layers_per_range` layers (lmc_decode_chunks_layers) on `stream`, each followed by its event: the caller's model
+ * starts on the first layers while the later ranges still decode.  (Per-range transfers -- the K run and the V run of
+ * every blob, per range -- were measured slower than whole blobs: many short copies, see lmc_api.hip.)  Stands where
+ * LMCLocalBackend.get + CacheGenDeserializer.from_bytes + the engine's torch.cat stand (local_backend.py:128-144,
+ * cache_engine.py:339-381): whole chunks to the GPU one `.to("cuda")` at a time, then everything decoded and
+ * concatenated, then the first layer can run.
  *   host_blob_ptrs_h  host array [nchunks] of pinned blob addresses (16-byte aligned); read during the call only
  *   sizes_h           host array [nchunks] of their sizes; read during the call only
  *   range_events      NULL, or [ceil(L / layers_per_range)] events: event r is recorded on `stream` behind the decode
  *                     of range r (the KV of its layers is complete once it has fired)
  *   layers_per_range  0 = all layers in one range
- * Returns LMC_ERR_INVALID, with nothing queued that could write `dst`, if a blob's header or directory does not check out.
+ * Returns LMC_ERR_INVALID, with nothing queued at all, if a blob's header does not check out (the stream directory is
+ * checked by the decoder: LMC_STATUS_BAD_STREAM in the job's status word).
  * The blobs themselves must stay where they are until `stream` has completed.
  */
 int lmc_load_chunks(lmc_ctx* ctx, const void* const* host_blob_ptrs_h, const uint32_t* sizes_h, int32_t nchunks,

@@ -41,11 +41,14 @@ struct DecodeArgs {
   u32* status;
 };
 
-// per-wave LDS: cdfT [33][64] u16 (4224) | word ring: 256 x u16 + 64-word mirror (640) | lut 32 x f32 (128)
+// LDS of a workgroup: the four waves' dequantisation LUTs (32 x f32 = 128 B each) FIRST -- their byte addresses stay
+// below 2^10 and fit into the packed table entries of the counts model -- then per wave: cdfT [33][64] u16 (4224) |
+// word ring: 256 x u16 + 64-word mirror (640)
 #define DEC_CDF_BYTES 4224
 #define DEC_RING_WORDS 256
 #define DEC_RING_BYTES (2 * (DEC_RING_WORDS + 64))
-#define DEC_WAVE_BYTES (DEC_CDF_BYTES + DEC_RING_BYTES + 128)
+#define DEC_LUT_BYTES 128
+#define DEC_WAVE_BYTES (DEC_CDF_BYTES + DEC_RING_BYTES)
 
 
 __device__ __forceinline__ u64 uniform_ptr(const void* p) {  // a pointer every lane holds -> SGPR pair
@@ -57,16 +60,16 @@ __device__ __forceinline__ u64 uniform_ptr(const void* p) {  // a pointer every 
 
 template <bool SYMOUT, int DT_OUT, bool PAGED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k_decode(DecodeArgs a) {
-  __shared__ __attribute__((aligned(16))) u8 lds_all[4 * DEC_WAVE_BYTES];
+  __shared__ __attribute__((aligned(16))) u8 lds_all[4 * (DEC_LUT_BYTES + DEC_WAVE_BYTES)];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform -> SGPRs
   const long long gid = (long long)blockIdx.x * 4 + wave;
   const int n = 2 * a.layer_count * a.G;  // streams of a chunk in this launch
   if (gid >= (long long)a.nchunks * n) return;
-  u8* wl = lds_all + wave * DEC_WAVE_BYTES;
+  u8* wl = lds_all + 4 * DEC_LUT_BYTES + wave * DEC_WAVE_BYTES;
   u16* cdfT = reinterpret_cast<u16*>(wl);                           // [33][64]: entry-major, bank = lane/2
   u16* ring = reinterpret_cast<u16*>(wl + DEC_CDF_BYTES);           // stream words, word j at slot j % 256; slots 256..319 mirror 0..63
-  float* lut = reinterpret_cast<float*>(wl + DEC_CDF_BYTES + DEC_RING_BYTES);  // (q - C) / C
+  float* lut = reinterpret_cast<float*>(lds_all + wave * DEC_LUT_BYTES);  // (q - C) / C
 
   const int chunk = (int)(gid / n);
   const int r = (int)(gid - (long long)chunk * n);
@@ -143,14 +146,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
     if (counts_model) {
       // LMC_MODEL_COUNTS: freq = 2 * count, start = 2 * (symbols below), total 2^9.
       if (nsym <= 16u) {
-        // quarters of packed entries start << 23 | freq (start is even, so an entry's low 24 bits are its freq);
+        // quarters of packed entries start << 23 | &lut[symbol] << 10 | freq (start is even and the LUTs lie in the
+        // first KiB of LDS: 9 + 10 + 10 bits; the token loop gets the symbol's LUT address out of the entry it
+        // found with one v_bfe instead of tracking it through the search);
         // symbols behind the last one that occurs would start at 2^9: all ones, above every search key
         u32* tab32 = reinterpret_cast<u32*>(cdfT);
+        const u32 lut0 = (u32)(size_t)(const __attribute__((address_space(3))) float*)lut;
+        if (lut0 + DEC_LUT_BYTES > 1024u) __builtin_trap();  // lds_all is the kernel's only LDS object: offset 0
         u32 acc = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
           const u32 ci = (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-          u32 ent = acc >= 256u ? 0xffffffffu : ((acc << 24) | (ci << 1));
+          u32 ent = acc >= 256u ? 0xffffffffu : ((acc << 24) | ((lut0 + 4u * (u32)i) << 10) | (ci << 1));
           if (!active) ent = ((u32)i << 24) | 2u;  // idle lanes: any strictly increasing column keeps the search in range
           tab32[(i >> 2) * 256 + lane * 4 + (i & 3)] = ent;
           acc += ci;
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
             [colB] "v"(colB_addr), [full] "s"(full_exec), [ksh] "n"(KSH)
           : "vcc");
       const u32x4_t e4 = *(const __attribute__((address_space(3))) u32x4_t*)(size_t)q;
-      r = (q - lut_qbias) >> 6;  // LUT entry of the quarter's first symbol: quarter * 1024 -> quarter * 16 bytes
+      if constexpr (!COUNTS) r = (q - lut_qbias) >> 6;  // LUT entry of the quarter's first symbol: quarter * 1024 -> quarter * 16 bytes
       u32 e0 = e4.x, e1 = e4.y, d;
       // levels 3-4 among the quarter's entries, then x = freq * (x >> 16) + (slot - start) (start is the entry's
       // upper half, freq its lower half) and the renormalisation test, as one block: no hazard padding in between
@@ -372,23 +379,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
             : [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [full] "s"(full_exec), [lv] "v"(Lv)
             : "vcc");
       } else {
-        // the same selection; then d = slot - start = (key - entry) >> 23 (the key's low bits are >= any freq: no
-        // borrow), and x = freq * (x >> 9) + d with freq = the entry's low 24 bits (start is even)
+        // the same selection without the address bookkeeping: the entry found carries its symbol's LUT address
+        // (bits 10..19) next to its freq (bits 0..9); d = slot - start = (key - entry) >> 23 (the key's low 23 bits
+        // are >= any entry's: no borrow), x = freq * (x >> 9) + d
+        u32 f;
         asm("v_cmpx_le_u32_e32 vcc, %[e2], %[sl]\n\t"
             "v_mov_b32_e32 %[e0], %[e2]\n\t"
             "v_mov_b32_e32 %[e1], %[e3]\n\t"
-            "v_add_u32_e32 %[r], 8, %[r]\n\t"
             "s_mov_b64 exec, %[full]\n\t"
             "v_cmpx_le_u32_e32 vcc, %[e1], %[sl]\n\t"
             "v_mov_b32_e32 %[e0], %[e1]\n\t"
-            "v_add_u32_e32 %[r], 4, %[r]\n\t"
             "s_mov_b64 exec, %[full]\n\t"
             "v_sub_u32_e32 %[d], %[sl], %[e0]\n\t"
+            "v_and_b32_e32 %[f], 0x3ff, %[e0]\n\t"
             "v_lshrrev_b32_e32 %[x], 9, %[x]\n\t"
             "v_lshrrev_b32_e32 %[d], 23, %[d]\n\t"
-            "v_mad_u32_u24 %[x], %[x], %[e0], %[d]\n\t"
+            "v_bfe_u32 %[r], %[e0], 10, 10\n\t"
+            "v_mad_u32_u24 %[x], %[x], %[f], %[d]\n\t"
             "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
-            : [e0] "+v"(e0), [e1] "+v"(e1), [r] "+v"(r), [x] "+v"(x), [d] "=&v"(d), [m] "=&s"(mask)
+            : [e0] "+v"(e0), [e1] "+v"(e1), [r] "=&v"(r), [x] "+v"(x), [d] "=&v"(d), [f] "=&v"(f), [m] "=&s"(mask)
             : [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [full] "s"(full_exec), [lv] "v"(Lv)
             : "vcc");
       }

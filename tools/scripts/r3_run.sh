@@ -1,6 +1,9 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-AB="tools/probes/encode_ab 32 8 128 16384 256 0 20 0 3"
-for s in 0 20 30 40 60 0 30; do LMC_FUSED_STAGGER_US=$s timeout 120 $AB > gpurun_out/r3s_st$s.log 2>&1; echo "stagger $s: $(grep -E '^fused' gpurun_out/r3s_st$s.log | awk '{print $2}' | tr '\n' ' ')"; done
-for v in serial main; do
-  if [ $v = main ]; then L=""; else L="$PWD/build_alt/$v"; fi
-  LD_LIBRARY_PATH=$L:$LD_LIBRARY_PATH timeout 120 $AB > gpurun_out/r3s_$v.log 2>&1; echo "$v: $(grep -E '^fused|^two' gpurun_out/r3s_$v.log | awk '{print $1, $2}' | tr '\n' ' ')"; done
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r3x_pytest.log 2>&1; tail -3 gpurun_out/r3x_pytest.log
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r3x_bench.json 2> gpurun_out/r3x_bench.err
+python - <<'PY'
+import json
+txt=open("gpurun_out/r3x_bench.json").read()
+d=json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
+print(d["ms_per_step"], d["value"], d["roofline"]["frac"]); t=d["ttft_proxy"]; print({k:t[k] for k in t if k.startswith(("layerwise","retrieve","one_step","warm","cold","pcie"))}); print(d["offload_c_abi"]); print(d["decode"]); print(d["store_hidden"])
+PY
