@@ -772,10 +772,44 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
                                 "note": "lmc_store_chunks: encode in 4 parts + a device-side copy kernel per part that "
                                         "reads the sizes on the GPU and writes the blobs, exact size, into the mapped "
                                         "pinned arena (k_offload.h); the call returns without any host wait"}
+        # ... and its layer-major form (lmc_store_pack / lmc_load_pack): what the pinned tier of the engine stores
+        hstatus[0] = 0
+        calls, totals = [], []
+        for r in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.store_pack(layout, 0, CTX, CHUNK, bins, harena.ptr, cap, p_sizes, stream=sp, status_ptr=p_status)
+            calls.append((time.perf_counter() - t0) * 1e3)
+            stream.synchronize()
+            totals.append((time.perf_counter() - t0) * 1e3)
+        ph = native.pack_info(harena.ptr, cap)
+        out_p = torch.empty((L, 2, CTX, H, D), dtype=torch.bfloat16, device=dev)
+        lay_p = native.KVLayout.from_chunk(out_p, "vllm")
+        loads = {}
+        for lpr in (0, 8):
+            tl = []
+            for r in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.load_pack(harena.ptr, ph.total_bytes, 0, lay_p, 0, lpr, None, stream=sp, status_ptr=p_status)
+                stream.synchronize()
+                tl.append((time.perf_counter() - t0) * 1e3)
+            loads[lpr] = median(tl[1:])
+        res["offload_pack"] = {"store_ms_per_context": round(median(totals[1:]), 3),
+                               "store_call_returns_after_ms": round(median(calls[1:]), 3),
+                               "pack_bytes": int(ph.total_bytes), "pcie_GBps_store": round(ph.total_bytes / median(totals[1:]) / 1e6, 1),
+                               "load_ms_per_context": round(loads[0], 3), "load_ms_per_context_8_layer_ranges": round(loads[8], 3),
+                               "pcie_GBps_load": round(ph.total_bytes / loads[0] / 1e6, 1), "status": int(hstatus[0]),
+                               "note": "lmc_store_pack: whole encode, then one device-side copy kernel writes the blobs "
+                                       "transposed (static sections, then streams ordered layer / K,V / chunk) into the "
+                                       "mapped pinned region; lmc_load_pack: table + static sections, then ONE "
+                                       "hipMemcpyAsync and one decode launch per range of layers"}
+        del out_p
         harena.free()
         hmeta.free()
     except Exception as e:
-        res["offload_c_abi"] = {"error": repr(e)}
+        res.setdefault("offload_c_abi", {"error": repr(e)})
+        res.setdefault("offload_pack", {"error": repr(e)})
 
     stage("decode leg")
     # ---- decode leg: blobs in HBM -> decoded KV written straight into per-layer tensors ----------------------
@@ -863,7 +897,7 @@ def overlap_legs(dev, kv, raw_bytes):
     reps = 5
     g = torch.Generator().manual_seed(1)
     engine = LMCacheEngine(cfg, meta)
-    engine.engine_.host_arena.reserve((reps + 1) * (640 << 20))   # a backend sized for its working set
+    engine.engine_.host_arena.reserve((reps + 1) * (700 << 20), slab_bytes=2800 << 20)   # a backend sized for its working set
     for r in range(reps):
         toks = torch.randint(0, 32000, (CTX,), generator=g)
         last_key = engine._make_key(engine._prefix_hash(engine._chunk_tokens(toks))[-1], "vllm")
@@ -908,12 +942,13 @@ def overlap_legs(dev, kv, raw_bytes):
         assert int(mask.sum()) == CTX
         del ret
     ttft = ttft[1:]
-    # the same warm prefix cut by layers (engine.retrieve_layerwise -> lmc_load_chunks): the 64 blobs cross PCIe whole
-    # (one hipMemcpyAsync each, two DMA queues), then one decode launch per layer range, each with its event: the model's
-    # layers of the ranges that are complete run beside the decode of the later ones.  Cutting the TRANSFER by layer
-    # ranges as well was measured and lost: 64 x (1 + 2 R) copies of a few hundred KB instead of 64 of 8 MB cost 14.0 ms
-    # (R = 4) against 9.8 ms, and a gather KERNEL reading the pinned blobs moves 41 GB/s against the DMA's 52
-    # 
+    # the same warm prefix cut by layers (engine.retrieve_layerwise -> lmc_load_pack): the store above left the 64 blobs
+    # in pinned memory as ONE layer-major pack (lmc_format.h), so the streams of a range of layers are one contiguous
+    # region: one hipMemcpyAsync + one decode launch + one event per range, and the model's layers of the ranges that
+    # are complete run while the later ranges are still crossing PCIe.  (With one blob per chunk the same cut costs
+    # 64 x 2 short copies per range -- 14.0 ms for four ranges against 9.8 ms for the 64 whole blobs, which is why
+    # lmc_load_chunks moves whole blobs and only cuts the decode; a gather KERNEL reading the pinned blobs moves
+    # 41 GB/s against the DMA's 52: DESIGN.md section 5)
     from lmcache_amd.storage_backend.serde.cachegen_device import layer_ranges
     piped = {}
     for lpr in (8, 16, 32):
@@ -960,9 +995,9 @@ def overlap_legs(dev, kv, raw_bytes):
                   "pcie_floor_ms": round(pcie_ms, 2),
                   "note": "engine.retrieve() of the warm 16k prefix from pinned host DRAM (510 MB of blobs over one PCIe "
                           "Gen5 x16 link, ~52 GB/s measured: that transfer alone is the floor shown) + one proxy step, "
-                          "over one proxy step.  retrieve_plus_one_step_ms: chunk-pipelined H2D/decode, then the step; layerwise_ms: "
-                          "whole-blob H2D, then one decode launch + event per layer range with the proxy's layers behind "
-                          "each event (DESIGN.md section 5)"}
+                          "over one proxy step.  retrieve_plus_one_step_ms: the whole prefix, then the step; layerwise_ms: the "
+                          "layer-major pack of the pinned tier, one transfer + decode launch + event per layer range with "
+                          "the proxy's layers behind each event (DESIGN.md section 5)"}
     # the same question for the tier that can meet the target: encoded chunks resident in HBM (local_device="cuda",
     # local_serde="cachegen"), retrieved layer by layer on a side stream while the model's layers run
     ttft_proxy["hbm_tier"] = ttft_hbm_tier(dev, kv, proxy, alone, meta)

@@ -208,6 +208,66 @@ static inline uint64_t lmc_blob_bound(uint32_t L, uint32_t T, uint32_t H, uint32
   return (uint64_t)h.off_streams + (uint64_t)h.nplanes * h.ngroups * lmc_group_cap_bytes(T);
 }
 
+
+/* ---- pack: the blobs of ONE store call, laid out layer-major for the pinned host tier -------------------------
+ *
+ * A chunk's blob is chunk-major: header, static sections, then the streams of plane 0, 1, ...  Retrieving a context
+ * layer range by layer range from such blobs means one short copy per (chunk, K run, V run, range).  A pack holds the
+ * same bytes transposed, so that the streams of a range of LAYERS of all chunks are one contiguous region:
+ *
+ *   [0, 256)        lmc_pack_header
+ *   off_table       uint64 seg_off[2 L n + 1]: segment (layer, kv, chunk) -- index (2 layer + kv) n + chunk -- starts at
+ *                   off_streams + seg_off[index]; the last entry is the size of the streams region
+ *   off_static      n slots of static_stride bytes: bytes [0, off_streams) of chunk i's blob (header, bins, row prefix,
+ *                   scales, checksums, counts, stream directory), unchanged
+ *   off_streams     the segments, in table order; segment (layer, kv, chunk) = the streams of plane kv L + layer of
+ *                   chunk `chunk`: bytes [S, E) of the blob's streams section, S = r16(gend[p G - 1]) (0 for p = 0),
+ *                   E = r16(gend[(p + 1) G - 1])
+ * Every offset is a multiple of 16.  The blob of chunk i is recovered byte for byte from its static slot and its 2 L
+ * segments (lmc_pack_extract, lmc_hip.h); the pack is written by the GPU (lmc_store_pack) and read by lmc_load_pack. */
+#define LMC_PACK_MAGIC 0x4b504d4cu /* "LMPK" */
+#define LMC_PACK_VERSION 1u
+#define LMC_PACK_HEADER_BYTES 256u
+typedef struct lmc_pack_header {
+  uint32_t magic;
+  uint32_t version;
+  uint32_t header_bytes;
+  uint32_t nchunks;       /* n */
+  uint32_t num_layers;    /* L */
+  uint32_t num_heads;     /* H */
+  uint32_t head_size;     /* D */
+  uint32_t chunk_tokens;  /* tokens of every chunk but (possibly) the last */
+  uint32_t ngroups;       /* G */
+  uint32_t static_stride; /* bytes per static slot = r16(off_streams of a chunk_tokens-token blob) */
+  uint32_t ntokens;       /* tokens of all chunks together */
+  uint32_t reserved0;
+  uint64_t off_table;
+  uint64_t off_static;
+  uint64_t off_streams;
+  uint64_t total_bytes;   /* off_streams + seg_off[2 L n] */
+  uint32_t reserved[44];
+} lmc_pack_header;
+
+static inline uint64_t lmc_r16_64(uint64_t x) { return (x + 15u) & ~(uint64_t)15u; }
+/* Section offsets of a pack of n chunks (everything but total_bytes, which only the writer knows). */
+static inline void lmc_pack_layout(uint32_t n, uint32_t L, uint32_t chunk_tokens, uint32_t H, uint32_t D, uint32_t cdf_rows,
+                                   lmc_pack_header* h) {
+  lmc_blob_header b;
+  lmc_blob_layout(L, chunk_tokens, H, D, cdf_rows, &b);
+  h->magic = LMC_PACK_MAGIC; h->version = LMC_PACK_VERSION; h->header_bytes = LMC_PACK_HEADER_BYTES;
+  h->nchunks = n; h->num_layers = L; h->num_heads = H; h->head_size = D; h->chunk_tokens = chunk_tokens;
+  h->ngroups = b.ngroups; h->static_stride = lmc_r16(b.off_streams);
+  h->off_table = LMC_PACK_HEADER_BYTES;
+  h->off_static = lmc_r16_64(h->off_table + 8ull * (2ull * L * n + 1ull));
+  h->off_streams = h->off_static + (uint64_t)n * h->static_stride;
+}
+/* Worst-case size of a pack (every plane at 32 bins, every stream at its capacity). */
+static inline uint64_t lmc_pack_bound(uint32_t n, uint32_t L, uint32_t chunk_tokens, uint32_t H, uint32_t D) {
+  lmc_pack_header h;
+  lmc_pack_layout(n, L, chunk_tokens, H, D, 31u * 2u * L, &h);
+  return h.off_streams + (uint64_t)n * 2u * L * h.ngroups * lmc_group_cap_bytes(chunk_tokens);
+}
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,7 +45,7 @@ const char* lmc_strerror(int code);
 int lmc_last_hip_error(void);
 /* ABI version of this header. */
 int lmc_abi_version(void);
-#define LMC_ABI_VERSION 4
+#define LMC_ABI_VERSION 5
 
 /* ------------------------------------------------------------------ */
 /* KV addressing                                                       */
@@ -285,6 +285,37 @@ int lmc_store_chunks(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin, 
 int lmc_load_chunks(lmc_ctx* ctx, const void* const* host_blob_ptrs_h, const uint32_t* sizes_h, int32_t nchunks,
                     const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, int32_t layers_per_range,
                     lmc_event_t* range_events, uint32_t* job_status, lmc_stream_t stream);
+
+/*
+ * Packs: the layer-major form of the pinned host tier (lmc_format.h, "pack").  lmc_store_pack is lmc_store_chunks with
+ * the job's blobs written TRANSPOSED into one pinned region -- static sections of every chunk, then the streams ordered
+ * (layer, K/V, chunk) -- so that lmc_load_pack moves the streams of a range of layers as ONE hipMemcpyAsync and the
+ * model's first layers run while the later ranges are still crossing PCIe.  That is the order the consumer needs and
+ * the reference cannot produce: its chunks arrive whole, one `.to("cuda")` each (local_backend.py:128-144), and
+ * nothing can be decoded before the last one (cache_engine.py:339-381).
+ *
+ * lmc_store_pack: encode [tok_begin, tok_end) of `src` and write the pack to pack_h (pinned, device-mapped, pack_cap
+ *   bytes; lmc_pack_bound is the worst case, a Llama-3-8B context needs about a quarter of it) without any host wait.
+ *   sizes_h: pinned uint32 [nchunks], the blob sizes (0 = that chunk's encode failed).  Valid once `stream` has completed:
+ *   the pack header's total_bytes (0 and LMC_STATUS_HOST_ARENA_FULL if the pack did not fit or a chunk failed).
+ * lmc_pack_info: check a pack's header and offset table (host only), return the header.
+ * lmc_pack_extract: chunk `chunk` of a pack as the blob lmc_encode_chunks wrote, byte for byte (host only: the
+ *   one-chunk path of the backend, and how the tests pin a pack to the oracle).
+ * lmc_load_pack: the first `nchunks` chunks of the pack (0 = all) -> decoded KV in `dst`, chunk i at tokens
+ *   dst_tok0 + i * chunk_tokens.  Offset table and static slots go first, then per range of `layers_per_range` layers
+ *   (0 = all in one) the streams -- one copy per range for the whole pack, one per (layer, K/V) for a prefix of its
+ *   chunks -- each followed by the range's decode on `stream` and, if given, range_events[r].  The pack must stay where it
+ *   is until `stream` has completed.  LMC_ERR_INVALID, with nothing queued, if the pack does not check out.
+ */
+int lmc_store_pack(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
+                   const int32_t* bins_h, void* pack_h, uint64_t pack_cap, uint32_t* sizes_h, uint32_t* job_status,
+                   lmc_stream_t stream);
+int lmc_pack_info(const void* pack_h, uint64_t nbytes, lmc_pack_header* out);
+int lmc_pack_extract(const void* pack_h, uint64_t nbytes, int32_t chunk, void* blob_out, uint64_t cap, uint32_t* size_out);
+int lmc_load_pack(lmc_ctx* ctx, const void* pack_h, uint64_t pack_bytes, int32_t nchunks, const lmc_kv_layout* dst,
+                  int32_t dst_tok0, int32_t layers_per_range, lmc_event_t* range_events, uint32_t* job_status,
+                  lmc_stream_t stream);
+
 
 int lmc_stream_create(lmc_stream_t* out);
 int lmc_stream_destroy(lmc_stream_t s);

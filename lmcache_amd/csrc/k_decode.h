@@ -39,6 +39,11 @@ struct DecodeArgs {
   int8_t* sym_out;     // SYMOUT=true: [P][T][C] (single blob)
   int P, C, G;
   u32* status;
+  // pack (lmc_format.h): `blobs` / `blob_stride` are the static slots, the streams of plane (layer, kv) of chunk c lie at
+  // seg_streams + seg_off[(2 layer + kv) seg_n + c]
+  const unsigned long long* seg_off;
+  const u8* seg_streams;
+  int seg_n;
 };
 
 // LDS of a workgroup: the four waves' dequantisation LUTs (32 x f32 = 128 B each) FIRST -- their byte addresses stay
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       hdw(22) != (T == LMC_COUNTS_T ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16) ||
       hdw(8) != (u32)a.P || hdw(15) != bo.streams || cdf_rows > 31u * (u32)a.P || hdw(20) != dev_count_bytes(T) ||
       // every section offset is a function of the fields checked above; the blob must also fit its slot
-      (!SYMOUT && (T > (u32)a.chunk_tokens || (unsigned long long)hdw(17) > (unsigned long long)a.blob_stride))) {
+      (!SYMOUT && (T > (u32)a.chunk_tokens ||
+                   (unsigned long long)hdw(a.seg_off ? 15 : 17) > (unsigned long long)a.blob_stride))) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_HEADER);
     return;
   }
@@ -208,8 +214,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   const u32 prev_end = pg == 0 ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)gend[pg - 1]);
   const u32 start = (prev_end + 15u) & ~15u;
   const u16* words = reinterpret_cast<const u16*>(blob + bo.streams + start);
+  bool seg_bad = false;
+  if (a.seg_off) {  // pack: this plane's streams are a segment of their own, wave-uniform addresses
+    const int Lh = a.P >> 1, layer = p < Lh ? p : p - Lh;
+    const long long si = (long long)(2 * layer + (p >= Lh ? 1 : 0)) * a.seg_n + chunk;
+    const unsigned long long so = uniform_ptr((const void*)a.seg_off[si]), se = uniform_ptr((const void*)a.seg_off[si + 1]);
+    const u32 pg0 = (u32)(p * a.G);
+    const u32 sbeg = pg0 ? ((u32)__builtin_amdgcn_readfirstlane((int)gend[pg0 - 1]) + 15u) & ~15u : 0u;
+    seg_bad = start < sbeg || se < so || (unsigned long long)end - sbeg > se - so;
+    words = reinterpret_cast<const u16*>(a.seg_streams + so + (start - sbeg));
+  }
   // 64-bit comparisons: a corrupt directory entry must not wrap its way past the bounds
-  if (prev_end > 0xfffffff0u || (unsigned long long)end < (unsigned long long)start + 256ull ||
+  if (seg_bad || prev_end > 0xfffffff0u || (unsigned long long)end < (unsigned long long)start + 256ull ||
       (unsigned long long)bo.streams + (unsigned long long)end > (unsigned long long)hdw(17)) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_STREAM);
     return;

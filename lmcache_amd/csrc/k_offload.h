@@ -77,3 +77,98 @@ __global__ __launch_bounds__(256) void k_offload(OffloadArgs a) {
   for (; i < n16; i += step) dst[i] = src[i];
 }
 
+
+// ---- pack: the blobs of one store call, transposed layer-major on their way to the pinned arena (lmc_format.h) ---
+//
+// k_pack_scan   one workgroup: the size of every (layer, kv, chunk) segment from the blobs' stream directories, their
+//               exclusive prefix sums in table order -> the pack's offset table (pinned, and a device copy for the
+//               copy kernel), the pack header with its total size.
+// k_pack_copy   a fixed number of workgroups walk the segments and the static slots and write them into the mapped
+//               pinned region (16-byte accesses, four loads in flight per thread; PCIe-bound like k_offload).
+struct PackArgs {
+  const u8* blobs;              // device arena, blob i at blobs + i * stride (what lmc_encode_chunks wrote)
+  long long stride;
+  const u32* sizes_d;           // [n] blob sizes (0: the chunk's encode failed)
+  int n, L, G;
+  u8* host;                     // pinned, device-mapped: where the pack goes
+  unsigned long long cap;
+  unsigned long long* table_d;  // device copy of the offset table, [2 L n + 1]
+  lmc_pack_header hdr;          // filled in by the host but for total_bytes
+  u32* status;
+};
+
+__device__ __forceinline__ u32 pack_seg_bytes(const PackArgs& a, int idx, u32* begin) {
+  const int lk = idx / a.n, chunk = idx - lk * a.n;
+  const int p = (lk & 1) * a.L + (lk >> 1);
+  const u8* blob = a.blobs + (long long)chunk * a.stride;
+  const u32* hd = reinterpret_cast<const u32*>(blob);
+  const u32* gend = reinterpret_cast<const u32*>(blob + hd[14]);
+  const u32 s = p ? (gend[p * a.G - 1] + 15u) & ~15u : 0u;
+  const u32 e = (gend[(p + 1) * a.G - 1] + 15u) & ~15u;
+  if (begin) *begin = hd[15] + s;
+  return a.sizes_d[chunk] != 0u && e >= s && (unsigned long long)hd[15] + e <= (unsigned long long)a.stride ? e - s : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_pack_scan(PackArgs a) {
+  __shared__ unsigned long long sums[256];
+  const int N = 2 * a.L * a.n, K = (N + 255) / 256;
+  const int t = (int)threadIdx.x, i0 = t * K, i1 = min(N, i0 + K);
+  unsigned long long mine = 0;
+  for (int i = i0; i < i1; i++) mine += pack_seg_bytes(a, i, nullptr);
+  sums[t] = mine;
+  __syncthreads();
+  unsigned long long off = 0, total = 0;
+  for (int j = 0; j < 256; j++) {  // 256 adds per thread: one launch per store
+    off += j < t ? sums[j] : 0ull;
+    total += sums[j];
+  }
+  bool bad = false;
+  for (int j = 0; j < a.n; j++) bad |= a.sizes_d[j] == 0u;
+  const bool fits = !bad && a.hdr.off_streams + total <= a.cap;
+  unsigned long long* table_h = reinterpret_cast<unsigned long long*>(a.host + a.hdr.off_table);
+  for (int i = i0; i < i1; i++) {
+    a.table_d[i] = off;
+    if (fits) table_h[i] = off;
+    off += pack_seg_bytes(a, i, nullptr);
+  }
+  if (t == 0) {
+    a.table_d[N] = fits ? total : ~0ull;  // all ones: nothing is copied
+    if (fits) table_h[N] = total;
+    lmc_pack_header h = a.hdr;
+    h.total_bytes = fits ? a.hdr.off_streams + total : 0ull;  // 0: not a pack
+    if (!fits) h.magic = 0u;
+    *reinterpret_cast<lmc_pack_header*>(a.host) = h;
+    if (!fits) atomicOr(a.status, LMC_ST_HOST_ARENA_FULL);
+  }
+}
+
+__device__ __forceinline__ void pack_copy16(uint4* dst, const uint4* src, u32 n16) {
+  const u32 step = 256u;
+  u32 i = threadIdx.x;
+  for (; i + 3u * step < n16; i += 4u * step) {
+    const uint4 v0 = src[i], v1 = src[i + step], v2 = src[i + 2u * step], v3 = src[i + 3u * step];
+    dst[i] = v0; dst[i + step] = v1; dst[i + 2u * step] = v2; dst[i + 3u * step] = v3;
+  }
+  for (; i < n16; i += step) dst[i] = src[i];
+}
+
+// grid = (workgroups), 256 threads: workgroup w takes items w, w + gridDim.x, ... of the 2 L n segments + n static slots
+__global__ __launch_bounds__(256) void k_pack_copy(PackArgs a) {
+  const int N = 2 * a.L * a.n;
+  if (a.table_d[N] == ~0ull) return;
+  for (int item = (int)blockIdx.x; item < N + a.n; item += (int)gridDim.x) {
+    if (item < N) {
+      u32 begin;
+      const u32 bytes = pack_seg_bytes(a, item, &begin);
+      const int chunk = item % a.n;
+      pack_copy16(reinterpret_cast<uint4*>(a.host + a.hdr.off_streams + a.table_d[item]),
+                  reinterpret_cast<const uint4*>(a.blobs + (long long)chunk * a.stride + begin), bytes >> 4);
+    } else {
+      const int chunk = item - N;
+      const u8* blob = a.blobs + (long long)chunk * a.stride;
+      const u32 bytes = min((reinterpret_cast<const u32*>(blob)[15] + 15u) & ~15u, a.hdr.static_stride);
+      pack_copy16(reinterpret_cast<uint4*>(a.host + a.hdr.off_static + (unsigned long long)chunk * a.hdr.static_stride),
+                  reinterpret_cast<const uint4*>(blob), bytes >> 4);
+    }
+  }
+}

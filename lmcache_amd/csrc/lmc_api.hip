@@ -45,6 +45,8 @@ struct lmc_ctx {
   int pre_step = 0;                     // fused encode: every pre_step-th workgroup of the first generation gets a head start
                                         // (0: none -- measured 1.06 ms without, 1.07-1.09 with 2 / 3 / 4: k_fused.h)
   u32 epoch = 0;                        // of the last fused launch (tags its look-back granules)
+  unsigned long long* pack_table = nullptr;  // device copy of a pack's offset table while it is written (lmc_store_pack)
+  size_t pack_table_bytes = 0;
   // store / load legs (lmc_store_chunks, lmc_load_chunks)
   u8* store_arena = nullptr; size_t store_bytes = 0;  // blobs of the job being offloaded
   u8* load_slots = nullptr; size_t load_bytes = 0;    // HBM slots the gather kernel fills
@@ -119,6 +121,7 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   if (c->copy_stream2) { (void)hipStreamSynchronize(c->copy_stream2); (void)hipStreamDestroy(c->copy_stream2); }
   if (c->store_arena) (void)hipFree(c->store_arena);
   if (c->load_slots) (void)hipFree(c->load_slots);
+  if (c->pack_table) (void)hipFree(c->pack_table);
   if (c->store_free) (void)hipEventDestroy(c->store_free);
   if (c->load_free) (void)hipEventDestroy(c->load_free);
   for (int i = 0; i < 64; i++) if (c->evpool[i]) (void)hipEventDestroy(c->evpool[i]);
@@ -458,6 +461,7 @@ static int decode_common(lmc_ctx* c, const void* blobs, uint64_t blob_stride, in
   if (!c || !blobs || nchunks < 1 || ((uintptr_t)blobs & 15) || (blob_stride & 15)) return LMC_ERR_INVALID;
   a.blobs = (const u8*)blobs; a.blob_stride = (long long)blob_stride; a.nchunks = nchunks;
   a.blob_ptrs = nullptr; a.layer_begin = 0; a.layer_count = L;
+  a.seg_off = nullptr; a.seg_streams = nullptr; a.seg_n = 0;
   a.P = 2 * L; a.C = H * D; a.G = (a.C + 63) / 64;
   a.status = job_status ? job_status : c->status_h;
   return LMC_OK;
@@ -682,7 +686,7 @@ int lmc_load_chunks(lmc_ctx* c, const void* const* host_blob_ptrs_h, const uint3
                     lmc_event_t* range_events, uint32_t* job_status, lmc_stream_t stream) {
   if (!c || !host_blob_ptrs_h || !sizes_h || nchunks < 1 || !layout_ok(dst) || chunk_tokens < 1 || layers_per_range < 0)
     return LMC_ERR_INVALID;
-  const int L = dst->num_layers, H = dst->num_heads, D = dst->head_size, P = 2 * L, G = (H * D + 63) / 64;
+  const int L = dst->num_layers, H = dst->num_heads, D = dst->head_size;
   if (H * D > LMC_MAX_CHANNELS) return LMC_ERR_INVALID;
   const uint64_t stride = (lmc_blob_bound((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D) + 15) & ~(uint64_t)15;
   HIP_TRY(hipSetDevice(c->device));
@@ -747,7 +751,195 @@ int lmc_load_chunks(lmc_ctx* c, const void* const* host_blob_ptrs_h, const uint3
   }
   HIP_TRY(hipEventRecord(c->load_free, s));
   c->load_used = true;
-  (void)P;
+  return LMC_OK;
+}
+
+// ---- packs (lmc_format.h): the layer-major form of the pinned host tier ---------------------------------------------
+int lmc_store_pack(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
+                   const int32_t* bins_h, void* pack_h, uint64_t pack_cap, uint32_t* sizes_h, uint32_t* job_status,
+                   lmc_stream_t stream) {
+  if (!c || !layout_ok(src) || tok_begin < 0 || tok_end <= tok_begin || chunk_tokens < 1 || chunk_tokens > 65535 || !bins_h ||
+      !pack_h || ((uintptr_t)pack_h & 15) || !sizes_h)
+    return LMC_ERR_INVALID;
+  const int nchunks = (tok_end - tok_begin + chunk_tokens - 1) / chunk_tokens;
+  const int L = src->num_layers, P = 2 * L;
+  if (nchunks > 65535 || (long long)P * nchunks > (1ll << 22)) return LMC_ERR_INVALID;
+  uint32_t rows = 0;
+  for (int p = 0; p < P; p++) {
+    if (bins_h[p] < 4 || bins_h[p] > LMC_MAX_BINS) return LMC_ERR_INVALID;
+    rows += lmc_cdf_row((uint32_t)bins_h[p]);
+  }
+  PackArgs pa;
+  memset(&pa, 0, sizeof pa);
+  lmc_pack_layout((uint32_t)nchunks, (uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)src->num_heads, (uint32_t)src->head_size, rows,
+                  &pa.hdr);
+  pa.hdr.ntokens = (uint32_t)(tok_end - tok_begin);
+  if (pa.hdr.off_streams > pack_cap) return LMC_ERR_INVALID;
+  const uint64_t stride = (lmc_blob_bound((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)src->num_heads,
+                                          (uint32_t)src->head_size) + 15) & ~(uint64_t)15;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  const size_t table_bytes = 8 * ((size_t)P * nchunks + 1);
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if ((rc = legs_init(c))) return rc;
+    if (c->store_bytes < (size_t)nchunks * stride || c->pack_table_bytes < table_bytes) {
+      if (c->store_used) HIP_TRY(hipEventSynchronize(c->store_free));  // growing frees the buffers: this call only
+      if (c->store_bytes < (size_t)nchunks * stride &&
+          (rc = ws_grow((void**)&c->store_arena, &c->store_bytes, (size_t)nchunks * stride)))
+        return rc;
+      if (c->pack_table_bytes < table_bytes && (rc = ws_grow((void**)&c->pack_table, &c->pack_table_bytes, table_bytes))) return rc;
+    }
+    if (c->store_used) HIP_TRY(hipStreamWaitEvent(s, c->store_free, 0));  // the previous job's copies have read the arena
+  }
+  // the segment offsets need every chunk's stream directory: the whole job is encoded (1 ms per 16 k tokens) before the
+  // first byte leaves (11 ms over PCIe) -- the part-wise overlap of lmc_store_chunks would save less than a tenth
+  if ((rc = lmc_encode_chunks(c, src, tok_begin, tok_end, chunk_tokens, bins_h, c->store_arena, stride, sizes_h, job_status, stream)))
+    return rc;
+  std::lock_guard<std::mutex> lk(c->mu);
+  hipEvent_t ev;
+  if ((rc = next_event(c, &ev))) return rc;
+  HIP_TRY(hipEventRecord(ev, s));
+  HIP_TRY(hipStreamWaitEvent(c->copy_stream, ev, 0));
+  pa.blobs = c->store_arena; pa.stride = (long long)stride; pa.sizes_d = sizes_h;
+  pa.n = nchunks; pa.L = L; pa.G = (int)pa.hdr.ngroups;
+  pa.host = (u8*)pack_h; pa.cap = pack_cap; pa.table_d = c->pack_table;
+  pa.status = job_status ? job_status : c->status_h;
+  hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(256), 0, c->copy_stream, pa);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_pack_copy, dim3(64), dim3(256), 0, c->copy_stream, pa);  // PCIe-bound: 64 workgroups fill the link
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->store_free, c->copy_stream));
+  c->store_used = true;
+  HIP_TRY(hipStreamWaitEvent(s, c->store_free, 0));  // the caller's stream is done when the pack has landed
+  return LMC_OK;
+}
+
+// Host-side check of a pack that lies in (pinned) host memory.
+static bool pack_ok(const u8* b, uint64_t nbytes, lmc_pack_header* h) {
+  if (!b || ((uintptr_t)b & 15) || nbytes < LMC_PACK_HEADER_BYTES) return false;
+  memcpy(h, b, sizeof *h);
+  if (h->magic != LMC_PACK_MAGIC || h->version != LMC_PACK_VERSION || h->header_bytes != LMC_PACK_HEADER_BYTES) return false;
+  if (h->nchunks < 1 || h->nchunks > 65535 || h->num_layers < 1 || h->num_layers > LMC_MAX_PLANES / 2 || h->num_heads == 0 ||
+      h->head_size == 0 || h->chunk_tokens < 1 || h->chunk_tokens > 65535 || (h->static_stride & 15) ||
+      h->static_stride < sizeof(lmc_blob_header))
+    return false;
+  const uint64_t N = 2ull * h->num_layers * h->nchunks;
+  if (h->off_table != LMC_PACK_HEADER_BYTES || h->off_static != lmc_r16_64(h->off_table + 8 * (N + 1)) ||
+      h->off_streams != h->off_static + (uint64_t)h->nchunks * h->static_stride || h->total_bytes > nbytes ||
+      h->total_bytes < h->off_streams)
+    return false;
+  const uint64_t* t = (const uint64_t*)(b + h->off_table);
+  if (t[0] != 0 || t[N] != h->total_bytes - h->off_streams) return false;
+  for (uint64_t i = 0; i < N; i++)
+    if (t[i + 1] < t[i] || (t[i] & 15)) return false;
+  return true;
+}
+
+int lmc_pack_info(const void* pack_h, uint64_t nbytes, lmc_pack_header* out) {
+  lmc_pack_header h;
+  if (!out || !pack_ok((const u8*)pack_h, nbytes, &h)) return LMC_ERR_INVALID;
+  *out = h;
+  return LMC_OK;
+}
+
+int lmc_pack_extract(const void* pack_h, uint64_t nbytes, int32_t chunk, void* blob_out, uint64_t cap, uint32_t* size_out) {
+  lmc_pack_header h;
+  const u8* b = (const u8*)pack_h;
+  if (!pack_ok(b, nbytes, &h) || chunk < 0 || (uint32_t)chunk >= h.nchunks || !blob_out || !size_out) return LMC_ERR_INVALID;
+  const u8* st = b + h.off_static + (uint64_t)chunk * h.static_stride;
+  lmc_blob_header bh;
+  memcpy(&bh, st, sizeof bh);
+  // the static slot is the head of the blob: its header says how long the head and the whole blob are
+  if (bh.magic != LMC_BLOB_MAGIC || bh.off_streams > h.static_stride || bh.off_streams < sizeof bh ||
+      bh.total_bytes != bh.off_streams + bh.stream_bytes || bh.total_bytes > cap || bh.num_layers != h.num_layers)
+    return LMC_ERR_INVALID;
+  memcpy(blob_out, st, bh.off_streams);
+  const uint64_t* t = (const uint64_t*)(b + h.off_table);
+  const uint32_t L = h.num_layers, n = h.nchunks;
+  uint64_t at = bh.off_streams;
+  for (uint32_t p = 0; p < 2 * L; p++) {  // plane order of the blob: K planes of every layer, then V planes
+    const uint32_t layer = p < L ? p : p - L, kv = p < L ? 0u : 1u;
+    const uint64_t i = (uint64_t)(2 * layer + kv) * n + (uint32_t)chunk;
+    const uint64_t len = t[i + 1] - t[i];
+    if (at + len > bh.total_bytes) return LMC_ERR_INVALID;
+    memcpy((u8*)blob_out + at, b + h.off_streams + t[i], len);
+    at += len;
+  }
+  if (at != bh.total_bytes) return LMC_ERR_INVALID;
+  *size_out = bh.total_bytes;
+  return LMC_OK;
+}
+
+int lmc_load_pack(lmc_ctx* c, const void* pack_h, uint64_t pack_bytes, int32_t nchunks, const lmc_kv_layout* dst,
+                  int32_t dst_tok0, int32_t layers_per_range, lmc_event_t* range_events, uint32_t* job_status,
+                  lmc_stream_t stream) {
+  lmc_pack_header h;
+  if (!c || !layout_ok(dst) || layers_per_range < 0 || nchunks < 0 || !pack_ok((const u8*)pack_h, pack_bytes, &h))
+    return LMC_ERR_INVALID;
+  const int L = dst->num_layers, H = dst->num_heads, D = dst->head_size;
+  if ((uint32_t)L != h.num_layers || (uint32_t)H != h.num_heads || (uint32_t)D != h.head_size || H * D > LMC_MAX_CHANNELS ||
+      (uint32_t)nchunks > h.nchunks)
+    return LMC_ERR_INVALID;
+  const int n = (int)h.nchunks, m = nchunks ? nchunks : n;  // the first m chunks of the pack
+  const u8* b = (const u8*)pack_h;
+  const uint64_t* t = (const uint64_t*)(b + h.off_table);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  const int step = layers_per_range > 0 && layers_per_range < L ? layers_per_range : L;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if ((rc = legs_init(c))) return rc;
+  if (c->load_bytes < h.total_bytes) {
+    if (c->load_used) HIP_TRY(hipEventSynchronize(c->load_free));
+    if ((rc = ws_grow((void**)&c->load_slots, &c->load_bytes, (size_t)h.total_bytes))) return rc;
+  }
+  hipStream_t cs = c->copy_stream;  // ONE queue: the ranges must arrive in layer order
+  if (c->load_used) HIP_TRY(hipStreamWaitEvent(cs, c->load_free, 0));  // the previous load's decodes have read the buffer
+  // the device copy keeps the pack's offsets: table, static slots and segments land where they lie in the pack
+  u8* dev = c->load_slots;
+  HIP_TRY(hipMemcpyAsync(dev + h.off_table, b + h.off_table, 8 * (2 * (size_t)L * n + 1), hipMemcpyHostToDevice, cs));
+  HIP_TRY(hipMemcpyAsync(dev + h.off_static, b + h.off_static, (size_t)m * h.static_stride, hipMemcpyHostToDevice, cs));
+  DecodeArgs da;
+  memset(&da, 0, sizeof da);
+  if ((rc = decode_common(c, dev + h.off_static, h.static_stride, m, L, H, D, job_status, da))) return rc;
+  da.dst = to_addr(dst); da.dst_tok0 = dst_tok0; da.chunk_tokens = (int)h.chunk_tokens;
+  da.seg_off = (const unsigned long long*)(dev + h.off_table); da.seg_streams = dev + h.off_streams; da.seg_n = n;
+  int r = 0;
+  for (int l0 = 0; l0 < L; l0 += step, r++) {
+    const int nl = l0 + step <= L ? step : L - l0;
+    // the streams of layers l0 .. l0 + nl: one contiguous region when the whole pack is wanted, else one run of the
+    // first m chunks per (layer, kv)
+    if (m == n) {
+      const uint64_t lo = t[(uint64_t)2 * l0 * n], hi = t[(uint64_t)2 * (l0 + nl) * n];
+      if (hi > lo) HIP_TRY(hipMemcpyAsync(dev + h.off_streams + lo, b + h.off_streams + lo, hi - lo, hipMemcpyHostToDevice, cs));
+    } else {
+      for (int lk = 2 * l0; lk < 2 * (l0 + nl); lk++) {
+        const uint64_t lo = t[(uint64_t)lk * n], hi = t[(uint64_t)lk * n + m];
+        if (hi > lo) HIP_TRY(hipMemcpyAsync(dev + h.off_streams + lo, b + h.off_streams + lo, hi - lo, hipMemcpyHostToDevice, cs));
+      }
+    }
+    hipEvent_t ev;
+    if ((rc = next_event(c, &ev))) return rc;
+    HIP_TRY(hipEventRecord(ev, cs));
+    HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+    da.layer_begin = l0; da.layer_count = nl;
+    const long long nstreams = (long long)m * 2 * nl * da.G;
+    const dim3 grid((unsigned)((nstreams + 3) / 4));
+    const bool paged = dst->slot_mapping != nullptr;
+    if (dst->dtype == LMC_DTYPE_BF16) {
+      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, true>), grid, dim3(256), 0, s, da);
+      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, false>), grid, dim3(256), 0, s, da);
+    } else {
+      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, true>), grid, dim3(256), 0, s, da);
+      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, false>), grid, dim3(256), 0, s, da);
+    }
+    HIP_TRY(hipGetLastError());
+    if (range_events && range_events[r]) HIP_TRY(hipEventRecord((hipEvent_t)range_events[r], s));
+  }
+  HIP_TRY(hipEventRecord(c->load_free, s));
+  c->load_used = true;
   return LMC_OK;
 }
 

@@ -62,6 +62,15 @@ class BlobHeader(ctypes.Structure):
                 ("reserved", ctypes.c_uint32 * 9)]
 
 
+class PackHeader(ctypes.Structure):
+    _fields_ = [("magic", ctypes.c_uint32), ("version", ctypes.c_uint32), ("header_bytes", ctypes.c_uint32),
+                ("nchunks", ctypes.c_uint32), ("num_layers", ctypes.c_uint32), ("num_heads", ctypes.c_uint32),
+                ("head_size", ctypes.c_uint32), ("chunk_tokens", ctypes.c_uint32), ("ngroups", ctypes.c_uint32),
+                ("static_stride", ctypes.c_uint32), ("ntokens", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+                ("off_table", ctypes.c_uint64), ("off_static", ctypes.c_uint64), ("off_streams", ctypes.c_uint64),
+                ("total_bytes", ctypes.c_uint64), ("reserved", ctypes.c_uint32 * 44)]
+
+
 # name -> (restype, argtypes); every symbol include/lmc_hip.h declares
 _vp, _i32, _u64, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64, ctypes.c_size_t
 _PL = ctypes.POINTER(KvLayoutStruct)
@@ -84,6 +93,10 @@ SYMBOLS = {
     "lmc_decode_symbols": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "lmc_store_chunks": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     "lmc_load_chunks": (ctypes.c_int, [_vp, _vp, _vp, _i32, _PL, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "lmc_store_pack": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp, _vp]),
+    "lmc_pack_info": (ctypes.c_int, [_vp, _u64, ctypes.POINTER(PackHeader)]),
+    "lmc_pack_extract": (ctypes.c_int, [_vp, _u64, _i32, _vp, _u64, _vp]),
+    "lmc_load_pack": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _vp, _vp, _vp]),
     "lmc_copy_kv": (ctypes.c_int, [_vp, _PL, _i32, _i32, _PL, _i32, _vp]),
     "lmc_pinned_alloc": (ctypes.c_int, [_sz, ctypes.POINTER(_vp)]),
     "lmc_pinned_free": (ctypes.c_int, [_vp]),
@@ -124,7 +137,7 @@ def lib() -> ctypes.CDLL:
             for name, (res, args) in SYMBOLS.items():
                 fn = getattr(L, name)  # AttributeError if the ABI and this binding drift apart
                 fn.restype, fn.argtypes = res, args
-            if L.lmc_abi_version() != 4:
+            if L.lmc_abi_version() != 5:
                 raise NativeError("liblmc_hip.so ABI version mismatch; rebuild")
             _lib = L
     return _lib
@@ -147,6 +160,30 @@ def dtype_code(dt: torch.dtype) -> int:
 
 def torch_dtype(code: int) -> torch.dtype:
     return torch.bfloat16 if code == BF16 else torch.float16
+
+
+def pack_info(pack_ptr: int, nbytes: int) -> PackHeader:
+    """Checked header of a pack in host memory (lmc_pack_info); raises NativeError if it does not check out."""
+    h = PackHeader()
+    check(lib().lmc_pack_info(pack_ptr, nbytes, ctypes.byref(h)), "lmc_pack_info")
+    return h
+
+
+def pack_extract(pack_ptr: int, nbytes: int, chunk: int) -> bytes:
+    """Chunk `chunk` of a pack as the blob lmc_encode_chunks wrote (lmc_pack_extract)."""
+    h = pack_info(pack_ptr, nbytes)
+    cap = blob_bound(h.num_layers, h.chunk_tokens, h.num_heads, h.head_size)
+    buf = ctypes.create_string_buffer(cap)
+    size = ctypes.c_uint32(0)
+    check(lib().lmc_pack_extract(pack_ptr, nbytes, chunk, buf, cap, ctypes.byref(size)), "lmc_pack_extract")
+    return buf.raw[:size.value]
+
+
+def pack_bound(n: int, L: int, chunk_tokens: int, H: int, D: int) -> int:
+    """lmc_pack_bound (lmc_format.h): worst-case bytes of a pack of n chunks."""
+    G = (H * D + LANES - 1) // LANES
+    static = r16(blob_static_bytes(L, chunk_tokens, H, D))
+    return r16(256 + 8 * (2 * L * n + 1)) + n * static + n * 2 * L * G * group_cap_bytes(chunk_tokens)
 
 
 def r16(x: int) -> int:
@@ -532,6 +569,23 @@ class Context:
         st = current_stream_ptr(dst.device) if stream is None else stream
         check(lib().lmc_load_chunks(self.handle, host_ptrs_ptr, sizes_ptr, nchunks, ctypes.byref(dst.struct), dst_tok0,
                                     chunk_tokens, layers_per_range, range_events_ptr, status_ptr, st), "lmc_load_chunks")
+
+    def store_pack(self, src: KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int, bins, pack_ptr: int, pack_cap: int,
+                   sizes_ptr: int, stream: Optional[int] = None, status_ptr: Optional[int] = None) -> int:
+        """lmc_store_pack: encode + the job's blobs transposed layer-major into one pinned region, no host wait."""
+        b = self._bins(bins)
+        st = current_stream_ptr(src.device) if stream is None else stream
+        check(lib().lmc_store_pack(self.handle, ctypes.byref(src.struct), tok_begin, tok_end, chunk_tokens, b, pack_ptr, pack_cap,
+                                   sizes_ptr, status_ptr, st), "lmc_store_pack")
+        return (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
+
+    def load_pack(self, pack_ptr: int, pack_bytes: int, nchunks: int, dst: KVLayout, dst_tok0: int, layers_per_range: int = 0,
+                  range_events_ptr: Optional[int] = None, stream: Optional[int] = None, status_ptr: Optional[int] = None) -> None:
+        """lmc_load_pack: the first nchunks chunks (0 = all) of a pack in pinned host memory -> decoded KV, one transfer
+        and one decode per range of layers."""
+        st = current_stream_ptr(dst.device) if stream is None else stream
+        check(lib().lmc_load_pack(self.handle, pack_ptr, pack_bytes, nchunks, ctypes.byref(dst.struct), dst_tok0, layers_per_range,
+                                  range_events_ptr, status_ptr, st), "lmc_load_pack")
 
     def decode_symbols(self, blob: torch.Tensor, L: int, H: int, D: int, T: int, stream: Optional[int] = None
                        ) -> torch.Tensor:

@@ -25,6 +25,8 @@ All three implement the optional put_kv_range / get_kv_range protocol
 (cache_engine.py:98-161) nor the final torch.cat (:362-368): KV is gathered
 from / scattered to the caller's tensors by the HIP kernels.
 """
+import ctypes
+import os
 import queue
 import threading
 from dataclasses import dataclass
@@ -38,7 +40,7 @@ from lmcache_amd.logging import init_logger
 from lmcache_amd.storage_backend.abstract_backend import LMCBackendInterface
 from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
 from lmcache_amd.storage_backend.serde.cachegen_decoder import output_spec
-from lmcache_amd.storage_backend.serde.cachegen_device import DeviceArena, HostBlob, PinnedArena, get_codec
+from lmcache_amd.storage_backend.serde.cachegen_device import DeviceArena, HostBlob, HostPack, PinnedArena, get_codec
 from lmcache_amd.utils import CacheEngineKey, _lmcache_nvtx_annotate
 
 logger = init_logger(__name__)
@@ -62,6 +64,18 @@ class _HostChunk:
     shape: Tuple[int, ...]             # chunk tensor shape in the engine's fmt
     dtype: torch.dtype
     encoded: bool
+
+
+@dataclass
+class _PackChunk:
+    """Chunk `index` of a pack: the blobs of one put_kv_range() call, stored layer-major in pinned host DRAM."""
+    pack: HostPack
+    index: int
+    shape: Tuple[int, ...]
+    dtype: torch.dtype
+    blob: Optional[HostBlob] = None    # the chunk as a blob of its own, reassembled on first single-chunk use
+    encoded: bool = True
+    ready: Optional[torch.cuda.Event] = None
 
 
 def _chunk_shape(fmt: str, L: int, T: int, H: int, D: int) -> Tuple[int, ...]:
@@ -104,6 +118,10 @@ class LMCLocalBackend(LMCBackendInterface):
         self.dict: Dict[CacheEngineKey, Union[torch.Tensor, _HostChunk]] = {}
         self.update_lock = threading.Lock()
         self.host_arena = PinnedArena() if self.mode in ("raw", "cachegen") else None
+        # pinned CacheGen tier: a put_kv_range() of several chunks is stored as ONE layer-major pack (lmc_store_pack), so
+        # that a retrieve of the same prefix moves a range of layers as one transfer (LMCACHE_AMD_PINNED_PACKS=0: one
+        # blob per chunk, as the reference stores them)
+        self.pack_stores = self.mode == "cachegen" and os.environ.get("LMCACHE_AMD_PINNED_PACKS", "1") != "0"
         self.dev_arena: Optional[DeviceArena] = None   # hbm-cachegen: created on first use, on the KV's device
         self._stage: Optional[torch.Tensor] = None   # device staging for raw gathers / scatters
         self._stage_free: Optional[torch.cuda.Event] = None
@@ -169,6 +187,21 @@ class LMCLocalBackend(LMCBackendInterface):
         for key, hb, shp in zip(keys, blobs, shapes):
             self._publish(key, _HostChunk(hb, None, shp, dtype, True))
 
+    def _finish_pack(self, keys: Sequence[CacheEngineKey], job, shapes, dtype) -> None:
+        pack = self._codec().finish_pack(job, self.host_arena)
+        for i, (key, shp) in enumerate(zip(keys, shapes)):
+            self._publish(key, _PackChunk(pack, i, shp, dtype))
+
+    def _own_blob(self, e: _PackChunk) -> HostBlob:
+        """A pack's chunk as a blob of its own in the pinned arena (the single-chunk paths: get(), a retrieve that mixes
+        chunks of different stores)."""
+        if e.blob is None:
+            data = e.pack.extract(e.index)
+            hb = self.host_arena.alloc(len(data))
+            ctypes.memmove(hb.ptr, data, len(data))
+            e.blob = hb
+        return e.blob
+
     def _put_chunk_now(self, key: CacheEngineKey, kv_chunk: torch.Tensor, fmt: str) -> None:
         if not kv_chunk.is_cuda:
             kv_chunk = kv_chunk.to(self.dst_device)
@@ -227,9 +260,12 @@ class LMCLocalBackend(LMCBackendInterface):
             T = entry.shape[2] if fmt == "vllm" else entry.shape[3]
             codec = self._codec()
             try:
-                codec.finish_decode(codec.decode([entry.blob], native.KVLayout.from_chunk(out, fmt), 0, T))
+                blob = self._own_blob(entry) if isinstance(entry, _PackChunk) else entry.blob
+                codec.finish_decode(codec.decode([blob], native.KVLayout.from_chunk(out, fmt), 0, T))
             except native.NativeError:
                 logger.exception("stored chunk does not decode: treated as a miss")
+                if isinstance(entry, _PackChunk):
+                    entry.blob = None  # reassembled again from the pack next time
                 return None
         else:
             cur = torch.cuda.current_stream(dev)
@@ -262,6 +298,15 @@ class LMCLocalBackend(LMCBackendInterface):
         dev = src.device
         if self.mode in ("cachegen", "hbm-cachegen"):
             _, out_dt = output_spec(fmt, 1, 1, 1, 8)
+            if self.pack_stores and n >= 2:
+                with torch.cuda.device(dev):
+                    pjob = self._codec().store_pack(src, tok_begin, tok_end, chunk_tokens, self.cachegen_config.plane_bins(L),
+                                                    self.host_arena)
+                if blocking:
+                    self._finish_pack(keys, pjob, shapes, out_dt)
+                else:
+                    self.put_queue.put(lambda: self._finish_pack(list(keys), pjob, shapes, out_dt))
+                return n
             with torch.cuda.device(dev):
                 job = self._codec().encode(src, tok_begin, tok_end, chunk_tokens, self.cachegen_config.plane_bins(L))
             if blocking:
@@ -345,6 +390,19 @@ class LMCLocalBackend(LMCBackendInterface):
             return len(entries)
         if self.mode == "cachegen":
             codec = self._codec()
+            e0 = entries[0]
+            if isinstance(e0, _PackChunk) and all(isinstance(e, _PackChunk) and e.pack is e0.pack and e.index == i
+                                                  for i, e in enumerate(entries)) and e0.pack.chunk_tokens == chunk_tokens:
+                # the leading chunks of ONE pack: a transfer and a decode per range of layers (lmc_load_pack)
+                with torch.cuda.device(dev):
+                    job = codec.load_pack(e0.pack, len(entries), dst, dst_tok0, layers_per_launch)
+                if layers_per_launch and jobs_out is not None:
+                    jobs_out.append((codec, job))
+                else:
+                    codec.finish_decode(job)
+                return len(entries)
+            entries = [_HostChunk(self._own_blob(e), None, e.shape, e.dtype, True) if isinstance(e, _PackChunk) else e
+                       for e in entries]
             if layers_per_launch and jobs_out is not None:
                 # pinned tier cut by layers (engine.retrieve_layerwise): one lmc_load_chunks call gathers and decodes
                 # range after range; the caller's layers wait for their range's event only

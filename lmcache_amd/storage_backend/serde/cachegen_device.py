@@ -36,13 +36,15 @@ class PinnedArena:
         self._lock = threading.Lock()
         self.total_allocated = 0
 
-    def alloc(self, nbytes: int) -> "HostBlob":
+    def alloc(self, nbytes: int, slab_hint: int = 0) -> "HostBlob":
+        """slab_hint: size of the slab to allocate if a new one is needed (a pack is allocated at its bound and cut
+        to its size afterwards: a slab of a few bounds keeps the cut-off tails usable)."""
         need = native.r16(max(nbytes, 16))
         with self._lock:
             if not self._slabs or self._used + need > self._slabs[-1].nbytes:
                 k = next((i for i, b in enumerate(self._spare) if b.nbytes >= need), None)
                 self._slabs.append(self._spare.pop(k) if k is not None
-                                   else native.PinnedBuffer(max(self.slab_bytes, need)))
+                                   else native.PinnedBuffer(max(self.slab_bytes, need, slab_hint)))
                 self._used = 0
             slab = self._slabs[-1]
             off = self._used
@@ -50,14 +52,25 @@ class PinnedArena:
             self.total_allocated += need
         return HostBlob(slab, off, nbytes)
 
-    def reserve(self, nbytes: int) -> None:
-        """Allocate slabs for `nbytes` more bytes now (hipHostMalloc of hundreds of MB takes tens of ms: a backend
-        sized for its working set pays that at start-up, not inside a store)."""
+    def shrink(self, hb: "HostBlob", nbytes: int) -> "HostBlob":
+        """Give back the tail of `hb` if it is still the arena's last allocation (a pack is allocated at its bound and
+        cut to its size once the GPU has written it); otherwise the tail stays unused."""
+        keep = native.r16(max(nbytes, 16))
+        with self._lock:
+            if self._slabs and hb.slab is self._slabs[-1] and hb.offset + native.r16(max(hb.nbytes, 16)) == self._used:
+                self.total_allocated -= self._used - (hb.offset + keep)
+                self._used = hb.offset + keep
+        return HostBlob(hb.slab, hb.offset, nbytes)
+
+    def reserve(self, nbytes: int, slab_bytes: int = 0) -> None:
+        """Allocate slabs for `nbytes` more bytes now (hipHostMalloc of hundreds of MB takes tens of ms and stalls
+        the device: a backend sized for its working set pays that at start-up, not inside a store)."""
+        slab = max(self.slab_bytes, slab_bytes)
         with self._lock:
             have = sum(b.nbytes for b in self._spare)
             while have < nbytes:
-                self._spare.append(native.PinnedBuffer(self.slab_bytes))
-                have += self.slab_bytes
+                self._spare.append(native.PinnedBuffer(slab))
+                have += slab
 
     def reset(self):
         """Recycle the newest slab (callers that own every blob handed out so far)."""
@@ -109,6 +122,49 @@ class EncodeJob:
     def __del__(self):  # a job dropped unread (an exception between launch and completion): its status word returns
         if _return_status_word is not None:  # (module globals are gone at interpreter shutdown)
             _return_status_word(self)
+
+
+@dataclass
+class HostPack:
+    """The blobs of one store call in pinned host DRAM, laid out layer-major (include/lmc_format.h, "pack")."""
+    blob: HostBlob
+    nchunks: int
+    chunk_tokens: int
+
+    def extract(self, chunk: int) -> bytes:
+        """Chunk `chunk` as the blob lmc_encode_chunks wrote (host-side reassembly)."""
+        return native.pack_extract(self.blob.ptr, self.blob.nbytes, chunk)
+
+
+@dataclass
+class PackJob:
+    """One store_pack() in flight."""
+    region: HostBlob           # where the GPU writes the pack (allocated at an upper bound)
+    nchunks: int
+    chunk_tokens: int
+    sizes: Optional[native.PinnedBuffer]
+    done: torch.cuda.Event
+    status_idx: int = -1
+    pool: Optional[native.StatusWords] = None
+    dev: Optional[torch.Tensor] = None   # dma=True: the HBM region the pack is written to first
+    d2h_issued: bool = True              # ... and whether its copies to pinned memory have been queued
+
+    def __del__(self):
+        if _return_status_word is not None:
+            _return_status_word(self)
+
+
+def pack_cap(n: int, L: int, T: int, H: int, D: int, bins: Sequence[int]) -> int:
+    """Bytes a pack of n T-token chunks can need: the static sections plus, per group stream, the coder's bound --
+    a lane emits at most T * log2(symbols) + 48 bits (DESIGN.md "stream bound") -- with 3 % on top."""
+    import math
+    G = (H * D + native.LANES - 1) // native.LANES
+    static = native.r16(native.blob_static_bytes(L, T, H, D, bins))
+    streams = 0
+    for b in bins:
+        lane_bytes = math.ceil((T * math.log2(max(2, b - 1)) * 1.03 + 64) / 8) + 4
+        streams += G * native.r16(native.LANES * lane_bytes)
+    return min(native.pack_bound(n, L, T, H, D), native.r16(256 + 8 * (2 * L * n + 1)) + n * (static + streams))
 
 
 def layer_ranges(L: int, layers_per_launch) -> list:
@@ -206,6 +262,10 @@ class CacheGenDeviceCodec:
         self._stage: Optional[native.PinnedBuffer] = None    # staging for pageable `bytes` inputs
         self._shared_job: Optional[EncodeJob] = None         # last job that encoded into the shared arena
         self.decode_batch_chunks = 8                         # chunks per H2D/decode pipeline stage
+        self._pack_dev: Optional[torch.Tensor] = None        # HBM staging of a pack on its way to pinned memory (store_pack)
+        self._pack_dev_free: Optional[torch.cuda.Event] = None
+        self._pack_prev: Optional[PackJob] = None
+        self._hdr: Optional[native.PinnedBuffer] = None
 
     # ---- encode ------------------------------------------------------------------
     def encode(self, src: native.KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int,
@@ -430,6 +490,121 @@ class CacheGenDeviceCodec:
             job = DecodeJob(events[-1], st, [(l1, ev) for (_, l1), ev in zip(ranges, events)], pool=self._status)
             job._meta, job._meta_pool = meta, self._meta_pool  # the kernels read the arrays: back in the pool at finish
             return job
+
+    # ---- packs: the layer-major pinned tier ---------------------------------------------------------------
+    def store_pack(self, src: native.KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int, bins: Sequence[int],
+                   arena: PinnedArena, dma: bool = True) -> PackJob:
+        """lmc_store_pack on the CURRENT stream: encode every chunk of [tok_begin, tok_end), then a copy kernel writes
+        the blobs transposed (static sections, then streams ordered layer / K,V / chunk) into one region.  No host
+        wait here; finish_pack() returns the pack in pinned host DRAM.
+        dma=True (default): the region is in HBM and finish_pack() moves the finished pack with two DMA copies of its
+        exact size -- the copy kernel then runs at HBM speed (0.3 ms) and the PCIe leg disturbs nobody.
+        dma=False: the region IS the pinned arena and the copy kernel's stores cross PCIe themselves: one call, no host
+        wait at all, but kernels that run beside 11 ms of shader stores to host memory were measured 4.3x slower
+        (bench.py store_hidden), so this is for callers with an otherwise idle GPU."""
+        L, H, D = src.L, src.H, src.D
+        n = (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
+        with self._lock, torch.cuda.device(self.device):
+            cap = pack_cap(n, L, chunk_tokens, H, D, bins)
+            cur = torch.cuda.current_stream(self.device)
+            region = dev = None
+            if dma:
+                prev = self._pack_prev
+                if prev is None or prev.d2h_issued:
+                    if self._pack_dev is None or self._pack_dev.numel() < cap:
+                        self._pack_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
+                    dev = self._pack_dev
+                    if self._pack_dev_free is not None:
+                        cur.wait_event(self._pack_dev_free)  # the previous pack has left the buffer
+                else:
+                    dev = torch.empty(cap, dtype=torch.uint8, device=self.device)  # the previous store has not been finished yet
+            else:
+                region = arena.alloc(cap, slab_hint=min(4 * cap, 4 << 30))
+            sizes = None
+            for k, b in enumerate(self._size_pool):
+                if b.nbytes >= 4 * n:
+                    sizes = self._size_pool.pop(k)
+                    break
+            if sizes is None:
+                sizes = native.PinnedBuffer(4 * max(n, 256))
+            st = self._status.acquire()
+            try:
+                self.ctx.store_pack(src, tok_begin, tok_end, chunk_tokens, bins, dev.data_ptr() if dma else region.ptr, cap,
+                                    sizes.ptr, stream=cur.cuda_stream, status_ptr=self._status.ptr(st))
+                done = torch.cuda.Event()
+                done.record(cur)
+            except BaseException:
+                self._abandon_status(st, cur)
+                self._size_pool.append(sizes)
+                raise
+            job = PackJob(region, n, chunk_tokens, sizes, done, st, pool=self._status)
+            job.dev, job.d2h_issued = dev, not dma
+            if dma and dev is self._pack_dev:
+                self._pack_prev = job
+            return job
+
+    def finish_pack(self, job: PackJob, arena: PinnedArena) -> HostPack:
+        """Wait for THIS store (its event), raise NativeError if a kernel flagged it, return the pack in pinned host DRAM
+        (dma=True: its size is read from the header the GPU wrote, the pinned region is allocated at that size and two
+        DMA queues move one half each)."""
+        job.done.synchronize()
+        with self._lock:
+            st, job.status_idx = self._status.read_release(job.status_idx), -1
+            if job.sizes is not None:
+                self._size_pool.append(job.sizes)
+                job.sizes = None
+        if st:
+            job.d2h_issued = True
+            raise native.NativeError("CacheGen store (pack): " + native.describe_status(st))
+        if job.dev is None:
+            h = native.pack_info(job.region.ptr, job.region.nbytes)
+            return HostPack(arena.shrink(job.region, h.total_bytes), job.nchunks, job.chunk_tokens)
+        with self._lock, torch.cuda.device(self.device):
+            if self._hdr is None:
+                self._hdr = native.PinnedBuffer(256)
+            cs = self.copy_stream
+            native.memcpy_async(self._hdr.ptr, job.dev.data_ptr(), 256, "d2h", cs.cuda_stream)
+            cs.synchronize()  # 256 bytes: the size of what follows
+            total = int(self._hdr.tensor[72:80].view(torch.int64)[0])  # lmc_pack_header.total_bytes
+            if total <= 0 or total > job.dev.numel():
+                job.d2h_issued = True
+                raise native.NativeError("CacheGen store (pack): the device left no pack")
+            region = arena.alloc(total)
+            half = native.r16(total // 2)
+            native.memcpy_async(region.ptr, job.dev.data_ptr(), half, "d2h", cs.cuda_stream)
+            native.memcpy_async(region.ptr + half, job.dev.data_ptr() + half, total - half, "d2h", self.copy_stream2.cuda_stream)
+            ev2 = torch.cuda.Event()
+            ev2.record(self.copy_stream2)
+            cs.wait_event(ev2)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+            job.d2h_issued = True
+            if job.dev is self._pack_dev:
+                self._pack_dev_free = ev
+        ev.synchronize()
+        h = native.pack_info(region.ptr, total)  # the pack checks out where it lies now
+        return HostPack(HostBlob(region.slab, region.offset, int(h.total_bytes)), job.nchunks, job.chunk_tokens)
+
+    def load_pack(self, pack: HostPack, nchunks: int, dst: native.KVLayout, dst_tok0: int, layers_per_range) -> DecodeJob:
+        """The first `nchunks` chunks of a pack -> decoded KV through ONE C-ABI call (lmc_load_pack): the streams of a
+        range of layers are one contiguous transfer, the range's decode follows it, an event per range
+        (DecodeJob.layer_events) lets the model run layer 0 while the later ranges are still crossing PCIe."""
+        step = layers_per_range if isinstance(layers_per_range, int) or not layers_per_range else int(list(layers_per_range)[0])
+        step = max(1, min(dst.L, int(step or dst.L)))
+        ranges = layer_ranges(dst.L, step)
+        with self._lock, torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            events = [native.NativeEvent() for _ in ranges]
+            handles = (ctypes.c_void_p * len(events))(*[e.handle for e in events])
+            st = self._status.acquire()
+            try:
+                self.ctx.load_pack(pack.blob.ptr, pack.blob.nbytes, 0 if nchunks >= pack.nchunks else nchunks, dst, dst_tok0, step,
+                                   ctypes.cast(handles, ctypes.c_void_p).value, stream=cur.cuda_stream,
+                                   status_ptr=self._status.ptr(st))
+            except BaseException:
+                self._abandon_status(st, cur)
+                raise
+            return DecodeJob(events[-1], st, [(l1, ev) for (_, l1), ev in zip(ranges, events)], pool=self._status)
 
     def _dec_slots(self, n: int, stride: int, cur) -> torch.Tensor:
         if self._dec_arena is None or self._dec_arena.numel() < n * stride:

@@ -101,3 +101,91 @@ def test_store_then_load_through_the_c_abi_only(nat, oracle, shape):
     assert int(status[0]) & 32 and sizes.tolist()[-1] == 0 and all(s > 0 for s in sizes.tolist()[:-1])
     arena.free()
     meta.free()
+
+
+@pytest.mark.parametrize("shape", [(4, 2148, 8, 128, 1, 5), (2, 700, 3, 128, 0, 0), (3, 512, 8, 128, 2, 1)],
+                         ids=["9chunks_tail_1layer_ranges_prefix5", "C384_whole", "2chunks_prefix1"])
+def test_pack_store_extract_load_through_the_c_abi_only(nat, oracle, shape):
+    """lmc_store_pack / lmc_pack_extract / lmc_load_pack: the layer-major form of the pinned tier.  Every chunk
+    extracted from the pack is the oracle's blob byte for byte; loading the whole pack, and a prefix of its chunks,
+    range by range gives the oracle's decode; a pack region that is too small is flagged and leaves no pack."""
+    L, T, H, D, lpr, prefix = shape
+    cs = 256
+    n = (T + cs - 1) // cs
+    g = torch.Generator().manual_seed(T + 1)
+    kv = torch.randn(L, 2, T, H, D, generator=g).to(torch.bfloat16)
+    kv_d = kv.to(DEV)
+    bins = [32 if l < max(1, L // 3) else 16 for l in range(L)] + [32 if l < 1 else 16 for l in range(L)]
+    ctx = nat.get_context(0)
+    cap = nat.pack_bound(n, L, cs, H, D)
+    region = nat.PinnedBuffer(cap)
+    meta = nat.PinnedBuffer(4 * n + 64)
+    sizes = meta.tensor[:4 * n].view(torch.int32)
+    status = meta.tensor[4 * n:4 * n + 4].view(torch.int32)
+    status[0] = 0
+    st = torch.cuda.Stream(device=DEV)
+    lay = nat.KVLayout.from_chunk(kv_d, "vllm")
+    ctx.store_pack(lay, 0, T, cs, bins, region.ptr, cap, meta.ptr, stream=st.cuda_stream, status_ptr=meta.ptr + 4 * n)
+    st.synchronize()
+    assert int(status[0]) == 0
+    h = nat.pack_info(region.ptr, cap)
+    assert (h.nchunks, h.num_layers, h.num_heads, h.head_size, h.chunk_tokens, h.ntokens) == (n, L, H, D, cs, T)
+    blobs = []
+    for i in range(n):
+        t0, t1 = i * cs, min(T, (i + 1) * cs)
+        b, code = oracle.torch_to_bits(kv[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
+        blobs.append(oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)))
+        got = nat.pack_extract(region.ptr, h.total_bytes, i)
+        assert got == blobs[i], f"chunk {i}"
+        assert int(sizes[i]) == len(blobs[i])
+    # the pack holds the blobs' bytes once, plus its header, table and slot padding
+    # (a ragged last chunk has shorter static sections than its slot)
+    assert h.total_bytes <= sum(len(b) for b in blobs) + 256 + 8 * (2 * L * n + 1) + 16 + 16 * n + 4 * L * cs + 64
+    refs = [oracle.decode_blob(b, oracle.BF16) for b in blobs]
+
+    def load(m):
+        out = torch.zeros_like(kv_d)
+        nranges = (L + lpr - 1) // lpr if lpr else 1
+        ev = (ctypes.c_void_p * nranges)()
+        for r in range(nranges):
+            e = ctypes.c_void_p()
+            nat.check(nat.lib().lmc_event_create(ctypes.byref(e), 0), "lmc_event_create")
+            ev[r] = e
+        status[0] = 0
+        ctx.load_pack(region.ptr, h.total_bytes, m, nat.KVLayout.from_chunk(out, "vllm"), 0, lpr,
+                      ctypes.cast(ev, ctypes.c_void_p).value, stream=st.cuda_stream, status_ptr=meta.ptr + 4 * n)
+        for r in range(nranges):
+            nat.check(nat.lib().lmc_event_synchronize(ev[r]), "lmc_event_synchronize")
+            nat.lib().lmc_event_destroy(ev[r])
+        st.synchronize()
+        assert int(status[0]) == 0
+        mm = m or n
+        for i in range(n):
+            t0, t1 = i * cs, min(T, (i + 1) * cs)
+            got = _bits(out[:, :, t0:t1]).reshape(L, 2, t1 - t0, H * D)
+            if i < mm:
+                assert np.array_equal(got, refs[i]), f"chunk {i} of {mm}"
+            else:
+                assert not got.any(), f"chunk {i} is outside the prefix and must stay untouched"
+
+    load(0)
+    if prefix:
+        load(prefix)
+    # a corrupt offset table is refused on the host, before anything is queued
+    tab = ctypes.cast(region.ptr + h.off_table, ctypes.POINTER(ctypes.c_uint64))
+    keep = tab[1]
+    tab[1] = keep + 16 if n * 2 * L > 1 else keep
+    tab[2 * L * n] += 16
+    with pytest.raises(nat.NativeError):
+        ctx.load_pack(region.ptr, h.total_bytes, 0, nat.KVLayout.from_chunk(torch.zeros_like(kv_d), "vllm"), 0, lpr, None,
+                      stream=st.cuda_stream, status_ptr=meta.ptr + 4 * n)
+    # a region that is too small: flagged, and what it holds is not a pack
+    status[0] = 0
+    ctx.store_pack(lay, 0, T, cs, bins, region.ptr, int(h.total_bytes) - 16, meta.ptr, stream=st.cuda_stream,
+                   status_ptr=meta.ptr + 4 * n)
+    st.synchronize()
+    assert int(status[0]) & 32
+    with pytest.raises(nat.NativeError):
+        nat.pack_info(region.ptr, cap)
+    region.free()
+    meta.free()

@@ -466,9 +466,21 @@ def test_corrupt_pinned_blob_is_a_miss_never_garbage(oracle):
         assert int(m.sum()) == 384
         keys = [engine._make_key(h, fmt) for h in engine._prefix_hash(engine._chunk_tokens(toks))]
         entry = engine.engine_.dict[keys[1]]
-        raw = (ctypes.c_uint8 * entry.blob.nbytes).from_address(entry.blob.ptr)
         # final states, a row prefix, a stream, a scale (176 .. 2224: caught by the per-plane checksums), a checksum
-        for where in (entry.blob.nbytes - 40, 146, entry.blob.nbytes // 2, 200, 2230):
+        if hasattr(entry, "pack"):  # the three chunks went to pinned memory as one layer-major pack
+            from lmcache_amd import native
+            pk = entry.pack.blob
+            h = native.pack_info(pk.ptr, pk.nbytes)
+            raw = (ctypes.c_uint8 * pk.nbytes).from_address(pk.ptr)
+            tab = ctypes.cast(pk.ptr + h.off_table, ctypes.POINTER(ctypes.c_uint64))
+            slot = h.off_static + 1 * h.static_stride                 # chunk 1's static sections
+            seg = lambda lk: (h.off_streams + tab[lk * 3 + 1], h.off_streams + tab[lk * 3 + 2])  # its segment (layer, kv)
+            last = seg(2 * nl - 1)
+            spots = (last[1] - 40, slot + 146, seg(3)[0] + 1000, slot + 200, slot + 2230)  # (+1000: inside the plane's first stream)
+        else:
+            raw = (ctypes.c_uint8 * entry.blob.nbytes).from_address(entry.blob.ptr)
+            spots = (entry.blob.nbytes - 40, 146, entry.blob.nbytes // 2, 200, 2230)
+        for where in spots:
             old = raw[where]
             raw[where] = old ^ 0x3c
             ret, mask = engine.retrieve(toks)

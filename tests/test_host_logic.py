@@ -164,7 +164,7 @@ def test_c_abi_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", native.SO_PATH], text=True)
     exported = set(re.findall(r" T (lmc_[a-z0-9_]+)", out))
     assert declared <= exported
-    assert L.lmc_abi_version() == 4
+    assert L.lmc_abi_version() == 5
     assert L.lmc_strerror(-1).decode().startswith("invalid")
 
 
