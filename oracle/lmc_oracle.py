@@ -62,6 +62,7 @@ def lib() -> ctypes.CDLL:
         L.lmco_decode_blob_symbols.restype = i32
         L.lmco_decode_blob.argtypes = [vp, sz, vp, i32]
         L.lmco_decode_blob.restype = i32
+        L.lmco_rans_magic.argtypes = [ctypes.c_uint32, vp, vp]
         L.lmco_blob_bound.argtypes = [i32, i32, i32, i32]
         L.lmco_blob_bound.restype = ctypes.c_uint64
         L.lmco_h2f.argtypes = [ctypes.c_uint16, i32]
@@ -75,6 +76,13 @@ def lib() -> ctypes.CDLL:
 def _p(a: np.ndarray) -> ctypes.c_void_p:
     assert a.flags["C_CONTIGUOUS"]
     return ctypes.c_void_p(a.ctypes.data)
+
+
+def rans_magic(count: int):
+    """(magic, shift) of lmc_rans_magic for freq = 2 * count."""
+    m, sh = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    lib().lmco_rans_magic(count, ctypes.byref(m), ctypes.byref(sh))
+    return m.value, sh.value
 
 
 def sha256_hex(data: bytes) -> str:

@@ -152,3 +152,29 @@ def test_blob_roundtrip_random_geometries(oracle):
             bad[where] ^= 1 << int(rng.integers(0, 8))
             with pytest.raises(AssertionError, match="rc=-4"):
                 oracle.decode_blob(bytes(bad), oracle.BF16)
+
+
+def test_rans_magic_gives_the_exact_quotient_for_every_count(oracle):
+    """lmc_rans_magic (lmc_format.h): x // freq == mulhi32(x, magic) >> shift for every freq = 2 * count of the counts
+    model and every state x < 2^31.  The premise of the proof in the header (magic * freq - 2^(31 + l) < freq) is
+    checked for every count; on top of it the identity itself on the multiples of freq and their neighbours over
+    the whole state range (sampled: every multiple for small quotients, a stride above), the top 2^16 states, and
+    a million random states per count."""
+    rng = np.random.default_rng(5)
+    for count in range(1, 256):
+        f = 2 * count
+        magic, shift = oracle.rans_magic(count)
+        l = shift + 1
+        assert (1 << (l - 1)) < f <= (1 << l) or f == 2 and l == 1
+        assert 2**31 <= magic < 2**32
+        assert magic * f - (1 << (31 + l)) < f and magic * f >= (1 << (31 + l))
+        kmax = (2**31 - 1) // f
+        ks = np.unique(np.concatenate([np.arange(0, min(kmax, 70000) + 1, dtype=np.uint64),
+                                       np.arange(0, kmax + 1, max(1, kmax // 60000), dtype=np.uint64),
+                                       np.array([kmax, max(kmax - 1, 0)], dtype=np.uint64)]))
+        xs = np.concatenate([ks * np.uint64(f), ks * np.uint64(f) + np.uint64(f - 1), ks * np.uint64(f) + np.uint64(1),
+                             np.arange(2**31 - 2**16, 2**31, dtype=np.uint64),
+                             rng.integers(0, 2**31, 1_000_000, dtype=np.uint64)])
+        xs = xs[xs < np.uint64(2**31)]
+        q = ((xs * np.uint64(magic)) >> np.uint64(32)) >> np.uint64(shift)
+        assert np.array_equal(q, xs // np.uint64(f)), count

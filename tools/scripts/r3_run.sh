@@ -1,10 +1,6 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_engine.py tests/test_c_abi_store_load.py -m gpu -x -q > gpurun_out/r3A_pytest.log 2>&1; tail -3 gpurun_out/r3A_pytest.log
-timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r3A_bench.json 2> gpurun_out/r3A_bench.err
-python - <<'PY'
-import json
-txt=open("gpurun_out/r3A_bench.json").read()
-d=json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
-print(d["ms_per_step"], d["value"], d["roofline"]["frac"]); t=d["ttft_proxy"]; print({k:t[k] for k in t if k.startswith(("layerwise","retrieve","one_step","warm","pcie"))}); print(d.get("offload_pack")); print(d["store_hidden"])
-PY
-tail -3 gpurun_out/r3A_bench.err
+for ctx in 16384 16640 16128; do
+AB="tools/probes/encode_ab 32 8 128 $ctx 256 0 20 0 2"
+for v in main rot7 rot13 main rot7; do
+  if [ $v = main ]; then L=""; else L="$PWD/build_alt/$v"; fi
+  LD_LIBRARY_PATH=$L:$LD_LIBRARY_PATH timeout 120 $AB > gpurun_out/r3C_$v.log 2>&1; echo "$ctx $v: $(grep -E '^fused|^two' gpurun_out/r3C_$v.log | awk '{print $1, $2, $6, $9, $10}' | tr '\n' ' ')"; done; done
