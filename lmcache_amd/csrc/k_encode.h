@@ -252,9 +252,9 @@ __device__ __forceinline__ u32 sym_of_token(const u32* symq, int C, int t, bool 
 // One group stream (chunk, plane, 64-channel group) = global stream id `gid`, by one wave: histogram, counts
 // section, CDF table, interleaved rANS into the stream's scratch slot.  `hist` is the wave's table slice of LDS
 // (ENC_TAB_DWORDS), `ring` its staging ring (ENC_RING_DWORDS).  Returns the finished stream in `t` (ENCODE).
-// LDSASM: the token loop of the <= 16-symbol planes issues its table reads from inside the renormalisation's asm
-// block (see code_token_rd); the fused kernel runs that form, k_cdf_encode the plain one.
-template <bool QUADSYM, bool ENCODE, bool LDSASM = false>
+// This is the CDF16 form (chunk lengths other than 256; lmc_format.h); 256-token chunks take
+// encode_group_stream_counts (k_encode_counts.h).
+template <bool QUADSYM, bool ENCODE>
 __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long long gid, u32* hist, u16* const ring,
                                                     int lane, PendingTile& t) {
   u16* tab = reinterpret_cast<u16*>(hist);          // [33][64] u16 CDF, written after hist is in registers
@@ -427,45 +427,6 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
     }
     x = rans_put(x, f, 0x10000u - f, st);
   };
-  // The same step with the NEXT token's two table reads (start at offset 0, frequency at row 17: nibble planes)
-  // issued from inside the block, after the ring store.  The compiler places its own s_waitcnt lgkmcnt(0) for
-  // table reads it can see right behind this block, where it also waits for the ds_write_b16 issued a few
-  // instructions earlier -- the LDS write round trip of every token.  Here the reads are invisible to it and the
-  // wait is OURS, at the top of the next block: by then store and reads are a whole token step old.  st and f are
-  // read-write operands so that every use the compiler sees comes after that wait; nxt_st / nxt_f may only be fed
-  // to the next block (or to lds_reads_done).
-  auto code_token_rd = [&](u32 st, u32 f, u32 nxt_addr, u32& nxt_st, u32& nxt_f) {
-    const u32 wbase = ring_addr + ((wcur & (ENC_RING_WORDS - 1)) << 1);  // scalar
-    u32 t, cnt;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 "v_cmpx_ge_u32_sdwa vcc, %[x], %[f] src0_sel:WORD_1 src1_sel:DWORD\n\t"
-                 "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                 "s_nop 0\n\t"
-                 "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                 "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                 "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
-                 "ds_write_b16 %[t], %[x]\n\t"
-                 "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                 "s_mov_b64 exec, %[full]\n\t"
-                 "ds_read_u16 %[ns], %[na]\n\t"
-                 "ds_read_u16 %[nf], %[na] offset:2176"
-                 : [x] "+v"(x), [f] "+v"(f), [st] "+v"(st), [t] "=&v"(t), [cnt] "=&s"(cnt), [ns] "=&v"(nxt_st),
-                   [nf] "=&v"(nxt_f)
-                 : [wb] "s"(wbase), [full] "s"(full_exec), [na] "v"(nxt_addr)
-                 : "vcc", "scc", "memory");
-    wcur += cnt;  // flush and state update: as in code_token
-    if (wcur - flushed >= 128u) {
-      wave_lds_fence();
-      if (flushed & 128u) {
-        const u32 over = wcur - flushed - 128u;  // < 64
-        if ((u32)lane < over) ring[lane] = ring[ENC_RING_WORDS + lane];
-      }
-      out32[(flushed >> 1) + lane] = reinterpret_cast<const u32*>(ring)[((flushed & (ENC_RING_WORDS - 1)) >> 1) + lane];
-      flushed += 128u;
-    }
-    x = rans_put(x, f, 0x10000u - f, st);
-  };
-  auto lds_reads_done = [&](u32& a0, u32& a1) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1) : : "memory"); };
   auto pass2 = [&](auto nib_tag) {
     constexpr bool NIB = decltype(nib_tag)::value;
     constexpr int DPB = NIB ? 4 : 8;
@@ -489,39 +450,7 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
     // full 32-token blocks, descending; software pipelined twice over:
     //   - the next block's symbol dwords are loaded while this block is coded,
     //   - the table entries of token t-1 are fetched from LDS before token t is coded.
-    if constexpr (LDSASM && NIB) {
-      if (nfull > 0) {
-        static_assert(17 * 128 == 2176, "offset of the frequency rows in code_token_rd");
-        typedef __attribute__((address_space(3))) u16* lds_u16t;
-        const u32 lane_tab = (u32)(size_t)(lds_u16t)tab + 2u * (u32)lane;  // LDS byte address of tab[0][lane]
-        u32 w[DPB], wn[DPB];
-#pragma unroll
-        for (int j = 0; j < DPB; j++) w[j] = active ? symq[(long long)((nfull - 1) * DPB + j) * a.C] : 0u;
-        u32 sn = sym_of_block<NIB, 31>(w);
-        u32 lo_n = tab[sn * 64 + lane], hi_n = second(sn);  // the first token's entries: plain loads
-        for (int b = nfull - 1; b >= 0; b--) {
-          if (b > 0) {
-#pragma unroll
-            for (int j = 0; j < DPB; j++) wn[j] = active ? symq[(long long)((b - 1) * DPB + j) * a.C] : 0u;
-          }
-          static_for<32>([&](auto itag) {
-            constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
-            // the token after this one: of this block, of the next block, or (the very last step) symbol 0,
-            // read and never used
-            if constexpr (i > 0) sn = sym_of_block<NIB, i - 1>(w);
-            else sn = b > 0 ? sym_of_block<NIB, 31>(wn) : 0u;
-            const u32 nxt_addr = lane_tab + (sn << 7);
-            u32 nst, nf;
-            code_token_rd(lo_n, hi_n, nxt_addr, nst, nf);
-            lo_n = nst;
-            hi_n = nf;
-          });
-#pragma unroll
-          for (int j = 0; j < DPB; j++) w[j] = wn[j];
-        }
-        lds_reads_done(lo_n, hi_n);  // the last step's reads land before their registers are free again
-      }
-    } else if (nfull > 0) {
+    if (nfull > 0) {
       u32 w[DPB], wn[DPB];
 #pragma unroll
       for (int j = 0; j < DPB; j++) w[j] = active ? symq[(long long)((nfull - 1) * DPB + j) * a.C] : 0u;
