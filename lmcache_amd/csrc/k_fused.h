@@ -49,6 +49,16 @@ struct FusedArgs {
   // without, 1.064-1.09 ms with pre_step 4 / 2 / 3 / 1 -- the phases were not in lock-step; what the fetch phase
   // costs is the wave slots its waves hold while they wait.
   u32 pre_limit, pre_step;
+  // Staggered start (lmc_api.hip: 50 us, LMC_FUSED_STAGGER_US): every workgroup of a launch takes the same time, so
+  // the four workgroups a CU holds tend to run their phases in lock-step for the whole launch -- all fetch (HBM busy,
+  // VALU idle), then all code (VALU busy, HBM idle).  A first-generation workgroup (ticket < stagger_limit) draws its
+  // rank among the workgroups of ITS CU (hardware id -> cu_rank[]) and holds its fetch back by rank x stagger_ticks
+  // (s_memrealtime ticks, 10 ns): the CU's slots then run about a quarter period apart.  Measured over alternating
+  // processes on one box: 1.046-1.12 ms without, 1.010-1.059 with 50 us (-3 % on average).  Keyed on the ticket
+  // instead of the CU (rank = ticket / CUs) it does nothing: tickets follow dispatch order, which is not one
+  // workgroup per CU at a time.
+  u32 stagger_ticks, stagger_limit;
+  u32* cu_rank;  // [4096] zero at launch: the workgroup with the launch's last ticket clears it again on its way out
 };
 
 __device__ __forceinline__ void aggE_store(unsigned long long* p, unsigned long long flag, u32 epoch, u32 v) {
@@ -235,6 +245,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   u16* const ring = reinterpret_cast<u16*>(lds_all + wave * ENC_RING_DWORDS);  // ... and staging ring
 
   rtab_to_lds(rtab_lds);  // visible to the coder waves behind the barrier that ends phase A
+  if (fa.stagger_ticks && item < fa.stagger_limit) {
+    __shared__ u32 cu_slot;
+    if (threadIdx.x == 0) {
+      const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_ID, XCC_ID
+      const u32 key = ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);  // XCC | SE, SH, CU
+      cu_slot = atomicAdd(&fa.cu_rank[key], 1u);
+    }
+    __syncthreads();
+    const unsigned long long hold = (unsigned long long)min(cu_slot, 3u) * fa.stagger_ticks;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < hold) __builtin_amdgcn_s_sleep(32);
+  }
   // ---- phase A: quantise the plane-chunk ----------------------------------------------------------------
   const bool head_start = item < fa.pre_limit && item % fa.pre_step == 0u;  // quantised by k_quantize already
   if (!head_start) {
@@ -298,7 +320,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   if (wave == 0) {
     unsigned long long* agg = a.agg + (long long)chunk * a.P;
     if (lane == 0 && p > 0) aggE_store(agg + p, AGG_A, fa.epoch, wg_total);
+#if LMC_EXP_TWICE & 256  // timing experiment: no look-back (the streams land at offset 0 of their chunk: blobs are wrong)
+    const u32 e = 0;
+#else
     const u32 e = lookback_exclusive_epoch(agg, p, fa.epoch, lane, a.status);
+#endif
     if (lane == 0) {
       aggE_store(agg + p, AGG_P, fa.epoch, e + wg_total);
       wg_excl = e;
@@ -327,5 +353,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     u8* blob = a.blobs + (long long)chunk * a.blob_stride;
     write_blob_static(blob, bo, a, (u32)Tc, wg_excl + wg_total, lane);
     if (lane == 0) a.sizes[chunk] = bo.streams + wg_excl + wg_total;
+  }
+  if (fa.stagger_ticks && item == (u32)(a.nchunks * a.P) - 1u) {  // every first-generation rank was drawn long ago
+    for (u32 i = threadIdx.x; i < 4096u; i += 64u * NW) fa.cu_rank[i] = 0u;
   }
 }

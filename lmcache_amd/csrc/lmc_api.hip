@@ -42,6 +42,8 @@ struct lmc_ctx {
   int num_cus = 256;
   int enc_path = LMC_ENCODE_PATH_AUTO;  // lmc_ctx_set_encode_path
   bool pre_all = false;
+  int stagger_us = 50;                  // fused encode: staggered start of a CU's first workgroups (k_fused.h), microseconds; LMC_FUSED_STAGGER_US=0: off
+  u32* cu_rank = nullptr;
   int pre_step = 0;                     // fused encode: every pre_step-th workgroup of the first generation gets a head start
                                         // (0: none -- measured 1.06 ms without, 1.07-1.09 with 2 / 3 / 4: k_fused.h)
   u32 epoch = 0;                        // of the last fused launch (tags its look-back granules)
@@ -103,6 +105,7 @@ int lmc_ctx_create(int device, lmc_ctx** out) {
   memset(c->status_h, 0, 64);
   e = hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming);
   if (e != hipSuccess) { g_last_hip = (int)e; (void)hipHostFree(c->status_h); delete c; return LMC_ERR_HIP; }
+  if (const char* e = getenv("LMC_FUSED_STAGGER_US")) c->stagger_us = atoi(e);
   if (const char* e = getenv("LMC_FUSED_PRE_STEP")) c->pre_step = atoi(e);  // A/B switch of the head start (tools/probes)
   if (const char* e = getenv("LMC_FUSED_PRE_ALL")) c->pre_all = atoi(e) != 0;  // experiment: EVERY plane-chunk quantised up front
   *out = c;
@@ -122,6 +125,7 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   if (c->store_arena) (void)hipFree(c->store_arena);
   if (c->load_slots) (void)hipFree(c->load_slots);
   if (c->pack_table) (void)hipFree(c->pack_table);
+  if (c->cu_rank) (void)hipFree(c->cu_rank);
   if (c->store_free) (void)hipEventDestroy(c->store_free);
   if (c->load_free) (void)hipEventDestroy(c->load_free);
   for (int i = 0; i < 64; i++) if (c->evpool[i]) (void)hipEventDestroy(c->evpool[i]);
@@ -436,6 +440,13 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
       HIP_TRY(hipGetLastError());
     } else {
       fa.pre_limit = 0; fa.pre_step = 1;
+    }
+    if (c->stagger_us > 0 && (long long)nfull * P >= 8ll * c->num_cus) {
+      if (!c->cu_rank) {  // zeroed once; every launch leaves it zero
+        HIP_TRY(hipMalloc((void**)&c->cu_rank, 4096 * sizeof(u32)));
+        HIP_TRY(hipMemsetAsync(c->cu_rank, 0, 4096 * sizeof(u32), s));
+      }
+      fa.stagger_ticks = (u32)c->stagger_us * 100u; fa.stagger_limit = 4u * (u32)c->num_cus; fa.cu_rank = c->cu_rank;
     }
     if (src->dtype == LMC_DTYPE_BF16) {
       if (C <= 512) hipLaunchKernelGGL((k_encode_fused<1, LMC_DTYPE_BF16, FUSED_WAVES>), grid, block, 0, s, fa);
