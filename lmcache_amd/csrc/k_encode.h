@@ -32,6 +32,7 @@ struct EncodeArgs {
   const int8_t* sym8;   // !QUADSYM: [P][T][C]
   int tok_begin, tok_end, chunk_tokens, nchunks;
   int P, C, G, TQ;
+  long long sym_stride;  // dwords between the workspace regions of consecutive (chunk, plane) pairs: >= TQ * C (lmc_api.hip pads it)
   // outputs
   u8* blobs;            // ENCODE: blob i at blobs + i*blob_stride (cdf section written here)
   long long blob_stride;
@@ -267,7 +268,7 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
   const int c = g * 64 + lane;
   const bool active = c < a.C;
 
-  const u32* symq = QUADSYM ? a.sym4 + ((long long)chunk * a.P + p) * a.TQ * a.C + c : nullptr;
+  const u32* symq = QUADSYM ? a.sym4 + ((long long)chunk * a.P + p) * a.sym_stride + c : nullptr;
   const int8_t* symb = QUADSYM ? nullptr : a.sym8 + (long long)p * Tc * a.C + c;
 
   // ---- pass 1: histogram --------------------------------------------------

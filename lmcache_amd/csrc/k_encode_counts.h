@@ -107,7 +107,7 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
   constexpr int Tc = (int)LMC_COUNTS_T;
   const int c = g * 64 + lane;
   const bool active = c < a.C;
-  const u32* symq = a.sym4 + ((long long)chunk * a.P + p) * a.TQ * a.C + c;
+  const u32* symq = a.sym4 + ((long long)chunk * a.P + p) * a.sym_stride + c;
   const bool nib = lmc_sym_nibbles((int)a.bins.b[p]);  // wave-uniform
   const u32 tab_addr = (u32)(size_t)(lds_u32w)tabmem;
   const u32 rtab_addr = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(lds_u32w) const_cast<u32*>(rtab));

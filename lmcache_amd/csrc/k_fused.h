@@ -263,11 +263,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const int bins = (int)a.bins.b[p];
     const float maxf = (float)(bins / 2 - 1);
     const bool nib = lmc_sym_nibbles(bins);
-#if LMC_EXP_TWICE & 32  // timing experiment: every workgroup of an XCD shares 4 symbol regions (stays in L2)
-    u32* const sym_pc = const_cast<u32*>(a.sym4) + (long long)(item % 32u) * a.TQ * a.C;
-#else
-    u32* const sym_pc = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.TQ * a.C;
-#endif
+    u32* const sym_pc = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.sym_stride;
     u16* const scl = reinterpret_cast<u16*>(fa.scale_base + (long long)chunk * fa.scale_stride) + (long long)p * Tc;
     const int TO = (Tc + 7) >> 3;
     const u16* const pbase = lmc_plane_base(fa.src, p);
@@ -297,18 +293,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
 
   // ---- phase B: code this wave's group streams -----------------------------------------------------------
-#if LMC_EXP_TWICE & 32
-  EncodeArgs a2 = a;
-  a2.sym4 = a.sym4 + ((long long)(item % 32u) - ((long long)chunk * a.P + p)) * a.TQ * a.C;
-#define LMC_FUSED_ENC_ARGS a2
-#else
-#define LMC_FUSED_ENC_ARGS a
-#endif
   const long long gid0 = ((long long)chunk * a.P + p) * a.G;
 #pragma unroll 1
   for (int g = wave; g < a.G; g += NW) {
     PendingTile t;
-    encode_group_stream_counts<LMC_COUNTS_LDSASM>(LMC_FUSED_ENC_ARGS, gid0 + g, hist, ring, rtab_lds, lane, t);
+    encode_group_stream_counts<LMC_COUNTS_LDSASM>(a, gid0 + g, hist, ring, rtab_lds, lane, t);
     if (lane == 0) st_len[g] = t.exact;
     wave_lds_fence();  // the next stream reuses this wave's LDS slices
   }

@@ -27,6 +27,7 @@ struct QuantArgs {
   BinsArg bins;
   int tok_begin, tok_end, chunk_tokens, nchunks;
   int P, C, TQ;          // TQ = ceil(chunk_tokens / 4)
+  long long sym_stride;  // QUAD: dwords between the workspace regions of consecutive (chunk, plane) pairs (>= TQ * C)
   int pc_limit;          // plane-chunks (chunk * P + plane) to quantise: nchunks * P
   u32* sym4;             // QUAD: symbol workspace, TQ*C dwords per (chunk, plane)
   int8_t* sym8;          // !QUAD: [P][T][C]
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
   const int bins = (int)a.bins.b[p];
   const float maxf = (float)(bins / 2 - 1);
   u16* scale_out = reinterpret_cast<u16*>(a.scale_base + (long long)chunk * a.scale_stride) + ((long long)p * Tc + oct * 8);
-  u32* sym_pc = QUAD ? a.sym4 + ((long long)chunk * a.P + p) * a.TQ * a.C : nullptr;  // this plane-chunk's workspace
+  u32* sym_pc = QUAD ? a.sym4 + ((long long)chunk * a.P + p) * a.sym_stride : nullptr;  // this plane-chunk's workspace
   int8_t* sym8_plane = QUAD ? nullptr : a.sym8 + (long long)p * Tc * a.C;
   if constexpr (QUAD) {
     constexpr int ROWS = NITER <= 2 ? 8 : 4;  // 16-byte loads in flight per lane: ROWS * NITER

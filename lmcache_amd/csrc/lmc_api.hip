@@ -42,6 +42,13 @@ struct lmc_ctx {
   int num_cus = 256;
   int enc_path = LMC_ENCODE_PATH_AUTO;  // lmc_ctx_set_encode_path
   bool pre_all = false;
+  // Skew of the library's own buffers (bytes, multiples of 16): consecutive work items are the same plane of
+  // consecutive chunks, and every natural stride between them -- 256 tokens of KV (512 KiB), 64 planes of symbol
+  // regions (16 MiB), 1024 stream slots (16.5 MiB) -- is a multiple of 512 KiB, so the 1024 workgroups in flight hit
+  // the same few HBM channels at the same time unless the fabric's address hash happens to spread them: the fused
+  // encode took 1.03 or 1.14 ms depending on WHERE hipMalloc had put workspace and arena (tools/probes/encode_modes).
+  // Padding the strides takes the power of two out of them.
+  size_t sym_pad = 4096 + 256, scr_pad = 256;
   int stagger_us = 50;                  // fused encode: staggered start of a CU's first workgroups (k_fused.h), microseconds; LMC_FUSED_STAGGER_US=0: off
   u32* cu_rank = nullptr;
   int pre_step = 0;                     // fused encode: every pre_step-th workgroup of the first generation gets a head start
@@ -106,6 +113,8 @@ int lmc_ctx_create(int device, lmc_ctx** out) {
   e = hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming);
   if (e != hipSuccess) { g_last_hip = (int)e; (void)hipHostFree(c->status_h); delete c; return LMC_ERR_HIP; }
   if (const char* e = getenv("LMC_FUSED_STAGGER_US")) c->stagger_us = atoi(e);
+  if (const char* e = getenv("LMC_SYM_PAD")) c->sym_pad = (size_t)atoll(e) & ~(size_t)15;
+  if (const char* e = getenv("LMC_SCRATCH_PAD")) c->scr_pad = (size_t)atoll(e) & ~(size_t)15;
   if (const char* e = getenv("LMC_FUSED_PRE_STEP")) c->pre_step = atoi(e);  // A/B switch of the head start (tools/probes)
   if (const char* e = getenv("LMC_FUSED_PRE_ALL")) c->pre_all = atoi(e) != 0;  // experiment: EVERY plane-chunk quantised up front
   *out = c;
@@ -252,8 +261,8 @@ static int ws_grow(void** p, size_t* have, size_t need) {
 // caller holds ctx->mu
 static int reserve_locked(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_chunks) {
   const size_t P = 2 * (size_t)L, C = (size_t)H * D, G = (C + 63) / 64, TQ = ((size_t)chunk_tokens + 3) / 4;
-  const size_t need_sym = (size_t)max_chunks * P * TQ * C * 4;
-  const size_t need_scr = (size_t)max_chunks * P * G * lmc_group_cap_bytes((uint32_t)chunk_tokens);
+  const size_t need_sym = (size_t)max_chunks * P * (TQ * C * 4 + c->sym_pad);
+  const size_t need_scr = (size_t)max_chunks * P * G * (lmc_group_cap_bytes((uint32_t)chunk_tokens) + c->scr_pad);
   const size_t need_len = (size_t)max_chunks * P * G * 4;
   if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && 2 * need_len <= c->agg_bytes) return LMC_OK;
   // growing frees memory that queued kernels may still use: wait for them (this call only)
@@ -336,7 +345,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   if (c->ws_used) HIP_TRY(hipStreamWaitEvent(s, c->ws_free, 0));
 
   const int TQ = (chunk_tokens + 3) / 4;
-  const u32 cap = lmc_group_cap_bytes((uint32_t)chunk_tokens);
+  const u32 cap = lmc_group_cap_bytes((uint32_t)chunk_tokens) + (u32)c->scr_pad;  // slot stride (and capacity)
   lmc_blob_header hl;
   lmc_blob_layout((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D, bins.rowpre[P], &hl);
   const long long PG = (long long)P * G;
@@ -346,6 +355,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   ea.sym4 = c->sym4;
   ea.tok_begin = tok_begin; ea.tok_end = tok_end; ea.chunk_tokens = chunk_tokens; ea.nchunks = nchunks;
   ea.P = P; ea.C = C; ea.G = G; ea.TQ = TQ;
+  ea.sym_stride = (long long)TQ * C + (long long)(c->sym_pad / 4);
   ea.blobs = (u8*)blobs; ea.blob_stride = (long long)blob_stride;
   ea.scratch = c->scratch; ea.cap = cap;
   ea.status = job_status ? job_status : c->status_h;
@@ -374,7 +384,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   auto two_kernels = [&](int c0, int n) -> int {
     EncodeArgs e2 = ea;
     e2.tok_begin = tok_begin + c0 * chunk_tokens; e2.nchunks = n;
-    e2.sym4 = c->sym4 + (size_t)c0 * P * TQ * C;
+    e2.sym4 = c->sym4 + (size_t)c0 * P * (size_t)ea.sym_stride;
     e2.blobs = (u8*)blobs + (size_t)c0 * blob_stride;
     e2.scratch = c->scratch + (size_t)c0 * PG * cap;
     e2.agg = c->agg + (size_t)c0 * PG;
@@ -383,7 +393,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     memset(&qa, 0, sizeof qa);
     qa.src = to_addr(src); qa.bins = bins;
     qa.tok_begin = e2.tok_begin; qa.tok_end = tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = n;
-    qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = n * P;
+    qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = n * P; qa.sym_stride = ea.sym_stride;
     qa.sym4 = const_cast<u32*>(e2.sym4);
     qa.scale_base = scale_base + (size_t)c0 * blob_stride;
     qa.scale_stride = (long long)blob_stride;
@@ -424,7 +434,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
       memset(&qa, 0, sizeof qa);
       qa.src = to_addr(src); qa.bins = bins;
       qa.tok_begin = tok_begin; qa.tok_end = fa.e.tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = nfull;
-      qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = nfull * P;
+      qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = nfull * P; qa.sym_stride = ea.sym_stride;
       qa.sym4 = c->sym4;
       qa.scale_base = scale_base; qa.scale_stride = (long long)blob_stride;
       qa.lin_step = c->pre_step;
