@@ -42,13 +42,14 @@ struct lmc_ctx {
   int num_cus = 256;
   int enc_path = LMC_ENCODE_PATH_AUTO;  // lmc_ctx_set_encode_path
   bool pre_all = false;
-  // Skew of the library's own buffers (bytes, multiples of 16): consecutive work items are the same plane of
-  // consecutive chunks, and every natural stride between them -- 256 tokens of KV (512 KiB), 64 planes of symbol
-  // regions (16 MiB), 1024 stream slots (16.5 MiB) -- is a multiple of 512 KiB, so the 1024 workgroups in flight hit
-  // the same few HBM channels at the same time unless the fabric's address hash happens to spread them: the fused
-  // encode took 1.03 or 1.14 ms depending on WHERE hipMalloc had put workspace and arena (tools/probes/encode_modes).
-  // Padding the strides takes the power of two out of them.
-  size_t sym_pad = 4096 + 256, scr_pad = 256;
+  // Optional skew of the library's own buffers (LMC_SYM_PAD / LMC_SCRATCH_PAD, bytes, multiples of 16; default none).
+  // The fused encode takes 1.03 or 1.14 ms for the same job depending on WHERE hipMalloc put the workspace and the
+  // caller's blob arena (tools/probes/encode_modes: deterministic per placement, one process holds fast and slow
+  // ones).  Consecutive work items are the same plane of consecutive chunks and every natural stride between them is
+  // a multiple of 512 KiB (256 tokens of KV, 64 symbol regions, 1024 stream slots), so channel aliasing was the first
+  // suspect -- but padded strides did not remove the slow placements (13 / 13 fast in one process, 2 / 13 in the
+  // next, like without), and the input's placement does not matter at all.  DESIGN.md section 6.
+  size_t sym_pad = 0, scr_pad = 0;
   int stagger_us = 50;                  // fused encode: staggered start of a CU's first workgroups (k_fused.h), microseconds; LMC_FUSED_STAGGER_US=0: off
   u32* cu_rank = nullptr;
   int pre_step = 0;                     // fused encode: every pre_step-th workgroup of the first generation gets a head start
