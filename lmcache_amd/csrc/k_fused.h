@@ -253,9 +253,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       cu_slot = atomicAdd(&fa.cu_rank[key], 1u);
     }
     __syncthreads();
-    const unsigned long long hold = (unsigned long long)min(cu_slot, 3u) * fa.stagger_ticks;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < hold) __builtin_amdgcn_s_sleep(32);
+    // wave-uniform, in SGPRs: the wait loop is scalar code (32-bit tick arithmetic: a hold is < 2^32 x 10 ns)
+    const u32 hold = (u32)__builtin_amdgcn_readfirstlane((int)(min(cu_slot, 3u) * fa.stagger_ticks));
+    const u32 t0 = (u32)__builtin_amdgcn_s_memrealtime();
+    while ((u32)__builtin_amdgcn_s_memrealtime() - t0 < hold) __builtin_amdgcn_s_sleep(32);
   }
   // ---- phase A: quantise the plane-chunk ----------------------------------------------------------------
   const bool head_start = item < fa.pre_limit && item % fa.pre_step == 0u;  // quantised by k_quantize already

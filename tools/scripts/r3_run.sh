@@ -1,11 +1,12 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-run() { env $2 timeout 200 tools/probes/encode_modes 4 > gpurun_out/r3K_$1.log 2>&1; echo "== $1 ($2): $(grep -o 'fused [0-9.]*' gpurun_out/r3K_$1.log | cut -d' ' -f2 | tr '\n' ' ')"; }
-run a "X=1"
-run b "LMC_SYM_PAD=0 LMC_SCRATCH_PAD=0"
-run c "X=1"
-run d "LMC_SYM_PAD=0 LMC_SCRATCH_PAD=0"
-run e "LMC_SCRATCH_PAD=0"
-run f "LMC_SYM_PAD=0"
-run g "LMC_SYM_PAD=65792 LMC_SCRATCH_PAD=1024"
-run h "LMC_SYM_PAD=20736 LMC_SCRATCH_PAD=4352"
-tail -3 gpurun_out/r3K_a.log
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r3M_pytest.log 2>&1; tail -3 gpurun_out/r3M_pytest.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r3M_bench.json 2> gpurun_out/r3M_bench.err
+bash tools/scripts/profile_round.sh r3prof > gpurun_out/r3M_prof.log 2>&1
+python - <<'PY'
+import json
+for f in ("gpurun_out/r3M_bench.json","gpurun_out/r3prof/stats.log"):
+    txt=open(f).read()
+    d=json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
+    print(f, d["ms_per_step"], d["value"], d["roofline"]["frac"], d.get("encode_paths"), d.get("seeds",{}).get("median"))
+PY
