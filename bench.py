@@ -791,7 +791,7 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
             for r in range(4):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                ctx.load_pack(harena.ptr, ph.total_bytes, 0, lay_p, 0, lpr, None, stream=sp, status_ptr=p_status)
+                ctx.load_pack(harena.ptr, ph.total_bytes, 0, 0, lay_p, 0, lpr, None, stream=sp, status_ptr=p_status)
                 stream.synchronize()
                 tl.append((time.perf_counter() - t0) * 1e3)
             loads[lpr] = median(tl[1:])

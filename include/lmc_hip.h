@@ -301,9 +301,9 @@ int lmc_load_chunks(lmc_ctx* ctx, const void* const* host_blob_ptrs_h, const uin
  * lmc_pack_info: check a pack's header and offset table (host only), return the header.
  * lmc_pack_extract: chunk `chunk` of a pack as the blob lmc_encode_chunks wrote, byte for byte (host only: the
  *   one-chunk path of the backend, and how the tests pin a pack to the oracle).
- * lmc_load_pack: the first `nchunks` chunks of the pack (0 = all) -> decoded KV in `dst`, chunk i at tokens
- *   dst_tok0 + i * chunk_tokens.  Offset table and static slots go first, then per range of `layers_per_range` layers
- *   (0 = all in one) the streams -- one copy per range for the whole pack, one per (layer, K/V) for a prefix of its
+ * lmc_load_pack: chunks [chunk_begin, chunk_begin + nchunks) of the pack (nchunks 0 = all that follow chunk_begin) ->
+ *   decoded KV in `dst`, chunk chunk_begin + i at tokens dst_tok0 + i * chunk_tokens.  Offset table and static slots go first, then per range of `layers_per_range` layers
+ *   (0 = all in one) the streams -- one copy per range for the whole pack, one per (layer, K/V) for a run of its
  *   chunks -- each followed by the range's decode on `stream` and, if given, range_events[r].  The pack must stay where it
  *   is until `stream` has completed.  LMC_ERR_INVALID, with nothing queued, if the pack does not check out.
  */
@@ -312,9 +312,9 @@ int lmc_store_pack(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin, in
                    lmc_stream_t stream);
 int lmc_pack_info(const void* pack_h, uint64_t nbytes, lmc_pack_header* out);
 int lmc_pack_extract(const void* pack_h, uint64_t nbytes, int32_t chunk, void* blob_out, uint64_t cap, uint32_t* size_out);
-int lmc_load_pack(lmc_ctx* ctx, const void* pack_h, uint64_t pack_bytes, int32_t nchunks, const lmc_kv_layout* dst,
-                  int32_t dst_tok0, int32_t layers_per_range, lmc_event_t* range_events, uint32_t* job_status,
-                  lmc_stream_t stream);
+int lmc_load_pack(lmc_ctx* ctx, const void* pack_h, uint64_t pack_bytes, int32_t chunk_begin, int32_t nchunks,
+                  const lmc_kv_layout* dst, int32_t dst_tok0, int32_t layers_per_range, lmc_event_t* range_events,
+                  uint32_t* job_status, lmc_stream_t stream);
 
 
 int lmc_stream_create(lmc_stream_t* out);

@@ -894,17 +894,18 @@ int lmc_pack_extract(const void* pack_h, uint64_t nbytes, int32_t chunk, void* b
   return LMC_OK;
 }
 
-int lmc_load_pack(lmc_ctx* c, const void* pack_h, uint64_t pack_bytes, int32_t nchunks, const lmc_kv_layout* dst,
-                  int32_t dst_tok0, int32_t layers_per_range, lmc_event_t* range_events, uint32_t* job_status,
-                  lmc_stream_t stream) {
+int lmc_load_pack(lmc_ctx* c, const void* pack_h, uint64_t pack_bytes, int32_t chunk_begin, int32_t nchunks,
+                  const lmc_kv_layout* dst, int32_t dst_tok0, int32_t layers_per_range, lmc_event_t* range_events,
+                  uint32_t* job_status, lmc_stream_t stream) {
   lmc_pack_header h;
-  if (!c || !layout_ok(dst) || layers_per_range < 0 || nchunks < 0 || !pack_ok((const u8*)pack_h, pack_bytes, &h))
+  if (!c || !layout_ok(dst) || layers_per_range < 0 || nchunks < 0 || chunk_begin < 0 ||
+      !pack_ok((const u8*)pack_h, pack_bytes, &h))
     return LMC_ERR_INVALID;
   const int L = dst->num_layers, H = dst->num_heads, D = dst->head_size;
   if ((uint32_t)L != h.num_layers || (uint32_t)H != h.num_heads || (uint32_t)D != h.head_size || H * D > LMC_MAX_CHANNELS ||
-      (uint32_t)nchunks > h.nchunks)
+      (uint32_t)chunk_begin >= h.nchunks || (uint32_t)nchunks > h.nchunks - (uint32_t)chunk_begin)
     return LMC_ERR_INVALID;
-  const int n = (int)h.nchunks, m = nchunks ? nchunks : n;  // the first m chunks of the pack
+  const int n = (int)h.nchunks, c0 = chunk_begin, m = nchunks ? nchunks : n - c0;  // chunks c0 .. c0 + m of the pack
   const u8* b = (const u8*)pack_h;
   const uint64_t* t = (const uint64_t*)(b + h.off_table);
   HIP_TRY(hipSetDevice(c->device));
@@ -922,23 +923,25 @@ int lmc_load_pack(lmc_ctx* c, const void* pack_h, uint64_t pack_bytes, int32_t n
   // the device copy keeps the pack's offsets: table, static slots and segments land where they lie in the pack
   u8* dev = c->load_slots;
   HIP_TRY(hipMemcpyAsync(dev + h.off_table, b + h.off_table, 8 * (2 * (size_t)L * n + 1), hipMemcpyHostToDevice, cs));
-  HIP_TRY(hipMemcpyAsync(dev + h.off_static, b + h.off_static, (size_t)m * h.static_stride, hipMemcpyHostToDevice, cs));
+  HIP_TRY(hipMemcpyAsync(dev + h.off_static + (size_t)c0 * h.static_stride, b + h.off_static + (size_t)c0 * h.static_stride,
+                         (size_t)m * h.static_stride, hipMemcpyHostToDevice, cs));
   DecodeArgs da;
   memset(&da, 0, sizeof da);
-  if ((rc = decode_common(c, dev + h.off_static, h.static_stride, m, L, H, D, job_status, da))) return rc;
+  if ((rc = decode_common(c, dev + h.off_static + (size_t)c0 * h.static_stride, h.static_stride, m, L, H, D, job_status, da)))
+    return rc;
   da.dst = to_addr(dst); da.dst_tok0 = dst_tok0; da.chunk_tokens = (int)h.chunk_tokens;
-  da.seg_off = (const unsigned long long*)(dev + h.off_table); da.seg_streams = dev + h.off_streams; da.seg_n = n;
+  da.seg_off = (const unsigned long long*)(dev + h.off_table) + c0; da.seg_streams = dev + h.off_streams; da.seg_n = n;
   int r = 0;
   for (int l0 = 0; l0 < L; l0 += step, r++) {
     const int nl = l0 + step <= L ? step : L - l0;
     // the streams of layers l0 .. l0 + nl: one contiguous region when the whole pack is wanted, else one run of the
-    // first m chunks per (layer, kv)
+    // m chunks per (layer, kv)
     if (m == n) {
       const uint64_t lo = t[(uint64_t)2 * l0 * n], hi = t[(uint64_t)2 * (l0 + nl) * n];
       if (hi > lo) HIP_TRY(hipMemcpyAsync(dev + h.off_streams + lo, b + h.off_streams + lo, hi - lo, hipMemcpyHostToDevice, cs));
     } else {
       for (int lk = 2 * l0; lk < 2 * (l0 + nl); lk++) {
-        const uint64_t lo = t[(uint64_t)lk * n], hi = t[(uint64_t)lk * n + m];
+        const uint64_t lo = t[(uint64_t)lk * n + c0], hi = t[(uint64_t)lk * n + c0 + m];
         if (hi > lo) HIP_TRY(hipMemcpyAsync(dev + h.off_streams + lo, b + h.off_streams + lo, hi - lo, hipMemcpyHostToDevice, cs));
       }
     }

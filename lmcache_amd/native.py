@@ -96,7 +96,7 @@ SYMBOLS = {
     "lmc_store_pack": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp, _vp]),
     "lmc_pack_info": (ctypes.c_int, [_vp, _u64, ctypes.POINTER(PackHeader)]),
     "lmc_pack_extract": (ctypes.c_int, [_vp, _u64, _i32, _vp, _u64, _vp]),
-    "lmc_load_pack": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _vp, _vp, _vp]),
+    "lmc_load_pack": (ctypes.c_int, [_vp, _vp, _u64, _i32, _i32, _PL, _i32, _i32, _vp, _vp, _vp]),
     "lmc_copy_kv": (ctypes.c_int, [_vp, _PL, _i32, _i32, _PL, _i32, _vp]),
     "lmc_pinned_alloc": (ctypes.c_int, [_sz, ctypes.POINTER(_vp)]),
     "lmc_pinned_free": (ctypes.c_int, [_vp]),
@@ -579,13 +579,14 @@ class Context:
                                    sizes_ptr, status_ptr, st), "lmc_store_pack")
         return (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
 
-    def load_pack(self, pack_ptr: int, pack_bytes: int, nchunks: int, dst: KVLayout, dst_tok0: int, layers_per_range: int = 0,
-                  range_events_ptr: Optional[int] = None, stream: Optional[int] = None, status_ptr: Optional[int] = None) -> None:
-        """lmc_load_pack: the first nchunks chunks (0 = all) of a pack in pinned host memory -> decoded KV, one transfer
-        and one decode per range of layers."""
+    def load_pack(self, pack_ptr: int, pack_bytes: int, chunk_begin: int, nchunks: int, dst: KVLayout, dst_tok0: int,
+                  layers_per_range: int = 0, range_events_ptr: Optional[int] = None, stream: Optional[int] = None,
+                  status_ptr: Optional[int] = None) -> None:
+        """lmc_load_pack: chunks [chunk_begin, chunk_begin + nchunks) (nchunks 0 = all that follow) of a pack in pinned
+        host memory -> decoded KV, one transfer and one decode per range of layers."""
         st = current_stream_ptr(dst.device) if stream is None else stream
-        check(lib().lmc_load_pack(self.handle, pack_ptr, pack_bytes, nchunks, ctypes.byref(dst.struct), dst_tok0, layers_per_range,
-                                  range_events_ptr, status_ptr, st), "lmc_load_pack")
+        check(lib().lmc_load_pack(self.handle, pack_ptr, pack_bytes, chunk_begin, nchunks, ctypes.byref(dst.struct), dst_tok0,
+                                  layers_per_range, range_events_ptr, status_ptr, st), "lmc_load_pack")
 
     def decode_symbols(self, blob: torch.Tensor, L: int, H: int, D: int, T: int, stream: Optional[int] = None
                        ) -> torch.Tensor:

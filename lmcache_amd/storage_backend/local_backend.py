@@ -391,11 +391,11 @@ class LMCLocalBackend(LMCBackendInterface):
         if self.mode == "cachegen":
             codec = self._codec()
             e0 = entries[0]
-            if isinstance(e0, _PackChunk) and all(isinstance(e, _PackChunk) and e.pack is e0.pack and e.index == i
+            if isinstance(e0, _PackChunk) and all(isinstance(e, _PackChunk) and e.pack is e0.pack and e.index == e0.index + i
                                                   for i, e in enumerate(entries)) and e0.pack.chunk_tokens == chunk_tokens:
-                # the leading chunks of ONE pack: a transfer and a decode per range of layers (lmc_load_pack)
+                # consecutive chunks of ONE pack: a transfer and a decode per range of layers (lmc_load_pack)
                 with torch.cuda.device(dev):
-                    job = codec.load_pack(e0.pack, len(entries), dst, dst_tok0, layers_per_launch)
+                    job = codec.load_pack(e0.pack, e0.index, len(entries), dst, dst_tok0, layers_per_launch)
                 if layers_per_launch and jobs_out is not None:
                     jobs_out.append((codec, job))
                 else:

@@ -585,8 +585,9 @@ class CacheGenDeviceCodec:
         h = native.pack_info(region.ptr, total)  # the pack checks out where it lies now
         return HostPack(HostBlob(region.slab, region.offset, int(h.total_bytes)), job.nchunks, job.chunk_tokens)
 
-    def load_pack(self, pack: HostPack, nchunks: int, dst: native.KVLayout, dst_tok0: int, layers_per_range) -> DecodeJob:
-        """The first `nchunks` chunks of a pack -> decoded KV through ONE C-ABI call (lmc_load_pack): the streams of a
+    def load_pack(self, pack: HostPack, chunk_begin: int, nchunks: int, dst: native.KVLayout, dst_tok0: int,
+                  layers_per_range) -> DecodeJob:
+        """Chunks [chunk_begin, chunk_begin + nchunks) of a pack -> decoded KV through ONE C-ABI call (lmc_load_pack): the streams of a
         range of layers are one contiguous transfer, the range's decode follows it, an event per range
         (DecodeJob.layer_events) lets the model run layer 0 while the later ranges are still crossing PCIe."""
         step = layers_per_range if isinstance(layers_per_range, int) or not layers_per_range else int(list(layers_per_range)[0])
@@ -598,7 +599,7 @@ class CacheGenDeviceCodec:
             handles = (ctypes.c_void_p * len(events))(*[e.handle for e in events])
             st = self._status.acquire()
             try:
-                self.ctx.load_pack(pack.blob.ptr, pack.blob.nbytes, 0 if nchunks >= pack.nchunks else nchunks, dst, dst_tok0, step,
+                self.ctx.load_pack(pack.blob.ptr, pack.blob.nbytes, chunk_begin, nchunks, dst, dst_tok0, step,
                                    ctypes.cast(handles, ctypes.c_void_p).value, stream=cur.cuda_stream,
                                    status_ptr=self._status.ptr(st))
             except BaseException:

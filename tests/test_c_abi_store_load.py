@@ -143,7 +143,7 @@ def test_pack_store_extract_load_through_the_c_abi_only(nat, oracle, shape):
     assert h.total_bytes <= sum(len(b) for b in blobs) + 256 + 8 * (2 * L * n + 1) + 16 + 16 * n + 4 * L * cs + 64
     refs = [oracle.decode_blob(b, oracle.BF16) for b in blobs]
 
-    def load(m):
+    def load(m, c0=0):
         out = torch.zeros_like(kv_d)
         nranges = (L + lpr - 1) // lpr if lpr else 1
         ev = (ctypes.c_void_p * nranges)()
@@ -152,32 +152,35 @@ def test_pack_store_extract_load_through_the_c_abi_only(nat, oracle, shape):
             nat.check(nat.lib().lmc_event_create(ctypes.byref(e), 0), "lmc_event_create")
             ev[r] = e
         status[0] = 0
-        ctx.load_pack(region.ptr, h.total_bytes, m, nat.KVLayout.from_chunk(out, "vllm"), 0, lpr,
+        ctx.load_pack(region.ptr, h.total_bytes, c0, m, nat.KVLayout.from_chunk(out, "vllm"), c0 * cs, lpr,
                       ctypes.cast(ev, ctypes.c_void_p).value, stream=st.cuda_stream, status_ptr=meta.ptr + 4 * n)
         for r in range(nranges):
             nat.check(nat.lib().lmc_event_synchronize(ev[r]), "lmc_event_synchronize")
             nat.lib().lmc_event_destroy(ev[r])
         st.synchronize()
         assert int(status[0]) == 0
-        mm = m or n
+        mm = m or n - c0
         for i in range(n):
             t0, t1 = i * cs, min(T, (i + 1) * cs)
             got = _bits(out[:, :, t0:t1]).reshape(L, 2, t1 - t0, H * D)
-            if i < mm:
-                assert np.array_equal(got, refs[i]), f"chunk {i} of {mm}"
+            if c0 <= i < c0 + mm:
+                assert np.array_equal(got, refs[i]), f"chunk {i} of [{c0}, {c0 + mm})"
             else:
-                assert not got.any(), f"chunk {i} is outside the prefix and must stay untouched"
+                assert not got.any(), f"chunk {i} is outside the run and must stay untouched"
 
     load(0)
     if prefix:
         load(prefix)
+    if n > 2:  # a run in the middle, and the tail from chunk 1 on
+        load(n - 2, 1)
+        load(0, 1)
     # a corrupt offset table is refused on the host, before anything is queued
     tab = ctypes.cast(region.ptr + h.off_table, ctypes.POINTER(ctypes.c_uint64))
     keep = tab[1]
     tab[1] = keep + 16 if n * 2 * L > 1 else keep
     tab[2 * L * n] += 16
     with pytest.raises(nat.NativeError):
-        ctx.load_pack(region.ptr, h.total_bytes, 0, nat.KVLayout.from_chunk(torch.zeros_like(kv_d), "vllm"), 0, lpr, None,
+        ctx.load_pack(region.ptr, h.total_bytes, 0, 0, nat.KVLayout.from_chunk(torch.zeros_like(kv_d), "vllm"), 0, lpr, None,
                       stream=st.cuda_stream, status_ptr=meta.ptr + 4 * n)
     # a region that is too small: flagged, and what it holds is not a pack
     status[0] = 0
