@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256) void k_pack_scan(PackArgs a) {
   }
   if (t == 0) {
     a.table_d[N] = fits ? total : ~0ull;  // all ones: nothing is copied
-    if (fits) table_h[N] = total;
+    if (fits) {
+      table_h[N] = total;
+      if (a.hdr.off_static > a.hdr.off_table + 8ull * (unsigned long long)(N + 1)) table_h[N + 1] = 0ull;  // alignment pad
+    }
     lmc_pack_header h = a.hdr;
     h.total_bytes = fits ? a.hdr.off_streams + total : 0ull;  // 0: not a pack
     if (!fits) h.magic = 0u;
@@ -167,8 +170,11 @@ __global__ __launch_bounds__(256) void k_pack_copy(PackArgs a) {
       const int chunk = item - N;
       const u8* blob = a.blobs + (long long)chunk * a.stride;
       const u32 bytes = min((reinterpret_cast<const u32*>(blob)[15] + 15u) & ~15u, a.hdr.static_stride);
-      pack_copy16(reinterpret_cast<uint4*>(a.host + a.hdr.off_static + (unsigned long long)chunk * a.hdr.static_stride),
-                  reinterpret_cast<const uint4*>(blob), bytes >> 4);
+      uint4* slot = reinterpret_cast<uint4*>(a.host + a.hdr.off_static + (unsigned long long)chunk * a.hdr.static_stride);
+      pack_copy16(slot, reinterpret_cast<const uint4*>(blob), bytes >> 4);
+      // a ragged last chunk has shorter static sections than its slot: the rest reads zero (a pack is a function of
+      // its blobs, byte for byte)
+      for (u32 i = (bytes >> 4) + threadIdx.x; i < (a.hdr.static_stride >> 4); i += 256u) slot[i] = make_uint4(0, 0, 0, 0);
     }
   }
 }

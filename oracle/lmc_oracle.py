@@ -245,3 +245,56 @@ def bits_to_torch(a: np.ndarray, code: int):
     import torch
     t = torch.from_numpy(np.ascontiguousarray(a).view(np.int16))
     return t.view(torch.bfloat16 if code == BF16 else torch.float16)
+
+
+def pack_from_blobs(blobs, chunk_tokens: int) -> bytes:
+    """CPU restatement of the pack layout (include/lmc_format.h, "pack"): the blobs of one store call -- all of the same
+    geometry, every chunk but possibly the last of `chunk_tokens` tokens -- transposed layer-major.  Test infrastructure:
+    what lmc_store_pack must produce byte for byte."""
+    import struct
+    hs = [parse_header(b) for b in blobs]
+    h0 = hs[0]
+    n, L, H, D, G = len(blobs), h0["num_layers"], h0["num_heads"], h0["head_size"], h0["ngroups"]
+    assert all((h["num_layers"], h["num_heads"], h["head_size"]) == (L, H, D) for h in hs)
+    r16 = lambda x: (x + 15) & ~15
+    # lmc_blob_layout for a chunk_tokens-token blob of this geometry: where its streams would start
+    P, C = 2 * L, H * D
+    cb = 1 if chunk_tokens <= 256 else 2
+    off = 128 + r16(P)                       # header | bins
+    off += r16(2 * (P + 1))                  # rowpre
+    off += r16(2 * P * chunk_tokens)         # scales
+    off += r16(4 * P)                        # scale checksums
+    off += r16(cb * C * h0["cdf_rows"])      # symbol counts
+    off += r16(4 * P * G)                    # stream directory
+    static_stride = r16(off)
+    assert all(h["ntokens"] == chunk_tokens for h in hs[:-1]) and all(h["off_streams"] <= static_stride for h in hs)
+    assert any(h["ntokens"] != chunk_tokens for h in hs) or h0["off_streams"] == off
+    N = 2 * L * n
+    off_table = 256
+    off_static = r16(off_table + 8 * (N + 1))
+    off_streams = off_static + n * static_stride
+    segs, table, at = [], [], 0
+    for layer in range(L):
+        for kv in range(2):
+            p = kv * L + layer
+            for c, (b, h) in enumerate(zip(blobs, hs)):
+                gend = np.frombuffer(b, dtype=np.uint32, count=2 * L * G, offset=h["off_gend"])
+                s0 = r16(int(gend[p * G - 1])) if p else 0
+                s1 = r16(int(gend[(p + 1) * G - 1]))
+                table.append(at)
+                segs.append(b[h["off_streams"] + s0:h["off_streams"] + s1])
+                at += s1 - s0
+    table.append(at)
+    ntok = sum(h["ntokens"] for h in hs)
+    head = struct.pack("<12I4Q", 0x4b504d4c, 1, 256, n, L, H, D, chunk_tokens, G, static_stride, ntok, 0,
+                       off_table, off_static, off_streams, off_streams + at)
+    out = bytearray(off_streams + at)
+    out[:len(head)] = head
+    out[off_table:off_table + 8 * (N + 1)] = struct.pack(f"<{N + 1}Q", *table)
+    for c, (b, h) in enumerate(zip(blobs, hs)):
+        out[off_static + c * static_stride:off_static + c * static_stride + h["off_streams"]] = b[:h["off_streams"]]
+    pos = off_streams
+    for sgm in segs:
+        out[pos:pos + len(sgm)] = sgm
+        pos += len(sgm)
+    return bytes(out)

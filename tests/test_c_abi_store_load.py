@@ -138,6 +138,8 @@ def test_pack_store_extract_load_through_the_c_abi_only(nat, oracle, shape):
         got = nat.pack_extract(region.ptr, h.total_bytes, i)
         assert got == blobs[i], f"chunk {i}"
         assert int(sizes[i]) == len(blobs[i])
+    # ... and the pack as a whole is the oracle's restatement of the layout, byte for byte
+    assert ctypes.string_at(region.ptr, h.total_bytes) == oracle.pack_from_blobs(blobs, cs)
     # the pack holds the blobs' bytes once, plus its header, table and slot padding
     # (a ragged last chunk has shorter static sections than its slot)
     assert h.total_bytes <= sum(len(b) for b in blobs) + 256 + 8 * (2 * L * n + 1) + 16 + 16 * n + 4 * L * cs + 64

@@ -304,3 +304,45 @@ def test_encode_path_names_follow_the_header():
     hdr = open(os.path.join(ROOT, "include", "lmc_hip.h")).read()
     consts = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define LMC_ENCODE_PATH_(\w+)\s+(\d+)", hdr)}
     assert consts == native.ENCODE_PATHS
+
+
+def test_pack_info_and_extract_on_the_host():
+    """lmc_pack_info / lmc_pack_extract are host-only (no GPU): a pack built by the oracle's restatement of the layout
+    from oracle blobs (a ragged last chunk included) checks out, every chunk comes back byte for byte, and damaged
+    headers / tables are refused."""
+    import ctypes
+    import numpy as np
+    from lmcache_amd import native
+    from oracle import lmc_oracle as oracle
+    oracle.build()
+    L, H, D, cs, T = 2, 3, 128, 256, 600
+    rng = np.random.default_rng(11)
+    kv = (rng.standard_normal((L, 2, T, H * D)).astype(np.float32))
+    bins = np.array([32, 16, 17, 16], np.int32)
+    blobs = []
+    for t0 in range(0, T, cs):
+        bits = np.ascontiguousarray((kv[:, :, t0:t0 + cs].view(np.uint32) >> 16).astype(np.uint16))  # truncated bf16: any bits do
+        blobs.append(oracle.encode_blob(bits, oracle.BF16, H, D, bins))
+    pack = oracle.pack_from_blobs(blobs, cs)
+    buf = ctypes.create_string_buffer(pack, len(pack))
+    ptr = ctypes.addressof(buf)
+    assert ptr % 16 == 0
+    h = native.pack_info(ptr, len(pack))
+    assert (h.nchunks, h.num_layers, h.num_heads, h.head_size, h.chunk_tokens, h.ntokens) == (3, L, H, D, cs, T)
+    assert h.total_bytes == len(pack)
+    for i, b in enumerate(blobs):
+        assert native.pack_extract(ptr, len(pack), i) == b
+    with pytest.raises(native.NativeError):
+        native.pack_extract(ptr, len(pack), 3)
+    # damage: magic, a table entry out of order, a total that does not match, a truncated buffer
+    for off, val in ((0, b"\x00"), (256 + 8 * 2, b"\xff\xff\xff\xff\xff\xff\xff\x7f"), (72, None)):
+        bad = bytearray(pack)
+        if val is None:
+            bad[off] ^= 0x10  # total_bytes off by 16
+        else:
+            bad[off:off + len(val)] = val
+        bb = ctypes.create_string_buffer(bytes(bad), len(bad))
+        with pytest.raises(native.NativeError):
+            native.pack_info(ctypes.addressof(bb), len(bad))
+    with pytest.raises(native.NativeError):
+        native.pack_info(ptr, len(pack) - 16)
