@@ -73,10 +73,15 @@ __device__ __forceinline__ u32 quant_special(float x, float factor, float maxf) 
 // workspace round trip of most planes is half a byte per element.
 // ROWS (4 or 2): rows loaded and reduced together -- 4 keeps 4*NITER 16-byte loads in flight per lane,
 // 2 halves the registers.
-template <int G, int NITER, int DT, bool QUAD, bool NIB, int ROWS = 4, int NQ = NIB ? 2 : 1>
+// SPLIT > 1 (planes of more than 1024 channels, workspace output): SPLIT waves of the workgroup share the task, wave
+// `slice` takes channels [slice, slice + 1) * NITER * 512, and the row maxima meet in `xmax` (LDS, [8][SPLIT]) behind
+// ONE workgroup barrier per task -- a wave then holds 8 rows x 1024 channels (98 VGPRs, 4 waves per SIMD) where a
+// whole 4096-channel row per wave costs 241 VGPRs and 2 waves per SIMD (C = 4096: 3.5 -> 4.3 TB/s).
+template <int G, int NITER, int DT, bool QUAD, bool NIB, int ROWS = 4, int NQ = NIB ? 2 : 1, int SPLIT = 1>
 __device__ __forceinline__ void quantize_task(const KvAddr& src, int p, int tok0, int Tc, int t_first, bool qvalid,
                                               bool q1valid, int C, float maxf, u32* sym_out, int8_t* sym8_plane,
-                                              u16* scale_out, int sl) {
+                                              u16* scale_out, int sl, int slice = 0, u32* xmax = nullptr) {
+  static_assert(SPLIT == 1 || (QUAD && ROWS == 4 * NQ), "a split task exchanges all its rows' maxima at once");
   static_assert(ROWS == 2 || ROWS == 4 || (ROWS == 8 && NQ == 2), "rows in flight: a power of two within the task");
   static_assert(QUAD || (!NIB && NQ == 1), "nibble packing and two-quad tasks are workspace formats");
   static_assert(!NIB || NQ == 2, "a nibble dword holds two row quads");
@@ -86,7 +91,7 @@ __device__ __forceinline__ void quantize_task(const KvAddr& src, int p, int tok0
   bool cval[NITER];
 #pragma unroll
   for (int it = 0; it < NITER; it++) {
-    c0[it] = (it * G + sl) * 8;
+    c0[it] = ((slice * NITER + it) * G + sl) * 8;
     cval[it] = c0[it] < C;
     int h = c0[it] / src.D, d = c0[it] - h * src.D;
     coff[it] = (long long)h * src.stride_head + d;
@@ -142,8 +147,22 @@ __device__ __forceinline__ void quantize_task(const KvAddr& src, int p, int tok0
       mrow[r + 1] = m2 >> 16;
     }
 
-    // scales: first lane of the group
-    if (sl == 0) {
+    if constexpr (SPLIT > 1) {  // the row maxima of the SPLIT channel slices meet in LDS
+      if (sl == 0) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) xmax[r * SPLIT + slice] = mrow[r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) {
+        u32 m = 0;
+#pragma unroll
+        for (int k = 0; k < SPLIT; k++) m = max(m, xmax[r * SPLIT + k]);
+        mrow[r] = m;
+      }
+    }
+    // scales: first lane of the group (of the first slice)
+    if (sl == 0 && slice == 0) {
 #pragma unroll
       for (int r = 0; r < ROWS; r++)
         if (tv[r]) scale_out[r0 + r] = (u16)mrow[r];
@@ -233,9 +252,11 @@ __device__ __forceinline__ void quantize_task(const KvAddr& src, int p, int tok0
 // get the nibble-packed workspace format (one dword per channel for the oct), the others two row quads.
 // grid = (ceil(TO / (4 * RPW)), P, chunks), TO = ceil(TQ / 2): plane and chunk come straight from the block
 // index, and with G = 64 everything but the channel offset is wave-uniform and lives in SGPRs.
-template <int G, int NITER, int DT, bool QUAD>
+template <int G, int NITER, int DT, bool QUAD, int SPLIT = 1>
 __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
+  static_assert(SPLIT == 1 || (QUAD && G == LMC_WAVE && (SPLIT == 2 || SPLIT == 4)), "split tasks: whole waves, workspace output");
   constexpr int RPW = LMC_WAVE / G;  // tasks per wave
+  __shared__ u32 xmax[SPLIT > 1 ? (4 / SPLIT) * 8 * SPLIT : 1];  // row maxima of the split tasks of this workgroup
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int sub = lane / G, sl = lane % G;
@@ -250,7 +271,8 @@ __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
     if (i < a.agg_n) a.agg[i] = 0ull;
   }
   const int TO = (a.TQ + 1) >> 1;
-  int oct = ((int)blockIdx.x * 4 + wave) * RPW + sub;
+  int oct = SPLIT > 1 ? ((int)blockIdx.x * 4 + wave) / SPLIT : ((int)blockIdx.x * 4 + wave) * RPW + sub;
+  const int slice = SPLIT > 1 ? wave % SPLIT : 0;
   const bool ovalid = oct < TO && chunk * a.P + p < a.pc_limit;
   if (!ovalid) oct = 0;
   const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
@@ -264,12 +286,13 @@ __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
     constexpr int ROWS = NITER <= 2 ? 8 : 4;  // 16-byte loads in flight per lane: ROWS * NITER
     u32* const sym_out = sym_pc + (long long)oct * (lmc_sym_nibbles(bins) ? 1 : 2) * a.C;
     const bool q1valid = 2 * oct + 1 < a.TQ;
+    u32* const xm = xmax + (SPLIT > 1 ? (wave / SPLIT) * 8 * SPLIT : 0);  // this task's exchange slots
     if (lmc_sym_nibbles(bins))
-      quantize_task<G, NITER, DT, true, true, ROWS, 2>(a.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out,
-                                                       nullptr, scale_out, sl);
+      quantize_task<G, NITER, DT, true, true, ROWS, 2, SPLIT>(a.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out,
+                                                              nullptr, scale_out, sl, slice, xm);
     else
-      quantize_task<G, NITER, DT, true, false, ROWS, 2>(a.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out,
-                                                        nullptr, scale_out, sl);
+      quantize_task<G, NITER, DT, true, false, ROWS, 2, SPLIT>(a.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out,
+                                                               nullptr, scale_out, sl, slice, xm);
   } else {
 #pragma unroll 1
     for (int hq = 0; hq < 2; hq++) {

@@ -231,14 +231,22 @@ static int launch_quant_dt(const QuantArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((TO + per_wg - 1) / per_wg), (unsigned)a.P, nz);                        \
     hipLaunchKernelGGL((k_quantize<G, N, DT, QUAD>), grid, dim3(256), 0, s, a);                    \
   } while (0)
+  // wide planes, workspace output: SPLIT waves share a row oct, 1024 channels each (k_quantize.h)
+#define LQS(SPLIT)                                                                                 \
+  do {                                                                                             \
+    const int TO = (a.TQ + 1) / 2, per_wg = 4 / (SPLIT);                                           \
+    dim3 grid((unsigned)((TO + per_wg - 1) / per_wg), (unsigned)a.P, nz);                        \
+    hipLaunchKernelGGL((k_quantize<64, 2, DT, QUAD, QUAD ? SPLIT : 1>), grid, dim3(256), 0, s, a); \
+  } while (0)
   if (C <= 128) LQ(16, 1);
   else if (C <= 256) LQ(32, 1);
   else if (C <= 512) LQ(64, 1);
   else if (C <= 1024) LQ(64, 2);
-  else if (C <= 2048) LQ(64, 4);
-  else if (C <= 4096) LQ(64, 8);
+  else if (C <= 2048) { if (QUAD) LQS(2); else LQ(64, 4); }
+  else if (C <= 4096) { if (QUAD) LQS(4); else LQ(64, 8); }
   else return LMC_ERR_INVALID;
 #undef LQ
+#undef LQS
   HIP_TRY(hipGetLastError());
   return LMC_OK;
 }

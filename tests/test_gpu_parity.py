@@ -122,7 +122,11 @@ CHUNK_SHAPES = [
     (2, 3, 1, 128, torch.bfloat16, "outlier"),  # C=128: one KV head per rank (70B TP=8)
     (2, 50, 2, 128, torch.float16, "randn"),
     (1, 33, 5, 128, torch.bfloat16, "outlier"),  # C=640: partial last group
-    (1, 40, 32, 128, torch.float16, "rand"),     # C=4096: BASELINE config 1 head count
+    (1, 40, 32, 128, torch.float16, "rand"),     # C=4096: BASELINE config 1 head count (four waves share a row oct)
+    (1, 256, 32, 128, torch.bfloat16, "outlier"),  # ... a full chunk of it, counts model
+    (1, 70, 16, 128, torch.bfloat16, "randn"),   # C=2048: two waves share a row oct
+    (1, 45, 12, 128, torch.float16, "outlier"),  # C=1536: the second wave's slice is half empty
+    (1, 29, 20, 128, torch.bfloat16, "rand"),    # C=2560: the fourth wave's slice is empty
     (3, 16, 3, 40, torch.float16, "randn"),      # C=120 (not a multiple of 64)
     (1, 300, 2, 64, torch.bfloat16, "randn"),    # T > 256: no 256-token sub-chunking needed
 ]
