@@ -491,10 +491,17 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
   t.chunk = chunk; t.pg = p * a.G + g; t.exact = exact; t.T = (u32)Tc; t.out = out;
 }
 
-// ---- the two-kernel path's coder launch: one wave per group stream, ENC_WAVES streams per workgroup ----------
-template <bool QUADSYM, bool ENCODE>
-__global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
-  __shared__ __attribute__((aligned(16))) u32 lds_all[ENC_WAVES * ENC_WAVE_DWORDS];  // the staging rings, then the tables
+// ---- the two-kernel path's coder launch: one wave per group stream, NW streams per workgroup ----------------
+// <.., ENC_WAVES, false>: any chunk length (CDF16 or counts per stream), 4 waves and 21.5 KB of LDS per workgroup:
+//     7 workgroups = 28 waves per CU.
+// <.., 8, true>: launches whose chunks are all 256 tokens long (the counts model only: 4 KiB tables, one 2 KiB
+//     reciprocal table shared by 8 waves): 39.9 KB per workgroup, 4 workgroups = 32 waves per CU -- the coder's time
+//     falls with every wave there is to interleave.
+template <bool QUADSYM, bool ENCODE, int NW = ENC_WAVES, bool COUNTS_ONLY = false>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 8 : 4, 8))) void k_cdf_encode(EncodeArgs a) {
+  static_assert(!COUNTS_ONLY || (QUADSYM && ENCODE), "the counts coder reads the workspace and places its streams");
+  constexpr int TAB_DWORDS = COUNTS_ONLY ? CNT_TAB_DWORDS : ENC_TAB_DWORDS;
+  __shared__ __attribute__((aligned(16))) u32 lds_all[NW * (ENC_RING_DWORDS + TAB_DWORDS)];  // the staging rings, then the tables
   __shared__ __attribute__((aligned(16))) u32 rtab_lds[ENCODE ? RTAB_DWORDS : 4];         // counts model: reciprocals
 #ifdef LMC_EXP_CDF_LDS_PAD  // timing experiment: fewer workgroups per CU (occupancy sweep of the coder)
   __shared__ u32 lds_pad[LMC_EXP_CDF_LDS_PAD];
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
   // everything derived from the wave id is wave-uniform: keep it in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long ngroups_total = (long long)a.nchunks * a.P * a.G;
-  u32* hist = lds_all + ENC_WAVES * ENC_RING_DWORDS + wave * ENC_TAB_DWORDS;  // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
+  u32* hist = lds_all + NW * ENC_RING_DWORDS + wave * TAB_DWORDS;  // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
 
   // Workgroup -> streams.  When the streams of a chunk fill whole workgroups, consecutive workgroups take the SAME
   // position of consecutive CHUNKS (chunk = block % nchunks): the predecessors a workgroup's placement depends on
@@ -519,16 +526,18 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
   // below only ever waits for workgroups that are running already
   u32 item = blockIdx.x;
   if constexpr (ENCODE) item = (u32)__builtin_amdgcn_readfirstlane((int)draw_ticket(a.ticket, a.ticket_base));
-  long long gid = (long long)item * ENC_WAVES + wave;
-  if (ENCODE && (a.P * a.G) % ENC_WAVES == 0) {
-    const int wpc = a.P * a.G / ENC_WAVES;  // workgroups per chunk
+  long long gid = (long long)item * NW + wave;
+  if (ENCODE && (a.P * a.G) % NW == 0) {
+    const int wpc = a.P * a.G / NW;  // workgroups per chunk
     const int ch = (int)(item % (unsigned)a.nchunks), pos = (int)(item / (unsigned)a.nchunks);
-    gid = ((long long)ch * wpc + pos) * ENC_WAVES + wave;
+    gid = ((long long)ch * wpc + pos) * NW + wave;
   }
   if (gid >= ngroups_total) return;
   PendingTile t;
   u16* const wring = reinterpret_cast<u16*>(lds_all + wave * (ENC_RING_DWORDS));
-  if constexpr (ENCODE && QUADSYM) {
+  if constexpr (COUNTS_ONLY) {
+    encode_group_stream_counts<LMC_COUNTS_LDSASM>(a, gid, hist, wring, rtab_lds, lane, t);
+  } else if constexpr (ENCODE && QUADSYM) {
     // 256-token chunks are coded on their symbol counts (LMC_MODEL_COUNTS), every other length on the 16-bit CDF
     const int chunk_of = (int)(gid / ((long long)a.P * a.G));
     const bool counts_model =
@@ -544,23 +553,23 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_cdf_encode(EncodeArgs a) {
   const int chunk = t.chunk;
   const u32 padded = (t.exact + 15u) & ~15u;
   unsigned long long* agg = a.agg + (long long)chunk * n;
-  if (n % ENC_WAVES == 0) {
+  if (n % NW == 0) {
     // The waves of a workgroup hold consecutive streams of one chunk: they add their lengths up in LDS and
-    // ONE wave runs the look-back over workgroup-level granules -- 1/ENC_WAVES of the granules, and of the
+    // ONE wave runs the look-back over workgroup-level granules -- 1/NW of the granules, and of the
     // walk when a whole chunk finishes at once and nobody has an inclusive prefix yet.
-    __shared__ u32 wg_len[ENC_WAVES];
+    __shared__ u32 wg_len[NW];
     __shared__ u32 wg_excl;
     if (lane == 0) wg_len[wave] = padded;
     __syncthreads();
     u32 intra = 0, wg_total = 0;
 #pragma unroll
-    for (int w = 0; w < ENC_WAVES; w++) {
+    for (int w = 0; w < NW; w++) {
       const u32 l = wg_len[w];
       intra += w < wave ? l : 0u;
       wg_total += l;
     }
     if (wave == 0) {
-      const int wgi = t.pg / ENC_WAVES;
+      const int wgi = t.pg / NW;
       if (lane == 0 && wgi > 0) agg_store(agg + wgi, AGG_A, wg_total);
       const u32 e = lookback_exclusive(agg, wgi, lane, a.status);
       if (lane == 0) {

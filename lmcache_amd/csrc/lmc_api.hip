@@ -412,10 +412,14 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     if ((r = launch_quant<true>(qa, s))) return r;
     if ((r = prof_mark(c, s))) return r;
     const long long ngroups = (long long)n * PG;
-    const unsigned nwg = (unsigned)((ngroups + ENC_WAVES - 1) / ENC_WAVES);
+    // launches of 256-token chunks only take the counts-only coder: 8 waves per workgroup, 32 waves per CU
+    const bool counts_only = chunk_tokens == (int)LMC_COUNTS_T && e2.tok_begin + n * chunk_tokens <= tok_end && PG % 8 == 0;
+    const int nw = counts_only ? 8 : ENC_WAVES;
+    const unsigned nwg = (unsigned)((ngroups + nw - 1) / nw);
     e2.ticket_base = c->tickets_drawn;
     c->tickets_drawn += nwg;
-    hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3(nwg), dim3(64 * ENC_WAVES), 0, s, e2);
+    if (counts_only) hipLaunchKernelGGL((k_cdf_encode<true, true, 8, true>), dim3(nwg), dim3(64 * 8), 0, s, e2);
+    else hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3(nwg), dim3(64 * ENC_WAVES), 0, s, e2);
     HIP_TRY(hipGetLastError());
     return prof_mark(c, s);
   };
@@ -477,6 +481,9 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     HIP_TRY(hipGetLastError());
     if ((rc = prof_mark(c, s))) return rc;
     if (nfull < nchunks && (rc = two_kernels(nfull, nchunks - nfull))) return rc;  // the ragged last chunk
+  } else if (nfull > 0 && nfull < nchunks && chunk_tokens == (int)LMC_COUNTS_T) {
+    // the full chunks with the counts-only coder, the ragged last one with the general one
+    if ((rc = two_kernels(0, nfull)) || (rc = two_kernels(nfull, nchunks - nfull))) return rc;
   } else {
     if ((rc = two_kernels(0, nchunks))) return rc;
   }
