@@ -335,6 +335,24 @@ def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=Fal
 
 
 # ---------------------------------------------------------------------------------------------- main
+def arm_watchdog(seconds, res, rank):
+    """If the multi-GPU legs are not done after `seconds`, rank 0 prints the result of the timed region (which is
+    complete by then) and every rank exits: a hung leg must not cost the run its one JSON line."""
+    import threading
+
+    def fire():
+        if rank == 0:
+            out = dict(res)
+            out["multi_gpu_legs"] = f"not finished after {seconds} s (watchdog); the timed region above is unaffected"
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,6 +366,7 @@ def main(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="only the timed region and the roofline")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the cpu_baseline sample (0 = auto)")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the exchange leg")
+    ap.add_argument("--legs-timeout", type=int, default=180, help="N>1: seconds the offload / exchange legs may take")
     ap.add_argument("--exchange-transport", choices=("both", "ipc", "rccl"), default="both",
                     help="N>1 exchange leg: HIP-IPC connector (xgmi://), RCCL batch_isend_irecv (XgmiShardStore), or both")
     args = ap.parse_args(argv)
@@ -448,22 +467,6 @@ def main(argv=None):
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * raw_bytes * args.steps / elapsed / 1e9
 
-    # ---- N>1: every rank's own offload leg at the same time (its PCIe link, its NUMA-local arena), and one
-    # exchange step of encoded chunks through the xgmi:// connector (BASELINE configs[2]); outside the timed region
-    offload_all = exchange = None
-    if use_dist and not STUB and not args.no_extras:
-        offload_all = all_ranks_offload(ctx, layout, bins, dev, local_rank, world)
-        if not args.no_exchange:
-            exchange = exchange_leg(blobs, sizes, stride, nchunks, rank, world, dev,
-                                    ("ipc", "rccl") if args.exchange_transport == "both" else (args.exchange_transport,))
-
-    if rank != 0:
-        if use_dist:
-            dist.barrier()
-            sync()
-            dist.destroy_process_group()
-        return
-
     res = {"metric": "KV encode+offload GB/s per GPU -- value = CacheGen encode, HBM -> HBM (raw 16-bit KV bytes consumed, "
                      "PCIe never inside value); the PCIe-inclusive encode+offload rate is offload.encode_plus_offload_GBps_raw_kv",
            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -477,6 +480,26 @@ def main(argv=None):
            "clock_ramp": {"untimed_steps_before_warmup": ramp_steps, "ms": args.ramp_ms,
                           "why": "a GPU fresh out of idle runs its first ~50 ms below its sustained clock; W + K steps "
                                  "of this workload are shorter than that (--ramp-ms 0 turns it off)"}}
+    # ---- N>1: every rank's own offload leg at the same time (its PCIe link, its NUMA-local arena), and one
+    # exchange step of encoded chunks (BASELINE configs[2]) by HIP-IPC and by RCCL; outside the timed region.  A
+    # watchdog guards the contract: should a multi-GPU leg hang (a peer that died, a collective out of step), rank 0
+    # still prints the JSON line of the timed region and every rank leaves.
+    offload_all = exchange = None
+    if use_dist and not STUB and not args.no_extras:
+        wd = arm_watchdog(args.legs_timeout, res, rank)
+        offload_all = all_ranks_offload(ctx, layout, bins, dev, local_rank, world)
+        if not args.no_exchange:
+            exchange = exchange_leg(blobs, sizes, stride, nchunks, rank, world, dev,
+                                    ("ipc", "rccl") if args.exchange_transport == "both" else (args.exchange_transport,))
+        wd.cancel()
+
+    if rank != 0:
+        if use_dist:
+            dist.barrier()
+            sync()
+            dist.destroy_process_group()
+        return
+
     if STUB:
         res["data"] = "stub (CPU rehearsal of the launch plumbing, no kernel ran)"
         print(json.dumps(res))
@@ -531,14 +554,14 @@ def main(argv=None):
     res["roofline"] = roofline
     res["encode_paths"] = encode_paths_ab(ctx, step, stream, max(5, min(20, args.steps)))
 
-    if not args.no_extras:
+    if not args.no_extras and world == 1:  # the single-GPU legs (store / retrieve / TTFT proxies, other geometries)
         extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, stream, sp, raw_bytes, blob_bytes,
                algo_bytes, gpu_ms_per_step)
     if offload_all is not None:
         res["offload_all_ranks"] = offload_all
     if exchange is not None:
         res["exchange"] = exchange
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line
         os.sched_setaffinity(0, cpus_before)  # the CPU baseline gets every host core, not only the GPU's NUMA node
         res["cpu_baseline"] = cpu_baseline(args.cpu_chunks or 128)
     print(json.dumps(res))
@@ -622,13 +645,22 @@ def exchange_leg(blobs, sizes, stride, nchunks, rank, world, dev, transports=("i
     peer = (rank + 1) % world
 
     def timed(fn):
+        """fn() between barriers; a rank whose fn raises still takes part in every collective, and all ranks learn
+        that the leg failed (so nobody waits in a barrier for a peer that has moved on)."""
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        r = fn()
-        torch.cuda.synchronize()
+        r, err = None, None
+        try:
+            r = fn()
+            torch.cuda.synchronize()
+        except Exception as e:
+            err = repr(e)
         dist.barrier()
-        return r, max_over_ranks(time.perf_counter() - t0, dev)
+        dt = max_over_ranks(time.perf_counter() - t0, dev)
+        if sum_over_ranks(1.0 if err else 0.0, dev) > 0:
+            raise RuntimeError(err or "a peer rank failed in this leg")
+        return r, dt
 
     def line(t_put, t_get, ok, note):
         return {"put_GBps_blob_all_ranks": round(tot / t_put / 1e9, 1), "get_GBps_blob_all_ranks": round(tot / t_get / 1e9, 1),
