@@ -9,7 +9,13 @@ followed by an `s_waitcnt lgkmcnt(0)` yet -- e.g. a register copy the allocator 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-strict-aliasing --cuda-device-only -S \
           -o /tmp/lmc.s lmcache_amd/csrc/lmc_api.hip
     python tools/check_pending_lds.py /tmp/lmc.s k_encode_fused k_cdf_encodeILb1ELb1
-Straight-line scan in layout order (branches are not followed: a conservative, order-of-text check).
+Straight-line scan in layout order (branches are not followed: an order-of-text check).
+
+KNOWN FLAW, and why the shipped coder no longer needs this script: a compiler-emitted `s_waitcnt lgkmcnt(0)` inside a
+branch that is normally SKIPPED (the ring flush) clears the pending set here although the hardware never executes it --
+which is how a `v_mov` of a still-pending ds_read_b64 half got past this check and corrupted streams at full size
+(round 3).  The coder now lets the compiler issue and track those loads and only pins their
+position; the script stays for whoever hides an LDS read in an asm block again.
 """
 import re
 import sys
