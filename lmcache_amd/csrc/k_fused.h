@@ -85,7 +85,7 @@ __device__ __forceinline__ u32 lookback_exclusive_epoch(unsigned long long* agg,
           if (lane == 0) atomicOr(status, LMC_ST_LOOKBACK_TIMEOUT);
           break;
         }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(10);  // ~0.3 us: a waiting wave should cost issue slots as rarely as possible
         continue;
       }
       excl += wave_sum_u32(lane <= first ? (u32)v : 0u);
