@@ -33,7 +33,7 @@ __global__ void fill(unsigned short* kv, long long n) {
 
 int main(int argc, char** argv) {
   const int L = 32, H = 8, D = 128, ctx_tok = 16384, chunk = 256, C = H * D, P = 2 * L, nchunks = ctx_tok / chunk;
-  const int ntrial = argc > 1 ? atoi(argv[1]) : 4, reps = 20;
+  const int ntrial = argc > 1 ? atoi(argv[1]) : 4, reps = argc > 2 ? atoi(argv[2]) : 20;
   const long long nelem = (long long)P * ctx_tok * C;
   std::vector<int32_t> bins(P);
   for (int p = 0; p < P; p++) { const int kv = p >= L, l = p - kv * L; bins[p] = !kv ? (l < 10 ? 32 : 16) : (l < 2 ? 32 : 16); }

@@ -1,8 +1,5 @@
-cd $GRAFT_REPO_ROOT; R=$PWD; mkdir -p gpurun_out/r3R
-AB="tools/probes/encode_ab 32 8 128 16384 256 0 20 0 2"
-for v in main head main head main head; do
-  if [ $v = main ]; then L=""; else L="$PWD/build_alt/$v"; fi
-  LD_LIBRARY_PATH=$L:$LD_LIBRARY_PATH timeout 120 $AB > gpurun_out/r3R_$v.log 2>&1; echo "$v: $(grep -E '^fused|^two' gpurun_out/r3R_$v.log | awk '{print $1, $2, $9, $10}' | tr '\n' ' ')"; done
-cd /tmp; export TMPDIR=/tmp
-timeout 100 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $R/gpurun_out/r3R/sq -o sq -- $R/tools/probes/encode_ab 32 8 128 16384 256 0 3 0 > $R/gpurun_out/r3R/sq.log 2>&1
-cd $R; python tools/rocpd_stats.py gpurun_out/r3R/sq/sq_results.db --min-grid 2000000 --per 16777216 | grep "k_encode_fused"
+cd $GRAFT_REPO_ROOT; R=$PWD; O=$R/gpurun_out/r3S; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+P="$R/tools/probes/encode_modes 3 2"
+timeout 80 rocprofv3 --kernel-trace --pmc TCC_HIT TCC_MISS TCC_EA0_RDREQ TCC_EA0_WRREQ TCC_EA0_WRREQ_STALL TCC_TAG_STALL -d $O/a -o a -- $P > $O/a.log 2>&1
+echo "rc $?"; grep -c fused $O/a.log
+cd $R; python tools/pmc_by_dispatch.py $O/a/a_results.db k_encode_fused > $O/a.md 2>&1; wc -l $O/a.md; grep "fused" $O/a.log | head -20
