@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r3T_pytest.log 2>&1; tail -3 gpurun_out/r3T_pytest.log
-timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+for i in 1 2 3 4 5 6 7 8 9 10 11 12; do timeout 120 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+import sys,json
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(d['ms_per_step'], d['encode_paths']['two_kernels_ms'], d['encode_paths']['fused_ms'])"; done
