@@ -118,11 +118,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
   const f32x2_t maxf2 = {maxf, maxf};
 #pragma unroll
   for (int hq = 0; hq < 2; hq++) {
-    u32 o[NITER][8];  // byte r = symbol of (token t_first + 4 hq + r, channel c0[it] + e)
-#pragma unroll
-    for (int it = 0; it < NITER; it++)
-#pragma unroll
-      for (int e = 0; e < 8; e++) o[it][e] = 0;
+    u32 o[NITER][8];  // byte r = symbol of (token t_first + 4 hq + r, channel c0[it] + e); row 0 of the quad defines it
 #pragma unroll
     for (int r0 = 0; r0 < 4; r0 += 2) {
       uint4 v[2][NITER];
@@ -162,18 +158,25 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
           if (tv[r]) scale_out[4 * hq + r0 + r] = (u16)mrow[r];
       }
       float factor[2];
-      bool special[2];
-      bool any_special = false;
-      // both row maxes are wave-uniform: one scalar branch picks the short division for the pair
+      bool special[2] = {false, false};
+      bool slow = false;
+      // both row maxes are wave-uniform: one scalar branch picks the short division for the pair -- and a max inside
+      // its range is finite, non-zero and has a finite factor, so such a pair cannot be special: no tests at all
       const bool short_div = LMC_SHORT_ROW_DIV && row_div_in_range(mrow[0], DT) && row_div_in_range(mrow[1], DT);
+      if (short_div) {
 #pragma unroll
-      for (int r = 0; r < 2; r++) {
-        const float sf = h2f_rt(mrow[r], DT);
-        factor[r] = short_div ? row_div_short(maxf, sf) : maxf / sf;  // IEEE fp32 division (lmc_device.h)
-        special[r] = !(__builtin_fabsf(factor[r]) < __builtin_inff()) || !(sf < __builtin_inff());
-        any_special |= special[r];
+        for (int r = 0; r < 2; r++) factor[r] = row_div_short(maxf, h2f_rt(mrow[r], DT));
+      } else {
+        bool any_special = false;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const float sf = h2f_rt(mrow[r], DT);
+          factor[r] = maxf / sf;  // IEEE fp32 division (lmc_device.h)
+          special[r] = !(__builtin_fabsf(factor[r]) < __builtin_inff()) || !(sf < __builtin_inff());
+          any_special |= special[r];
+        }
+        slow = __ballot(any_special) != 0;  // wave-uniform and rare
       }
-      const bool slow = __ballot(any_special) != 0;  // wave-uniform and rare
 #pragma unroll
       for (int it = 0; it < NITER; it++) {
         if (!cval[it]) continue;
@@ -185,8 +188,8 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
 #pragma unroll
             for (int k = 0; k < 4; k++) {
               const f32x2_t z = quant_z2(h_lo<DT>(w[k]), h_hi<DT>(w[k]), f2, maxf2);
-              o[it][2 * k] = __builtin_amdgcn_cvt_pk_u8_f32(z.x, r0 + r, o[it][2 * k]);
-              o[it][2 * k + 1] = __builtin_amdgcn_cvt_pk_u8_f32(z.y, r0 + r, o[it][2 * k + 1]);
+              o[it][2 * k] = __builtin_amdgcn_cvt_pk_u8_f32(z.x, r0 + r, r0 + r ? o[it][2 * k] : 0u);
+              o[it][2 * k + 1] = __builtin_amdgcn_cvt_pk_u8_f32(z.y, r0 + r, r0 + r ? o[it][2 * k + 1] : 0u);
             }
           } else {
 #pragma unroll
@@ -194,8 +197,8 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
               const float xl = h_lo<DT>(w[k]), xh = h_hi<DT>(w[k]);
               const u32 sl_ = (special[r] ? quant_special(xl, factor[r], maxf) : quant_fast(xl, factor[r], maxf)) & 0xffu;
               const u32 sh_ = (special[r] ? quant_special(xh, factor[r], maxf) : quant_fast(xh, factor[r], maxf)) & 0xffu;
-              o[it][2 * k] |= sl_ << (8 * (r0 + r));
-              o[it][2 * k + 1] |= sh_ << (8 * (r0 + r));
+              o[it][2 * k] = (r0 + r ? o[it][2 * k] : 0u) | sl_ << (8 * (r0 + r));
+              o[it][2 * k + 1] = (r0 + r ? o[it][2 * k + 1] : 0u) | sh_ << (8 * (r0 + r));
             }
           }
         }
