@@ -101,7 +101,9 @@ __device__ __forceinline__ u32 lookback_exclusive_epoch(unsigned long long* agg,
 // quant_special on zero / inf / NaN rows), two rows in flight, one row quad of accumulators at a time: a byte
 // plane stores each quad as soon as it is complete; a nibble plane parks the first quad's 8 * NITER dwords in
 // the wave's idle LDS slice and merges them with the second (byte k = token k | token 4 + k << 4).
-template <int NITER, int DT, bool NIB>
+// FULL: every lane of every iteration holds channels of the plane (C == NITER * 512: Llama / Mistral GQA shapes), so
+// no per-lane validity is tested and no register is zero-filled for absent channels.
+template <int NITER, int DT, bool NIB, bool FULL = false>
 __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16* pbase, int tok0, int Tc, int t_first,
                                                    bool q1valid, int C, float maxf, u32* sym_out, u16* scale_out,
                                                    uint4* park, int lane) {
@@ -111,7 +113,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
 #pragma unroll
   for (int it = 0; it < NITER; it++) {
     c0[it] = (it * 64 + lane) * 8;
-    cval[it] = c0[it] < C;
+    cval[it] = FULL || c0[it] < C;
     const int h = c0[it] / src.D, d = c0[it] - h * src.D;
     coff[it] = (long long)h * src.stride_head + d;
   }
@@ -134,7 +136,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
 #endif
 #pragma unroll
         for (int it = 0; it < NITER; it++) {
-          if (tv[r] && cval[it]) v[r][it] = ld_global_u4(rowp + coff[it]);
+          if (tv[r] && (FULL || cval[it])) v[r][it] = ld_global_u4(rowp + coff[it]);
           else v[r][it] = make_uint4(0, 0, 0, 0);
         }
       }
@@ -179,7 +181,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
       }
 #pragma unroll
       for (int it = 0; it < NITER; it++) {
-        if (!cval[it]) continue;
+        if (!FULL && !cval[it]) continue;
 #pragma unroll
         for (int r = 0; r < 2; r++) {
           const u32 w[4] = {v[r][it].x, v[r][it].y, v[r][it].z, v[r][it].w};
@@ -206,7 +208,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
     }
 #pragma unroll
     for (int it = 0; it < NITER; it++) {
-      if (!cval[it]) continue;
+      if (!FULL && !cval[it]) continue;
       if (NIB) {
         uint4* pk = park + (it * 2) * 64 + lane;
         if (hq == 0) {
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const int bins = (int)a.bins.b[p];
     const float maxf = (float)(bins / 2 - 1);
     const bool nib = lmc_sym_nibbles(bins);
+    const bool full = a.C == NITER * 512;  // no absent channels: the variant without per-lane validity
     u32* const sym_pc = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.sym_stride;
     u16* const scl = reinterpret_cast<u16*>(fa.scale_base + (long long)chunk * fa.scale_stride) + (long long)p * Tc;
     const int TO = (Tc + 7) >> 3;
@@ -282,7 +285,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll 1
     for (int oct = wave; oct < TO; oct += NW) {
       const bool q1valid = 2 * oct + 1 < a.TQ;
-      if (nib)
+      if (full) {  // wave-uniform
+        if (nib)
+          quantize_oct_fused<NITER, DT, true, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                    sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
+        else
+          quantize_oct_fused<NITER, DT, false, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                     sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
+      } else if (nib)
         quantize_oct_fused<NITER, DT, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
                                             sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
       else
