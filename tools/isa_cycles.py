@@ -6,7 +6,7 @@
     python tools/isa_cycles.py /tmp/lmc.s k_encode_fusedILi2ELi0 --between v_cmpx_ge_u32_sdwa --nth 45
 
 Round 2 learned the hard way that the NUMBER of VALU instructions per token does not predict the coders' time
-(33.5 -> 30.8 instructions per token step changed nothing, DESIGN.md section 6 "Round 2e"): what the SIMD spends is
+(33.5 -> 30.8 instructions per token step changed nothing, HISTORY.md "Round 2e"): what the SIMD spends is
 issue time, and that differs by class.  The costs below are the measured ones (tools/probes/valu_rates.py on
 MI355X, 8 waves per SIMD, ns per wave-instruction per SIMD; 1 cycle = 0.43 ns at the 2.3 GHz the encoder sustains):
 
