@@ -389,7 +389,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
                                     (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * P > 4ll * c->num_cus));
   // the chunks [c0, c0 + n) of the job with the two kernels: k_quantize, then k_cdf_encode (CDF or counts table +
-  // coder + in-kernel compaction of the streams into the blobs).  Measured alternatives that lost: DESIGN.md section 6.
+  // coder + in-kernel compaction of the streams into the blobs).  Measured alternatives that lost: HISTORY.md.
   auto two_kernels = [&](int c0, int n) -> int {
     EncodeArgs e2 = ea;
     e2.tok_begin = tok_begin + c0 * chunk_tokens; e2.nchunks = n;

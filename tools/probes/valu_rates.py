@@ -4,7 +4,7 @@ destination registers in rotation), times it with s_memtime at 1 and 4 waves per
 
     python tools/probes/valu_rates.py            # on the GPU box; prints a table, writes gpurun_out/valu_rates.txt
 
-Result on MI355X (ROCm 7.2) is recorded in DESIGN.md section 6.
+Result on MI355X (ROCm 7.2) is recorded in HISTORY.md ("What bounds what").
 """
 import os
 import subprocess
