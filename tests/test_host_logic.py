@@ -346,3 +346,26 @@ def test_pack_info_and_extract_on_the_host():
             native.pack_info(ctypes.addressof(bb), len(bad))
     with pytest.raises(native.NativeError):
         native.pack_info(ptr, len(pack) - 16)
+
+
+def test_pack_cap_covers_the_least_compressible_input():
+    """serde/cachegen_device.pack_cap sizes the region a pack is written to from the coder's bound (T * log2(symbols)
+    + 48 bits per lane).  Uniform noise over a wide range is the least compressible input the quantiser can see
+    (every symbol about equally likely); packs of it, and of a ragged job, must fit."""
+    import numpy as np
+    from lmcache_amd.storage_backend.serde.cachegen_device import pack_cap
+    from oracle import lmc_oracle as oracle
+    oracle.build()
+    L, H, D, cs = 2, 3, 128, 256
+    bins = [32, 17, 16, 32]
+    rng = np.random.default_rng(3)
+    for T in (512, 300):
+        x = rng.uniform(-1.0, 1.0, (L, 2, T, H * D)).astype(np.float32)
+        bits = np.ascontiguousarray((x.view(np.uint32) >> 16).astype(np.uint16))  # bf16 bits (truncated): uniform symbols
+        blobs = [oracle.encode_blob(np.ascontiguousarray(bits[:, :, t0:t0 + cs]), oracle.BF16, H, D, np.array(bins, np.int32))
+                 for t0 in range(0, T, cs)]
+        pack = oracle.pack_from_blobs(blobs, cs)
+        cap = pack_cap(len(blobs), L, cs, H, D, bins)
+        assert len(pack) <= cap, (T, len(pack), cap)
+        if T % cs == 0:  # (a ragged last chunk is sized like a full one)
+            assert cap < 1.35 * len(pack), "the bound should stay close to the least compressible case"
