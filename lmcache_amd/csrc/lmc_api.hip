@@ -39,6 +39,17 @@ struct lmc_ctx {
   unsigned long long* agg = nullptr; size_t agg_bytes = 0;  // look-back granules of the in-kernel compaction
   hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
   bool ws_used = false;
+  // Workspace placement search.  The fused encode takes 1.03 or 1.13 ms for the same job depending on where hipMalloc
+  // put the workspace (tools/probes/encode_modes: deterministic per allocation, cause unknown -- DESIGN.md section 6).
+  // So a workspace for a large job is allocated ws_cands times, the first fused jobs run on each candidate in turn
+  // (4 jobs each, the last two timed with events on the caller's stream -- no host wait), and once the timings are in
+  // the fastest stays and the others are freed.  LMC_WS_CANDIDATES=1 turns it off.
+  struct WsCand { u32* sym4; u8* scratch; unsigned long long* agg; hipEvent_t t0, t1; };
+  WsCand wsc[4] = {};
+  int ws_cands = 3, ws_n = 0;   // candidates wanted / alive (wsc[0 .. ws_n))
+  int ws_jobs = 0;              // fused jobs measured so far
+  int ws_cur = 0;               // the candidate sym4 / scratch / agg point to
+  bool ws_search = false;
   int num_cus = 256;
   int enc_path = LMC_ENCODE_PATH_AUTO;  // lmc_ctx_set_encode_path
   bool pre_all = false;
@@ -98,6 +109,24 @@ const char* lmc_strerror(int code) {
 int lmc_last_hip_error(void) { return g_last_hip; }
 int lmc_abi_version(void) { return LMC_ABI_VERSION; }
 
+// The workspace candidates other than the current one go (the caller made sure nothing queued uses them), and the
+// search state with them.
+static void ws_drop_candidates(lmc_ctx* c) {
+  const int cur = c->ws_cur;
+  for (int k = 0; k < c->ws_n; k++) {
+    lmc_ctx::WsCand& w = c->wsc[k];
+    if (k != cur) {
+      if (w.sym4) (void)hipFree(w.sym4);
+      if (w.scratch) (void)hipFree(w.scratch);
+      if (w.agg) (void)hipFree(w.agg);
+    }
+    if (w.t0) (void)hipEventDestroy(w.t0);
+    if (w.t1) (void)hipEventDestroy(w.t1);
+    w = lmc_ctx::WsCand{};
+  }
+  c->ws_n = 0; c->ws_jobs = 0; c->ws_cur = 0; c->ws_search = false;
+}
+
 int lmc_ctx_create(int device, lmc_ctx** out) {
   if (!out) return LMC_ERR_INVALID;
   HIP_TRY(hipSetDevice(device));
@@ -114,6 +143,7 @@ int lmc_ctx_create(int device, lmc_ctx** out) {
   e = hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming);
   if (e != hipSuccess) { g_last_hip = (int)e; (void)hipHostFree(c->status_h); delete c; return LMC_ERR_HIP; }
   if (const char* e = getenv("LMC_FUSED_STAGGER_US")) c->stagger_us = atoi(e);
+  if (const char* e = getenv("LMC_WS_CANDIDATES")) c->ws_cands = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
   if (const char* e = getenv("LMC_SYM_PAD")) c->sym_pad = (size_t)atoll(e) & ~(size_t)15;
   if (const char* e = getenv("LMC_SCRATCH_PAD")) c->scr_pad = (size_t)atoll(e) & ~(size_t)15;
   if (const char* e = getenv("LMC_FUSED_PRE_STEP")) c->pre_step = atoi(e);  // A/B switch of the head start (tools/probes)
@@ -126,6 +156,7 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   if (!c) return LMC_OK;
   (void)hipSetDevice(c->device);
   if (c->ws_used) (void)hipEventSynchronize(c->ws_free);
+  ws_drop_candidates(c);
   if (c->sym4) (void)hipFree(c->sym4);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->agg) (void)hipFree(c->agg);
@@ -283,7 +314,66 @@ static int reserve_locked(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int
   if ((rc = ws_grow((void**)&c->agg, &c->agg_bytes, 2 * need_len))) return rc;
   // fresh granules must not look like a published value of some epoch (k_fused.h)
   if (c->agg_bytes != agg_before) HIP_TRY(hipMemset(c->agg, 0, c->agg_bytes));
+  // a new workspace: the old candidates go, and a large one gets rivals (see lmc_ctx::WsCand)
+  ws_drop_candidates(c);
+  if (c->ws_cands > 1 && c->sym4_bytes + c->scratch_bytes >= ((size_t)256 << 20)) {
+    c->wsc[0].sym4 = c->sym4; c->wsc[0].scratch = c->scratch; c->wsc[0].agg = c->agg;
+    c->ws_n = 1;
+    for (int k = 1; k < c->ws_cands; k++) {
+      lmc_ctx::WsCand w{};
+      if (hipMalloc((void**)&w.sym4, c->sym4_bytes) != hipSuccess || hipMalloc((void**)&w.scratch, c->scratch_bytes) != hipSuccess ||
+          hipMalloc((void**)&w.agg, c->agg_bytes) != hipSuccess || hipMemset(w.agg, 0, c->agg_bytes) != hipSuccess) {
+        if (w.sym4) (void)hipFree(w.sym4);   // no room for a rival: the search runs over what there is
+        if (w.scratch) (void)hipFree(w.scratch);
+        if (w.agg) (void)hipFree(w.agg);
+        (void)hipGetLastError();
+        break;
+      }
+      c->wsc[c->ws_n++] = w;
+    }
+    for (int k = 0; k < c->ws_n; k++) {
+      if (hipEventCreate(&c->wsc[k].t0) != hipSuccess || hipEventCreate(&c->wsc[k].t1) != hipSuccess) { ws_drop_candidates(c); return LMC_OK; }
+    }
+    c->ws_search = c->ws_n > 1;
+    if (!c->ws_search) ws_drop_candidates(c);
+  }
   return LMC_OK;
+}
+
+// One step of the workspace placement search, for a job that takes the fused kernel.  Returns the candidate whose
+// events bracket this job (-1: none) and which of them to record: bit 0 = t0 before the launch, bit 1 = t1 after it.
+#define LMC_WS_REPS 4
+static int ws_search_step(lmc_ctx* c, int* record) {
+  *record = 0;
+  if (!c->ws_search) return -1;
+  const int k = c->ws_jobs / LMC_WS_REPS, r = c->ws_jobs % LMC_WS_REPS;
+  if (k < c->ws_n) {  // measuring: this job runs on candidate k
+    c->ws_cur = k;
+    c->sym4 = c->wsc[k].sym4; c->scratch = c->wsc[k].scratch; c->agg = c->wsc[k].agg;
+    c->ws_jobs++;
+    if (r == LMC_WS_REPS - 2) *record = 1;
+    if (r == LMC_WS_REPS - 1) *record = 2;
+    return k;
+  }
+  // every candidate has been timed: are the timings in?  (never wait for them: the job runs on the last candidate
+  // until they are)
+  int best = -1;
+  float best_ms = 0.f;
+  for (int j = 0; j < c->ws_n; j++) {
+    if (hipEventQuery(c->wsc[j].t1) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->wsc[j].t0, c->wsc[j].t1) != hipSuccess) { (void)hipGetLastError(); ms = 1e30f; }
+    if (best < 0 || ms < best_ms) { best = j; best_ms = ms; }
+  }
+  // t1 of the last candidate has fired, so no queued kernel uses any candidate but the current one (every job waits
+  // for its predecessor's ws_free): the losers can go now, unless the current one loses -- then wait until it is idle
+  if (best != c->ws_cur) {
+    if (hipEventQuery(c->ws_free) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    c->ws_cur = best;
+    c->sym4 = c->wsc[best].sym4; c->scratch = c->wsc[best].scratch; c->agg = c->wsc[best].agg;
+  }
+  ws_drop_candidates(c);
+  return -1;
 }
 
 extern "C" {
@@ -423,6 +513,10 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     HIP_TRY(hipGetLastError());
     return prof_mark(c, s);
   };
+  int ws_rec = 0;
+  const int ws_k = fused ? ws_search_step(c, &ws_rec) : -1;  // may move sym4 / scratch / agg to another candidate
+  ea.sym4 = c->sym4; ea.scratch = c->scratch; ea.agg = c->agg;
+  if (ws_rec & 1) HIP_TRY(hipEventRecord(c->wsc[ws_k].t0, s));
   if (fused) {
     // One launch for the full chunks: a workgroup per (chunk, plane) quantises, then codes and places its streams.
     FusedArgs fa;
@@ -488,6 +582,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     if ((rc = two_kernels(0, nchunks))) return rc;
   }
 
+  if (ws_rec & 2) HIP_TRY(hipEventRecord(c->wsc[ws_k].t1, s));
   HIP_TRY(hipEventRecord(c->ws_free, s));
   c->ws_used = true;
   return LMC_OK;
