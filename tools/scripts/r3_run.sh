@@ -1,4 +1,18 @@
+# Round validation on the GPU box (through gpurun):  bash tools/scripts/r3_run.sh
+# full GPU suite, smoke, the driver-style bench, then the profile passes behind profiles/ (render with
+# tools/scripts/render_profiles.sh r3prof r03_a afterwards)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-AB="tools/probes/encode_ab 32 8 128 16384 256 0 20 0 3"
-for c in 3 1 3 1 3 1 3 1; do LMC_WS_CANDIDATES=$c timeout 120 $AB > gpurun_out/r3Z_c$c.log 2>&1; echo "cands $c: $(grep -E '^fused|PARITY' gpurun_out/r3Z_c$c.log | awk '{print $1, $2}' | tr '\n' ' ')"; done
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_c_abi_store_load.py tests/test_gpu_engine.py -m gpu -x -q > gpurun_out/r3Z_pytest.log 2>&1; tail -3 gpurun_out/r3Z_pytest.log
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r3_pytest.log 2>&1; tail -2 gpurun_out/r3_pytest.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+for i in 1 2 3 4 5; do timeout 120 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+import sys,json
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(d['ms_per_step'], d['encode_paths']['two_kernels_ms'], d['encode_paths']['fused_ms'])"; done
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r3_bench.json 2> gpurun_out/r3_bench.err
+bash tools/scripts/profile_round.sh r3prof > gpurun_out/r3_prof.log 2>&1
+python - <<'PY'
+import json
+for f in ("gpurun_out/r3_bench.json", "gpurun_out/r3prof/stats.log"):
+    txt = open(f).read()
+    d = json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
+    print(f, d["ms_per_step"], d["value"], d["roofline"]["frac"], d.get("encode_paths", {}).get("two_kernels_ms"), d.get("seeds", {}).get("median"))
+PY
