@@ -178,6 +178,12 @@ __device__ __forceinline__ u32 lookback_exclusive(unsigned long long* agg, int i
 #ifndef LMC_PLACE_BATCH
 #define LMC_PLACE_BATCH 4  // KiB of LDS = loads in flight
 #endif
+#ifndef LMC_PLACE_NT_IN
+#define LMC_PLACE_NT_IN 0  // experiment: the scratch slot is read for the last time: non-temporal (aux = 2)
+#endif
+#ifndef LMC_PLACE_NT_OUT
+#define LMC_PLACE_NT_OUT 1  // the placed streams are not read again by this kernel: non-temporal stores (k_fused.h)
+#endif
 #ifndef LMC_PLACE_SERIAL
 #define LMC_PLACE_SERIAL 0
 #endif
@@ -195,14 +201,18 @@ __device__ __forceinline__ void copy_stream16(uint4* dst, const uint4* src, u32 
 #pragma unroll
     for (int k = 0; k < LMC_PLACE_BATCH; k++) {
       const u32 i = base + 64u * k + lane;
-      __builtin_amdgcn_global_load_lds((gptr)(src + (i < n16 ? i : n16 - 1u)), (lptr)(lds4k + 256 * k), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(src + (i < n16 ? i : n16 - 1u)), (lptr)(lds4k + 256 * k), 16, 0, LMC_PLACE_NT_IN ? 2 : 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int k = 0; k < LMC_PLACE_BATCH; k++) {
       const u32 i = base + 64u * k + lane;
       const uint4 v = *reinterpret_cast<const uint4*>(lds4k + 256 * k + 4 * lane);
+#if LMC_PLACE_NT_OUT
+      if (i < n16) __builtin_nontemporal_store(*reinterpret_cast<const u32x4_t*>(&v), reinterpret_cast<LMC_GLOBAL u32x4_t*>((LMC_GLOBAL uint4*)(dst + i)));
+#else
       if (i < n16) dst[i] = v;
+#endif
       asm volatile("" ::: "memory");  // one piece in registers at a time
     }
   }

@@ -56,6 +56,15 @@ __device__ __forceinline__ void rtab_to_lds(u32* rtab_lds) {
 // coding pass twice (all three leave the blobs unchanged), bit 3 no placement copy (blobs incomplete); bits 4-6 put
 // the raw rows / the symbol workspace / the stream scratch of the fused kernel on a few aliased regions that stay
 // in L2 (what the kernel costs without that HBM traffic; blobs are garbage)
+// the coding pass reads a symbol dword for the last time: with LMC_SYM_NT the load says so (non-temporal)
+#ifndef LMC_SYM_NT
+#define LMC_SYM_NT 1
+#endif
+#if LMC_SYM_NT
+#define LMC_SYM_LAST_LOAD(p) __builtin_nontemporal_load((const LMC_GLOBAL u32*)(p))
+#else
+#define LMC_SYM_LAST_LOAD(p) (*(p))
+#endif
 #ifndef LMC_EXP_TWICE
 #define LMC_EXP_TWICE 0
 #endif
@@ -281,14 +290,14 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
     };
     u32 w[DPB], wn[DPB];
 #pragma unroll
-    for (int j = 0; j < DPB; j++) w[j] = active ? symq[(long long)((NB - 1) * DPB + j) * a.C] : 0u;
+    for (int j = 0; j < DPB; j++) w[j] = active ? LMC_SYM_LAST_LOAD(symq + (long long)((NB - 1) * DPB + j) * a.C) : 0u;
     if constexpr (LDSASM == 0) {
       // plain form: loads and waits left to the compiler, the entry and its reciprocal fetched a token ahead
       u32 e_n = entry_at(row_addr_cnt<NIB, 31>(w, col));
       u32x2_t r_n = rtab_of(e_n);
       for (int b = NB - 1; b >= 0; b--) {
 #pragma unroll
-        for (int j = 0; j < DPB; j++) wn[j] = (b > 0 && active) ? symq[(long long)((b - 1) * DPB + j) * a.C] : 0u;
+        for (int j = 0; j < DPB; j++) wn[j] = (b > 0 && active) ? LMC_SYM_LAST_LOAD(symq + (long long)((b - 1) * DPB + j) * a.C) : 0u;
         static_for<32>([&](auto itag) {
           constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
           const u32 e = e_n;
@@ -349,7 +358,7 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
       u32x2_t R1 = rtab_of(E1);
       for (int b = NB - 1; b >= 0; b--) {
 #pragma unroll
-        for (int j = 0; j < DPB; j++) wn[j] = (b > 0 && active) ? symq[(long long)((b - 1) * DPB + j) * a.C] : 0u;
+        for (int j = 0; j < DPB; j++) wn[j] = (b > 0 && active) ? LMC_SYM_LAST_LOAD(symq + (long long)((b - 1) * DPB + j) * a.C) : 0u;
         static_for<32>([&](auto itag) {
           constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
           u32 ad4;  // row address of the token four further on (past the last block: row 0, read and never used)
@@ -412,7 +421,7 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
       u32x2_t R0 = rtab_of(E0);
       for (int b = NB - 1; b >= 0; b--) {
 #pragma unroll
-        for (int j = 0; j < DPB; j++) wn[j] = (b > 0 && active) ? symq[(long long)((b - 1) * DPB + j) * a.C] : 0u;
+        for (int j = 0; j < DPB; j++) wn[j] = (b > 0 && active) ? LMC_SYM_LAST_LOAD(symq + (long long)((b - 1) * DPB + j) * a.C) : 0u;
         static_for<32>([&](auto itag) {
           constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
           u32 ad2;  // row address of the token after next (past the last block: row 0, read and never used)

@@ -28,6 +28,15 @@
 #ifndef FUSED_WAVES
 #define FUSED_WAVES 8  // waves per workgroup: 4 workgroups per CU
 #endif
+// Cache policy of the fused encode's streams.  The symbol workspace and the stream scratch are written and read back
+// within a workgroup's life, and 1024 workgroups' worth of them (~300 MB) is about what L2 + Infinity Cache hold --
+// so everything that is touched ONCE says so: the raw KV is loaded non-temporal (LMC_FUSED_NT_IN), the placed streams
+// are stored non-temporal (LMC_PLACE_NT_OUT, k_encode.h), the coding pass reads its symbols for the last time
+// non-temporal (LMC_SYM_NT, k_encode_counts.h).  Same box, alternating processes: 1.017-1.027 ms without, 0.982-0.988
+// with the first, 0.968-0.975 with all three; a non-temporal re-read of the scratch slot on top changes nothing.
+#ifndef LMC_FUSED_NT_IN
+#define LMC_FUSED_NT_IN 1
+#endif
 #ifndef LMC_FUSED_PRIO_A
 #define LMC_FUSED_PRIO_A 3  // wave priority while a wave fetches / quantises (phase A) ...
 #endif
@@ -136,7 +145,11 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
 #endif
 #pragma unroll
         for (int it = 0; it < NITER; it++) {
+#if LMC_FUSED_NT_IN
+          if (tv[r] && (FULL || cval[it])) v[r][it] = ld_global_u4_nt(rowp + coff[it]);
+#else
           if (tv[r] && (FULL || cval[it])) v[r][it] = ld_global_u4(rowp + coff[it]);
+#endif
           else v[r][it] = make_uint4(0, 0, 0, 0);
         }
       }

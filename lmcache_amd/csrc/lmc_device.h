@@ -93,6 +93,11 @@ __device__ __forceinline__ uint4 ld_global_u4(const u16* p) {
   const u32x4_t v = *reinterpret_cast<const LMC_GLOBAL u32x4_t*>((const LMC_GLOBAL u16*)p);
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+// the same load with the non-temporal hint: streamed-once data (the raw KV) should not push the workspace out of the caches
+__device__ __forceinline__ uint4 ld_global_u4_nt(const u16* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const LMC_GLOBAL u32x4_t*>((const LMC_GLOBAL u16*)p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void st_global_u4(u16* p, uint4 v) {
   u32x4_t t;
   t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
