@@ -49,6 +49,9 @@ struct DecodeArgs {
 // LDS of a workgroup: the four waves' dequantisation LUTs (32 x f32 = 128 B each) FIRST -- their byte addresses stay
 // below 2^10 and fit into the packed table entries of the counts model -- then per wave: cdfT [33][64] u16 (4224) |
 // word ring: 256 x u16 + 64-word mirror (640)
+#ifndef LMC_DEC_NT_IN
+#define LMC_DEC_NT_IN 1  // the stream words are read once: non-temporal loads (decode 0.963 -> 0.950 ms, same box)
+#endif
 #define DEC_CDF_BYTES 4224
 #define DEC_RING_WORDS 256
 #define DEC_RING_BYTES (2 * (DEC_RING_WORDS + 64))
@@ -247,7 +250,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   const LMC_GLOBAL u32* const words32 = (const LMC_GLOBAL u32*)words;  // streams start 16-byte aligned
   auto block_load = [&](int b) -> u32 {
     const int d = 64 * b + lane;  // dword = words 2d, 2d + 1; the 128 state words that follow belong to the stream too
+#if LMC_DEC_NT_IN
+    return (b >= 0 && (u32)(2 * d + 1) < nwords + 128u) ? __builtin_nontemporal_load(words32 + d) : 0u;
+#else
     return (b >= 0 && (u32)(2 * d + 1) < nwords + 128u) ? words32[d] : 0u;
+#endif
   };
   auto block_commit = [&](int b, u32 v) {
     ring32[((b & 1) << 6) + lane] = v;

@@ -119,7 +119,7 @@ __device__ __forceinline__ void quantize_task(const KvAddr& src, int p, int tok0
       const u16* rowp = pbase + (tv[r] ? lmc_tok_off(src, tok0 + t) : 0);
 #pragma unroll
       for (int it = 0; it < NITER; it++) {
-        if (tv[r] && cval[it]) v[r][it] = ld_global_u4(rowp + coff[it]);
+        if (tv[r] && cval[it]) v[r][it] = ld_global_u4(rowp + coff[it]);  // (non-temporal here: two-kernel path +0.5 %)
         else v[r][it] = make_uint4(0, 0, 0, 0);
       }
     }
