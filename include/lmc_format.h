@@ -19,7 +19,6 @@
  *
  *   header   128 B          struct lmc_blob_header
  *   bins     u8  [P]        quantisation bins of each plane (32 or 16 ...)
- *   rowpre   u16 [P+1]      rowpre[p] = sum over planes before p of R, R = bins - 1
  *   scales   u16 [P][T]     per-(plane,token) absmax, raw bits of the KV dtype
  *                           (= max_tensors_key ++ max_tensors_value)
  *   scsum    u32 [P]        checksum of each plane's scales (v4): sum over t of (t + 1) * (bits_t + 1)
@@ -27,40 +26,53 @@
  *                           counts and the streams by itself (the final rANS states must come out at
  *                           their start value); the scales are the one section it cannot see, and a
  *                           flipped scale would silently rescale a whole token row.
- *   cdf      the per-channel symbol statistics the 16-bit CDF is a function of.  Per plane p:
- *                           [R_p][C] counts of the symbols 0 .. R_p - 1 (symbol-major since v5: a
- *                           coder lane owns a channel and reads / writes its counts with one
- *                           coalesced access per symbol), R_p = bins - 1 being the number of
- *                           symbols the quantiser can emit (plane p starts C * rowpre[p] entries in).  header.count_bytes = 1 when T <= 256:
- *                           one byte per count, a count of 256 stored as 255 (the counts of
- *                           a channel sum to T, so a reader adds T - sum to the entry that
- *                           reads 255); otherwise 2 (u16).  The CDF of a channel is
- *                             cdf[i] = RNE(N_i * 65504 / T) + i  (mod 2^16),
- *                             N_i = number of its symbols < i,  i = 0 .. 32
- *                           -- exactly the values of the reference's `cdf` tensor
- *                           [2L, C, 33] (cachegen_encoder.py:95-126, 175-222; entries above
- *                           R_p come out as 65504 + i because N_i = T there).  Counts
- *                           instead of the 33 (v1) or bins - 2 (v2) u16 entries take a
- *                           Llama-3-8B chunk blob from 11.1 MB (v1) over 9.0 MB to 7.9 MB.
- *   gend     u32 [P][G]     EXACT end offset (bytes, relative to the streams
- *                           section) of group stream (p,g); G = ceil(C/64).
- *                           Stream (p,g) starts at roundup16(gend[prev]) (0 for
- *                           the first) -- so every stream starts 16-B aligned.
- *   streams  bytes          group streams in (p,g) order, each padded with
- *                           zero bytes to a multiple of 16.
+ *   gdir     u32 [P][G][2]  stream directory (v6): {beg, end} of group stream (p,g), byte offsets
+ *                           relative to the streams section; G = ceil(C/64).  beg is a multiple
+ *                           of 16, end is EXACT.
+ *   streams  bytes          group streams in (p,g) order.  Every stream owns an ALLOCATION
+ *                           alloc(p,g), a multiple of 16, and begins at the sum of the allocations
+ *                           of the streams before it; the bytes between its end and the end of
+ *                           its allocation are zero.
+ *                             LMC_MODEL_COUNTS  alloc = lmc_counts_alloc_bytes(head, words): an UPPER
+ *                                               BOUND of the stream's length that follows from the
+ *                                               channels' symbol counts alone (lmc_counts_bits);
+ *                             LMC_MODEL_CDF16   alloc = r16(its exact length).
+ *                           Why a bound: with the allocation known BEFORE the coder runs, the
+ *                           encoder's single-pass prefix over the chunk's streams runs in front of
+ *                           the coding pass and every 256-byte piece of a stream goes straight to
+ *                           its final place -- no padded scratch, no second pass that moves the
+ *                           streams (v5 wrote every stream twice and read it once in between).  The
+ *                           price is the slack of the bound: < 1 % of the blob.
  *
- * Group stream = interleaved rANS over 64 adjacent channels ("lanes"),
- * 32-bit state words, 16-bit renormalisation words:
+ * Group stream (p,g) = the symbol statistics of its 64 channels ("lanes"), then their symbols as
+ * one interleaved rANS stream:
  *
- *   [ u16 words, in the order the ENCODER emitted them ][ u32 state[64] ]
+ *   [ head: widths u8[R8] | planes u64[W] | zeros to 16 B ][ u16 words ][ u32 state[64] ]
  *
- * The encoder walks tokens T-1 .. 0; at each token the lanes that must
+ * head (v6; v1-v5 kept a [P][R][C] counts / CDF section of its own: 15 % of a blob, and every byte of it had
+ * to be there before the first stream could be decoded).  R = bins - 1 symbols the plane's quantiser can
+ * emit, R8 = R rounded up to 8.  The STORED count of (symbol i, lane) is the number of the channel's
+ * tokens with that symbol -- for T <= 256 a count of 256 is stored as 255 (the counts of a channel sum
+ * to T: a reader adds T - sum to the entry that reads 255); lanes whose channel is >= C store 0.
+ * widths[i] = number of significant bits of the largest stored count of symbol i over the 64 lanes
+ * (0: the symbol does not occur in the group; <= 16), widths[R .. R8) = 0.  The counts are stored
+ * bit-sliced: W = sum of the widths planes of 8 bytes, symbol 0's first, a symbol's most
+ * significant bit first; bit l of a plane = that bit of lane l's stored count.  (A wave writes a
+ * plane with one ballot and reads its lane's bit with one add-with-carry; a symbol that occurs
+ * 40 times at most costs 6 bits per channel instead of 8, one that does not occur costs nothing:
+ * the counts of a Llama-3-8B chunk take 0.44 MB instead of 1.18.)  The CDF of a channel is
+ *   cdf[i] = RNE(N_i * 65504 / T) + i  (mod 2^16),  N_i = number of its symbols < i,  i = 0 .. 32
+ * -- exactly the values of the reference's `cdf` tensor [2L, C, 33] (cachegen_encoder.py:95-126,
+ * 175-222; entries above R come out as 65504 + i because N_i = T there).
+ *
+ * words / states: interleaved rANS over the 64 lanes, 32-bit states, 16-bit renormalisation words in
+ * the order the ENCODER emitted them.  The encoder walks tokens T-1 .. 0; at each token the lanes that must
  * renormalise append their low 16 state bits in ascending lane order.  The
  * decoder starts from the tail (states), walks tokens 0 .. T-1 and pops words
  * from the end, again in ascending lane order inside one token step.
  *
  * header.model says which probabilities the coder runs on (v5); both are
- * functions of the counts section alone:
+ * functions of the counts in the stream's head alone:
  *
  *   LMC_MODEL_CDF16 (0)  any T.  The reference's 16-bit CDF itself:
  *       start = cdf[s], freq = cdf[s+1] - cdf[s], total 2^16, state in
@@ -89,7 +101,7 @@ extern "C" {
 #endif
 
 #define LMC_BLOB_MAGIC 0x31434D4Cu /* "LMC1" */
-#define LMC_BLOB_VERSION 5u
+#define LMC_BLOB_VERSION 6u
 #define LMC_HEADER_BYTES 128u
 
 #define LMC_DTYPE_BF16 0
@@ -123,14 +135,12 @@ typedef struct lmc_blob_header {
   uint32_t lp;          /* LMC_LP */
   uint32_t off_bins;
   uint32_t off_scales;
-  uint32_t off_cdf;
-  uint32_t off_gend;
+  uint32_t zero13;       /* (v1-v5: off_cdf, the counts / CDF section; v6 keeps the counts in the streams' heads) */
+  uint32_t off_gdir;     /* stream directory {beg, end} */
   uint32_t off_streams;
-  uint32_t stream_bytes; /* padded size of the streams section */
+  uint32_t stream_bytes; /* size of the streams section = sum of the streams' allocations */
   uint32_t total_bytes;  /* off_streams + stream_bytes */
-  uint32_t off_rowpre;
-  uint32_t cdf_rows;     /* rowpre[P] = sum of R over all planes */
-  uint32_t count_bytes;  /* bytes per stored count: 1 (T <= 256) or 2 */
+  uint32_t zero18[3];    /* (v2-v5: off_rowpre, cdf_rows, count_bytes) */
   uint32_t off_scsum;    /* per-plane scale checksums */
   uint32_t model;        /* LMC_MODEL_*: = lmc_model_for(ntokens) */
   uint32_t reserved[9];
@@ -141,10 +151,18 @@ static inline uint32_t lmc_r16(uint32_t x) { return (x + 15u) & ~15u; }
 /* One term of a plane's scale checksum: token t (0-based) whose scale has the raw bits `bits`. */
 static inline uint32_t lmc_scale_checksum_term(uint32_t t, uint32_t bits) { return (t + 1u) * (bits + 1u); }
 
-/* Counts stored per channel of a plane quantised with `bins` bins: one per symbol 0 .. bins-2. */
+/* Symbols the quantiser of a plane with `bins` bins can emit: 0 .. bins - 2. */
 static inline uint32_t lmc_cdf_row(uint32_t bins) { return bins - 1u; }
-/* Bytes per stored count for a chunk of T tokens. */
-static inline uint32_t lmc_count_bytes(uint32_t T) { return T <= 256u ? 1u : 2u; }
+
+/* ---- stream head (the symbol counts of a group's 64 channels, bit-sliced) ------------------------------------- */
+/* A count as it is stored in a chunk of T tokens. */
+static inline uint32_t lmc_stored_count(uint32_t count, uint32_t T) { return (T <= 256u && count > 255u) ? 255u : count; }
+/* Significant bits of v (0 for 0). */
+static inline uint32_t lmc_bit_width(uint32_t v) { uint32_t w = 0; while (v) { w++; v >>= 1; } return w; }
+/* Bytes of the head of a stream of a plane with R symbols whose widths sum to W. */
+static inline uint32_t lmc_head_bytes(uint32_t R, uint32_t W) { return lmc_r16(((R + 7u) & ~7u) + 8u * W); }
+/* ... and its largest possible value in a chunk of T tokens (31 symbols, every width at its maximum). */
+static inline uint32_t lmc_head_cap_bytes(uint32_t T) { return lmc_head_bytes(31u, 31u * lmc_bit_width(lmc_stored_count(T, T))); }
 
 /* The coder model of a chunk of T tokens. */
 static inline uint32_t lmc_model_for(uint32_t T) { return T == LMC_COUNTS_T ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16; }
@@ -171,40 +189,71 @@ static inline void lmc_rans_magic(uint32_t count, uint32_t* magic, uint32_t* shi
   *shift = l - 1u;
 }
 
-/* Section offsets for a chunk geometry.  cdf_rows = sum over planes of lmc_cdf_row(bins[p]);
- * pass 31 * P (all planes at 32 bins) for an upper bound. */
-static inline void lmc_blob_layout(uint32_t L, uint32_t T, uint32_t H, uint32_t D, uint32_t cdf_rows,
-                                   lmc_blob_header* h) {
+/* ---- LMC_MODEL_COUNTS: how long can a stream get?  (v6: streams are placed BEFORE they are coded) ----------------
+ * A lane starts at x = 2^15 and ends at x >= 2^15; a renormalisation takes 16 bits out, and coding a symbol of model
+ * count c (frequency f = 2 c of 2^9) takes the state from x_r to x' < 2^9 (x_r / f + 1) = (2^9 / f) x_r (1 + f / x_r):
+ *   16 * words <= sum over tokens of [ log2(256 / c) + log2(1 + f / x_r) ].
+ * x_r >= 2^15 on a step without renormalisation, x_r >= f * 2^6 on a step with one (the emit test is x >= f << 22), so
+ *   words <= floor( ( sum_s c_s (log2(256 / c_s) + log2(1 + 2 c_s / 2^15)) + words * log2(1 + 2^-6) ) / 16 ).
+ * lmc_counts_bits[c] = the first bracket for a symbol that occurs c times, in units of 2^-8 bit, rounded up (+1);
+ * log2(1 + 2^-6) < 6 * 2^-8.  The table is a constant of the FORMAT (written out so that every implementation
+ * uses the same integers; tests/test_oracle_golden.py recomputes it and attacks the bound with adversarial
+ * channels).  Index 0 and 256 are never used by a model (lmc_counts_model). */
+#define LMC_COUNTS_BITS_LIST \
+  0, 2050, 3586, 4928, 6146, 7270, 8320, 9308, 10243, 11132, 11980, 12790, 13568, 14314, 15032, 15724, 16391, \
+  17035, 17658, 18260, 18842, 19406, 19953, 20483, 20996, 21495, 21979, 22448, 22904, 23347, 23777, 24195, 24601, \
+  24995, 25378, 25751, 26113, 26464, 26806, 27138, 27461, 27774, 28079, 28375, 28662, 28941, 29212, 29474, 29729, \
+  29977, 30216, 30449, 30674, 30892, 31104, 31308, 31506, 31697, 31882, 32060, 32233, 32399, 32559, 32713, 32862, \
+  33004, 33141, 33273, 33399, 33520, 33635, 33745, 33850, 33950, 34045, 34135, 34220, 34300, 34375, 34446, 34512, \
+  34574, 34631, 34684, 34732, 34776, 34815, 34850, 34882, 34908, 34931, 34950, 34965, 34976, 34982, 34985, 34985, \
+  34980, 34972, 34959, 34944, 34924, 34901, 34874, 34844, 34810, 34773, 34732, 34688, 34641, 34590, 34536, 34479, \
+  34418, 34354, 34287, 34217, 34144, 34067, 33988, 33905, 33820, 33731, 33639, 33545, 33447, 33347, 33244, 33137, \
+  33028, 32917, 32802, 32685, 32564, 32441, 32316, 32188, 32057, 31923, 31787, 31648, 31506, 31362, 31216, 31067, \
+  30915, 30761, 30604, 30445, 30284, 30120, 29953, 29785, 29613, 29440, 29264, 29086, 28905, 28722, 28537, 28350, \
+  28160, 27968, 27774, 27577, 27379, 27178, 26975, 26770, 26562, 26353, 26141, 25928, 25712, 25494, 25274, 25052, \
+  24828, 24602, 24373, 24143, 23911, 23677, 23441, 23203, 22962, 22720, 22476, 22230, 21983, 21733, 21481, 21228, \
+  20972, 20715, 20456, 20195, 19932, 19667, 19401, 19132, 18862, 18590, 18317, 18041, 17764, 17485, 17204, 16922, \
+  16637, 16351, 16064, 15774, 15483, 15191, 14896, 14600, 14302, 14003, 13702, 13399, 13095, 12789, 12481, 12172, \
+  11861, 11549, 11235, 10919, 10602, 10283, 9963, 9641, 9318, 8993, 8666, 8338, 8009, 7678, 7345, 7011, 6676, \
+  6339, 6000, 5660, 5319, 4976, 4631, 4286, 3938, 3590, 3239, 2888, 2535, 2180, 1825, 0
+static const uint16_t lmc_counts_bits[257] = {LMC_COUNTS_BITS_LIST};
+
+/* Upper bound of the 16-bit words one lane emits, from S = sum over the symbols of lmc_counts_bits[model count]. */
+static inline uint32_t lmc_counts_lane_words(uint32_t S) { return (S + 6u * ((S >> 12) + 2u)) >> 12; }
+
+/* Allocation of a counts-model stream with a head of `head` bytes whose active lanes may emit `words` words in all
+ * (+ the 64 final states). */
+static inline uint32_t lmc_counts_alloc_bytes(uint32_t head, uint32_t words) { return lmc_r16(head + 2u * (words + 2u * LMC_LANES)); }
+
+/* Section offsets for a chunk geometry (they do not depend on the data). */
+static inline void lmc_blob_layout(uint32_t L, uint32_t T, uint32_t H, uint32_t D, lmc_blob_header* h) {
   uint32_t C = H * D, P = 2u * L, G = (C + LMC_LANES - 1u) / LMC_LANES;
   h->magic = LMC_BLOB_MAGIC;
   h->version = LMC_BLOB_VERSION;
   h->header_bytes = LMC_HEADER_BYTES;
   h->num_layers = L; h->ntokens = T; h->num_heads = H; h->head_size = D;
   h->nchannels = C; h->nplanes = P; h->ngroups = G; h->lp = LMC_LP;
-  h->cdf_rows = cdf_rows;
-  h->count_bytes = lmc_count_bytes(T);
   h->model = lmc_model_for(T);
+  h->zero13 = 0; h->zero18[0] = h->zero18[1] = h->zero18[2] = 0;
   h->off_bins = LMC_HEADER_BYTES;
-  h->off_rowpre = h->off_bins + lmc_r16(P);
-  h->off_scales = h->off_rowpre + lmc_r16(2u * (P + 1u));
+  h->off_scales = h->off_bins + lmc_r16(P);
   h->off_scsum = h->off_scales + lmc_r16(2u * P * T);
-  h->off_cdf = h->off_scsum + lmc_r16(4u * P);
-  h->off_gend = h->off_cdf + lmc_r16(h->count_bytes * C * cdf_rows);
-  h->off_streams = h->off_gend + lmc_r16(4u * P * G);
+  h->off_gdir = h->off_scsum + lmc_r16(4u * P);
+  h->off_streams = h->off_gdir + lmc_r16(8u * P * G);
 }
 
-/* Capacity (bytes) reserved for one group stream while encoding.  Proof that it
- * cannot overflow is in DESIGN.md ("stream bound"): every occurring symbol has
+/* Capacity (bytes) reserved for one group stream: the largest head, and for words and states -- proof that
+ * they cannot overflow is in DESIGN.md ("stream bound"): every occurring symbol has
  * freq >= count*65504/T (CDF16; counts model: exactly count/256), so a lane emits
  * <= T*log2(31)+48 bits < 8*(T+8). */
 static inline uint32_t lmc_group_cap_bytes(uint32_t T) {
-  return lmc_r16(LMC_LANES * (T + 8u));
+  return lmc_head_cap_bytes(T) + lmc_r16(LMC_LANES * (T + 8u));
 }
 
-/* Worst-case blob size for a chunk geometry (every plane at 32 bins). */
+/* Worst-case blob size for a chunk geometry. */
 static inline uint64_t lmc_blob_bound(uint32_t L, uint32_t T, uint32_t H, uint32_t D) {
   lmc_blob_header h;
-  lmc_blob_layout(L, T, H, D, 31u * 2u * L, &h);
+  lmc_blob_layout(L, T, H, D, &h);
   return (uint64_t)h.off_streams + (uint64_t)h.nplanes * h.ngroups * lmc_group_cap_bytes(T);
 }
 
@@ -218,15 +267,15 @@ static inline uint64_t lmc_blob_bound(uint32_t L, uint32_t T, uint32_t H, uint32
  *   [0, 256)        lmc_pack_header
  *   off_table       uint64 seg_off[2 L n + 1]: segment (layer, kv, chunk) -- index (2 layer + kv) n + chunk -- starts at
  *                   off_streams + seg_off[index]; the last entry is the size of the streams region
- *   off_static      n slots of static_stride bytes: bytes [0, off_streams) of chunk i's blob (header, bins, row prefix,
- *                   scales, checksums, counts, stream directory), unchanged
+ *   off_static      n slots of static_stride bytes: bytes [0, off_streams) of chunk i's blob (header, bins, scales,
+ *                   checksums, stream directory), unchanged
  *   off_streams     the segments, in table order; segment (layer, kv, chunk) = the streams of plane kv L + layer of
- *                   chunk `chunk`: bytes [S, E) of the blob's streams section, S = r16(gend[p G - 1]) (0 for p = 0),
- *                   E = r16(gend[(p + 1) G - 1])
+ *                   chunk `chunk`: bytes [S, E) of the blob's streams section, S = beg of stream (p, 0),
+ *                   E = beg of stream (p + 1, 0) (the end of the section for the last plane)
  * Every offset is a multiple of 16.  The blob of chunk i is recovered byte for byte from its static slot and its 2 L
  * segments (lmc_pack_extract, lmc_hip.h); the pack is written by the GPU (lmc_store_pack) and read by lmc_load_pack. */
 #define LMC_PACK_MAGIC 0x4b504d4cu /* "LMPK" */
-#define LMC_PACK_VERSION 1u
+#define LMC_PACK_VERSION 2u
 #define LMC_PACK_HEADER_BYTES 256u
 typedef struct lmc_pack_header {
   uint32_t magic;
@@ -250,10 +299,9 @@ typedef struct lmc_pack_header {
 
 static inline uint64_t lmc_r16_64(uint64_t x) { return (x + 15u) & ~(uint64_t)15u; }
 /* Section offsets of a pack of n chunks (everything but total_bytes, which only the writer knows). */
-static inline void lmc_pack_layout(uint32_t n, uint32_t L, uint32_t chunk_tokens, uint32_t H, uint32_t D, uint32_t cdf_rows,
-                                   lmc_pack_header* h) {
+static inline void lmc_pack_layout(uint32_t n, uint32_t L, uint32_t chunk_tokens, uint32_t H, uint32_t D, lmc_pack_header* h) {
   lmc_blob_header b;
-  lmc_blob_layout(L, chunk_tokens, H, D, cdf_rows, &b);
+  lmc_blob_layout(L, chunk_tokens, H, D, &b);
   h->magic = LMC_PACK_MAGIC; h->version = LMC_PACK_VERSION; h->header_bytes = LMC_PACK_HEADER_BYTES;
   h->nchunks = n; h->num_layers = L; h->num_heads = H; h->head_size = D; h->chunk_tokens = chunk_tokens;
   h->ngroups = b.ngroups; h->static_stride = lmc_r16(b.off_streams);
@@ -261,10 +309,10 @@ static inline void lmc_pack_layout(uint32_t n, uint32_t L, uint32_t chunk_tokens
   h->off_static = lmc_r16_64(h->off_table + 8ull * (2ull * L * n + 1ull));
   h->off_streams = h->off_static + (uint64_t)n * h->static_stride;
 }
-/* Worst-case size of a pack (every plane at 32 bins, every stream at its capacity). */
+/* Worst-case size of a pack (every stream at its capacity). */
 static inline uint64_t lmc_pack_bound(uint32_t n, uint32_t L, uint32_t chunk_tokens, uint32_t H, uint32_t D) {
   lmc_pack_header h;
-  lmc_pack_layout(n, L, chunk_tokens, H, D, 31u * 2u * L, &h);
+  lmc_pack_layout(n, L, chunk_tokens, H, D, &h);
   return h.off_streams + (uint64_t)n * 2u * L * h.ngroups * lmc_group_cap_bytes(chunk_tokens);
 }
 

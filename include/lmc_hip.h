@@ -45,7 +45,7 @@ const char* lmc_strerror(int code);
 int lmc_last_hip_error(void);
 /* ABI version of this header. */
 int lmc_abi_version(void);
-#define LMC_ABI_VERSION 5
+#define LMC_ABI_VERSION 6
 
 /* ------------------------------------------------------------------ */
 /* KV addressing                                                       */

@@ -26,7 +26,7 @@
 // through a raw buffer store (row = scalar offset, channel = vector offset; idle lanes fall outside the
 // descriptor's range).  4.9 KiB of LDS per wave -> 8 waves per SIMD.
 #pragma once
-#include "lmc_device.h"
+#include "k_head.h"
 
 struct DecodeArgs {
   const u8* blobs;
@@ -91,12 +91,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   auto hdw = [&](int i) { return (u32)__builtin_amdgcn_readfirstlane((int)hd[i]); };
   const u32 T = hdw(4);
   const u32 src_dtype = hdw(2);
-  const u32 cdf_rows = hdw(19);
   const bool counts_model = hdw(22) == LMC_MODEL_COUNTS;  // wave-uniform: the coder ran on the symbol counts (T == 256)
-  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, cdf_rows);
-  if (hdw(0) != LMC_BLOB_MAGIC || (hdw(1) & 0xffffu) != LMC_BLOB_VERSION || hdw(7) != (u32)a.C ||
+  const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.G);
+  if (hdw(0) != LMC_BLOB_MAGIC || (hdw(1) & 0xffffu) != LMC_BLOB_VERSION || hdw(7) != (u32)a.C || T == 0u || T > 65535u ||
       hdw(22) != (T == LMC_COUNTS_T ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16) ||
-      hdw(8) != (u32)a.P || hdw(15) != bo.streams || cdf_rows > 31u * (u32)a.P || hdw(20) != dev_count_bytes(T) ||
+      hdw(8) != (u32)a.P || hdw(15) != bo.streams ||
       // every section offset is a function of the fields checked above; the blob must also fit its slot
       (!SYMOUT && (T > (u32)a.chunk_tokens ||
                    (unsigned long long)hdw(a.seg_off ? 15 : 17) > (unsigned long long)a.blob_stride))) {
@@ -106,36 +105,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   const int c = g * 64 + lane;
   const bool active = c < a.C;
 
-  // ---- symbol counts of this group -> the CDF table in LDS, [entry][lane] u16 ----------------------------
-  // The blob stores the counts of every channel's symbols 0 .. nsym-1 (nsym = bins - 1), one byte each for
-  // T <= 256 (lmc_format.h), symbol-major: a lane fetches its own channel's counts (coalesced rows) and turns
-  // them into its column of the table with the encoder's integer arithmetic.
+  // ---- where the stream lies (directory entry {beg, end}, lmc_format.h v6) ------------------------------------------
+  const u32* gdir = reinterpret_cast<const u32*>(blob + bo.gdir);
+  const u32 start = (u32)__builtin_amdgcn_readfirstlane((int)gdir[2 * pg]);
+  const u32 end = (u32)__builtin_amdgcn_readfirstlane((int)gdir[2 * pg + 1]);
+  const u8* sbytes = blob + bo.streams + start;
+  bool seg_bad = false;
+  if (a.seg_off) {  // pack: this plane's streams are a segment of their own, wave-uniform addresses
+    const int Lh = a.P >> 1, layer = p < Lh ? p : p - Lh;
+    const long long si = (long long)(2 * layer + (p >= Lh ? 1 : 0)) * a.seg_n + chunk;
+    const unsigned long long so = uniform_ptr((const void*)a.seg_off[si]), se = uniform_ptr((const void*)a.seg_off[si + 1]);
+    const u32 sbeg = (u32)__builtin_amdgcn_readfirstlane((int)gdir[2 * (p * a.G)]);  // the plane's first stream
+    seg_bad = start < sbeg || se < so || (unsigned long long)end - sbeg > se - so;
+    sbytes = a.seg_streams + so + (start - sbeg);
+  }
+  // 64-bit comparisons: a corrupt directory entry must not wrap its way past the bounds
+  if (seg_bad || (start & 15u) || (unsigned long long)end < (unsigned long long)start + 256ull ||
+      (unsigned long long)bo.streams + (unsigned long long)end > (unsigned long long)hdw(17)) {
+    if (lane == 0) atomicOr(a.status, LMC_ST_BAD_STREAM);
+    return;
+  }
+
+  // ---- the stream's head: symbol counts of this group -> the CDF table in LDS, [entry][lane] u16 ---------------------
+  // The head stores the counts of every channel's symbols 0 .. nsym-1 (nsym = bins - 1) bit-sliced (k_head.h); a lane
+  // takes its own channel's counts and turns them into its column of the table with the encoder's integer arithmetic.
   const u32 nsym = min(31u, max(3u, (u32)__builtin_amdgcn_readfirstlane((int)blob[bo.bins + p]) - 1u));
+  u32 head_bytes;
   {
-    const u32 rp = (u32)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const u16*>(blob + bo.rowpre)[p]);
-    if (rp + nsym > cdf_rows) {  // a corrupt row prefix must not send the count loads outside the section
-      if (lane == 0) atomicOr(a.status, LMC_ST_BAD_HEADER);
+    u32 cv[32];
+    head_bytes = head_read<32>(sbytes, end - start - 256u, nsym, reinterpret_cast<u32*>(cdfT), cv, lane);
+    if (head_bytes == 0u) {
+      if (lane == 0) atomicOr(a.status, LMC_ST_BAD_STREAM);
       return;
     }
-    // plane p of the counts section is [nsym][C] (symbol-major): the lane reads its own channel's counts, one
-    // coalesced row per symbol, straight into registers (two counts per register)
-    const bool bytes1 = dev_count_bytes(T) == 1u;  // wave-uniform
-    const u8* const row0 = blob + bo.cdf + (long long)a.C * rp * (bytes1 ? 1 : 2);  // uniform
-    u32 cv[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) {
-      cv[i] = 0u;
-      if ((u32)i < nsym && active)  // the first test is uniform
-        cv[i] = bytes1 ? (u32)(row0 + (long long)i * a.C)[c] : (u32)(reinterpret_cast<const u16*>(row0) + (long long)i * a.C)[c];
-    }
+    const bool bytes1 = T <= 256u;  // wave-uniform: a count of 256 was stored as 255
     u32 hreg[16];  // this lane's 32 counts, two per register
 #pragma unroll
     for (int i = 0; i < 16; i++) hreg[i] = cv[2 * i] | (cv[2 * i + 1] << 16);
-    if (bytes1) {  // a count of 256 was stored as 255: the counts of a channel sum to T
+    if (bytes1) {  // the counts of a channel sum to T
       u32 sum = 0;
 #pragma unroll
       for (int i = 0; i < 16; i++) sum += (hreg[i] & 0xffffu) + (hreg[i] >> 16);
-      const u32 deficit = T - sum;  // 0 or 1 in a well-formed blob
+      const u32 deficit = active ? T - sum : 0u;  // 0 or 1 in a well-formed blob
       if (__ballot(deficit != 0u)) {
         if (counts_model) {
           // the counts model codes such a channel with 255 and a count of 1 on symbol 0 -- on symbol 1 if the 255 is
@@ -212,28 +223,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   }
 
   // ---- stream ----------------------------------------------------------------
-  const u32* gend = reinterpret_cast<const u32*>(blob + bo.gend);
-  const u32 end = (u32)__builtin_amdgcn_readfirstlane((int)gend[pg]);
-  const u32 prev_end = pg == 0 ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)gend[pg - 1]);
-  const u32 start = (prev_end + 15u) & ~15u;
-  const u16* words = reinterpret_cast<const u16*>(blob + bo.streams + start);
-  bool seg_bad = false;
-  if (a.seg_off) {  // pack: this plane's streams are a segment of their own, wave-uniform addresses
-    const int Lh = a.P >> 1, layer = p < Lh ? p : p - Lh;
-    const long long si = (long long)(2 * layer + (p >= Lh ? 1 : 0)) * a.seg_n + chunk;
-    const unsigned long long so = uniform_ptr((const void*)a.seg_off[si]), se = uniform_ptr((const void*)a.seg_off[si + 1]);
-    const u32 pg0 = (u32)(p * a.G);
-    const u32 sbeg = pg0 ? ((u32)__builtin_amdgcn_readfirstlane((int)gend[pg0 - 1]) + 15u) & ~15u : 0u;
-    seg_bad = start < sbeg || se < so || (unsigned long long)end - sbeg > se - so;
-    words = reinterpret_cast<const u16*>(a.seg_streams + so + (start - sbeg));
-  }
-  // 64-bit comparisons: a corrupt directory entry must not wrap its way past the bounds
-  if (seg_bad || prev_end > 0xfffffff0u || (unsigned long long)end < (unsigned long long)start + 256ull ||
-      (unsigned long long)bo.streams + (unsigned long long)end > (unsigned long long)hdw(17)) {
-    if (lane == 0) atomicOr(a.status, LMC_ST_BAD_STREAM);
-    return;
-  }
-  const u32 nwords = ((end - start) >> 1) - 128u;  // 16-bit words in front of the 64 states
+  const u16* words = reinterpret_cast<const u16*>(sbytes + head_bytes);
+  const u32 nwords = ((end - start - head_bytes) >> 1) - 128u;  // 16-bit words in front of the 64 states
   u32 x = (u32)words[nwords + 2 * lane] | ((u32)words[nwords + 2 * lane + 1] << 16);
   // The decoder consumes the stream from its end: after `e` = number of words not yet consumed, a token whose
   // cnt lanes renormalise takes words [e - cnt, e), ascending with the lane (the encoder's append order).  The

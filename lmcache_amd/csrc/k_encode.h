@@ -11,8 +11,7 @@
 //
 //   pass 1  per-lane histogram in LDS, u16 counters [symbol][lane]; lanes 2i and
 //           2i+1 share a dword and add 1 / 1 << 16 with ds_add_u32 (bank = lane / 2).
-//           The counts go to the blob (its "cdf" section holds counts: lmc_format.h)
-//           with coalesced stores read transposed from LDS.
+//           The counts open the stream, bit-sliced (k_head.h; lmc_format.h "head").
 //   CDF     cdf[i] = RNE(n_i * 65504 / T) + i, exact integer arithmetic
 //           (cdf_column_to_lds, shared with the decoder), kept in LDS as
 //           tab[entry][lane] u16 (aliases the dead histogram: 4.2 KiB per wave)
@@ -24,7 +23,7 @@
 //           (single-pass prefix over the group lengths of the chunk, one look-back per workgroup)
 // 4.75 KiB of LDS per wave -> 8 waves per SIMD.
 #pragma once
-#include "lmc_device.h"
+#include "k_head.h"
 
 struct EncodeArgs {
   // symbols
@@ -34,14 +33,14 @@ struct EncodeArgs {
   int P, C, G, TQ;
   long long sym_stride;  // dwords between the workspace regions of consecutive (chunk, plane) pairs: >= TQ * C (lmc_api.hip pads it)
   // outputs
-  u8* blobs;            // ENCODE: blob i at blobs + i*blob_stride (cdf section written here)
+  u8* blobs;            // ENCODE: blob i at blobs + i*blob_stride
   long long blob_stride;
   u16* cdf_out;         // !ENCODE: [P][C][33]
   u8* scratch;          // [nchunks*P*G][cap] padded group streams
   u32 cap;              // bytes per scratch slot
   u32* status;
-  BinsArg bins;         // ENCODE: bins and CDF row prefix per plane
-  // in-kernel stream compaction (single-pass prefix over the padded group lengths of a chunk)
+  BinsArg bins;         // ENCODE: bins per plane
+  // in-kernel stream compaction (single-pass prefix over the allocations of a chunk's streams)
   unsigned long long* agg;  // [nchunks][P*G], zeroed before the launch: flag << 62 | value
   u32* sizes;               // [nchunks] total blob bytes
   int L, H, D, dtype;       // for the header
@@ -75,17 +74,14 @@ __device__ __forceinline__ unsigned long long agg_load(unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Header, bins, rowpre and the zero pads between sections (what the oracle memsets): by one wave.
+// Header, bins and the zero pads between sections (what the oracle memsets): by one wave.
 __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, const EncodeArgs& a, u32 T,
                                                   u32 stream_bytes, int lane) {
-  const u32 P = (u32)a.P, n = (u32)(a.P * a.G), cdf_rows = a.bins.rowpre[a.P];
-  for (u32 i = lane; i < bo.rowpre - bo.bins; i += 64) blob[bo.bins + i] = i < P ? a.bins.b[i] : (u8)0;
-  for (u32 i = lane; i < (bo.scales - bo.rowpre) / 2; i += 64)
-    reinterpret_cast<u16*>(blob + bo.rowpre)[i] = i <= P ? a.bins.rowpre[i] : (u16)0;
+  const u32 P = (u32)a.P, n = (u32)(a.P * a.G);
+  for (u32 i = lane; i < bo.scales - bo.bins; i += 64) blob[bo.bins + i] = i < P ? a.bins.b[i] : (u8)0;
   for (u32 i = bo.scales + 2u * P * T + lane; i < bo.scsum; i += 64) blob[i] = 0;
-  for (u32 i = bo.scsum + 4u * P + lane; i < bo.cdf; i += 64) blob[i] = 0;
-  for (u32 i = bo.cdf + dev_count_bytes(T) * (u32)a.C * cdf_rows + lane; i < bo.gend; i += 64) blob[i] = 0;
-  for (u32 i = bo.gend + 4u * n + lane; i < bo.streams; i += 64) blob[i] = 0;
+  for (u32 i = bo.scsum + 4u * P + lane; i < bo.gdir; i += 64) blob[i] = 0;
+  for (u32 i = bo.gdir + 8u * n + lane; i < bo.streams; i += 64) blob[i] = 0;
   if (lane < 32) {
     u32 v = 0;
     switch (lane) {
@@ -102,14 +98,10 @@ __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, c
       case 10: v = LMC_LP; break;
       case 11: v = bo.bins; break;
       case 12: v = bo.scales; break;
-      case 13: v = bo.cdf; break;
-      case 14: v = bo.gend; break;
+      case 14: v = bo.gdir; break;  // the stream directory {beg, end}
       case 15: v = bo.streams; break;
       case 16: v = stream_bytes; break;
       case 17: v = bo.streams + stream_bytes; break;
-      case 18: v = bo.rowpre; break;
-      case 19: v = cdf_rows; break;
-      case 20: v = dev_count_bytes(T); break;
       case 21: v = bo.scsum; break;
       case 22: v = T == LMC_COUNTS_T ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16; break;  // lmc_model_for
       default: v = 0;
@@ -178,59 +170,56 @@ __device__ __forceinline__ u32 lookback_exclusive(unsigned long long* agg, int i
 #ifndef LMC_PLACE_BATCH
 #define LMC_PLACE_BATCH 4  // KiB of LDS = loads in flight
 #endif
-#ifndef LMC_PLACE_NT_IN
-#define LMC_PLACE_NT_IN 0  // experiment: the scratch slot is read for the last time: non-temporal (aux = 2)
-#endif
-#ifndef LMC_PLACE_NT_OUT
-#define LMC_PLACE_NT_OUT 1  // the placed streams are not read again by this kernel: non-temporal stores (k_fused.h)
-#endif
-#ifndef LMC_PLACE_SERIAL
-#define LMC_PLACE_SERIAL 0
-#endif
 __device__ __forceinline__ void copy_stream16(uint4* dst, const uint4* src, u32 n16_v, u32* lds4k, int lane) {
   typedef __attribute__((address_space(1))) const void* gptr;
   typedef __attribute__((address_space(3))) void* lptr;
   const u32 n16 = (u32)__builtin_amdgcn_readfirstlane((int)n16_v);  // wave-uniform: scalar loop control
-#if LMC_PLACE_SERIAL  // A/B: the round-2 loop
-#pragma unroll 4
-  for (u32 i = lane; i < n16; i += 64) dst[i] = src[i];
-  return;
-#endif
 #pragma unroll 1
   for (u32 base = 0; base < n16; base += 64u * LMC_PLACE_BATCH) {
 #pragma unroll
     for (int k = 0; k < LMC_PLACE_BATCH; k++) {
       const u32 i = base + 64u * k + lane;
-      __builtin_amdgcn_global_load_lds((gptr)(src + (i < n16 ? i : n16 - 1u)), (lptr)(lds4k + 256 * k), 16, 0, LMC_PLACE_NT_IN ? 2 : 0);
+      __builtin_amdgcn_global_load_lds((gptr)(src + (i < n16 ? i : n16 - 1u)), (lptr)(lds4k + 256 * k), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int k = 0; k < LMC_PLACE_BATCH; k++) {
       const u32 i = base + 64u * k + lane;
       const uint4 v = *reinterpret_cast<const uint4*>(lds4k + 256 * k + 4 * lane);
-#if LMC_PLACE_NT_OUT
+      // the placed streams are not read again by this kernel: non-temporal stores
       if (i < n16) __builtin_nontemporal_store(*reinterpret_cast<const u32x4_t*>(&v), reinterpret_cast<LMC_GLOBAL u32x4_t*>((LMC_GLOBAL uint4*)(dst + i)));
-#else
-      if (i < n16) dst[i] = v;
-#endif
       asm volatile("" ::: "memory");  // one piece in registers at a time
     }
   }
   wave_lds_fence();  // the slice is free for its next user
 }
 
+// 16-byte zero fill of [p, p + n), n a multiple of 16, by one wave (the slack between a stream and its allocation)
+__device__ __forceinline__ void zero_fill16(u8* p, u32 n, int lane) {
+  for (u32 i = 16u * (u32)lane; i < n; i += 1024u) *reinterpret_cast<uint4*>(p + i) = make_uint4(0, 0, 0, 0);
+}
+
+// A finished stream from its scratch slot to byte `beg` of the chunk's streams section, the zeros up to the end of its
+// allocation, and its directory entry {beg, end} (lmc_format.h, v6).  STATIC: the chunk's last stream also writes
+// header, static sections and the size word (chunk_total = bytes of the whole streams section).
 template <bool STATIC = true>
-__device__ __forceinline__ void place_stream(const EncodeArgs& a, const PendingTile& t, u32 excl, u32* lds4k, int lane) {
+__device__ __forceinline__ void place_stream(const EncodeArgs& a, const PendingTile& t, u32 beg, u32 alloc, u32 chunk_total,
+                                             u32* lds4k, int lane) {
   const int n = a.P * a.G;
   const u32 padded = (t.exact + 15u) & ~15u;
-  const BlobOff bo = lmc_blob_off((u32)a.P, t.T, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
+  const BlobOff bo = lmc_blob_off((u32)a.P, t.T, (u32)a.G);
   u8* blob = a.blobs + (long long)t.chunk * a.blob_stride;
-  if (lane == 0) reinterpret_cast<u32*>(blob + bo.gend)[t.pg] = excl + t.exact;
+  if (lane == 0) {
+    u32* d = reinterpret_cast<u32*>(blob + bo.gdir) + 2 * t.pg;
+    d[0] = beg;
+    d[1] = beg + t.exact;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stream stores have landed before it re-reads them
-  copy_stream16(reinterpret_cast<uint4*>(blob + bo.streams + excl), reinterpret_cast<const uint4*>(t.out), padded >> 4, lds4k, lane);
-  if (STATIC && t.pg == n - 1) {  // the last group knows the chunk's size: header, static sections, size word
-    write_blob_static(blob, bo, a, t.T, excl + padded, lane);
-    if (lane == 0) a.sizes[t.chunk] = bo.streams + excl + padded;
+  copy_stream16(reinterpret_cast<uint4*>(blob + bo.streams + beg), reinterpret_cast<const uint4*>(t.out), padded >> 4, lds4k, lane);
+  if (alloc > padded) zero_fill16(blob + bo.streams + beg + padded, alloc - padded, lane);
+  if (STATIC && t.pg == n - 1) {  // the last stream knows the chunk's size: header, static sections, size word
+    write_blob_static(blob, bo, a, t.T, chunk_total, lane);
+    if (lane == 0) a.sizes[t.chunk] = bo.streams + chunk_total;
   }
 }
 
@@ -334,33 +323,31 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
     }
   }
   if (ENCODE) {
-    // The blob stores the COUNTS of every channel's symbols 0 .. R-1 (R = bins - 1; lmc_format.h), symbol-major.
-    // One byte per count for T <= 256 (256 saturates to 255).
     wave_lds_fence();  // every lane's ds_add has landed
-    const u32 T = (u32)Tc;
-    const u32 R = (u32)a.bins.b[p] - 1u;
-    const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
-    u8* const blob0 = a.blobs + (long long)chunk * a.blob_stride;
     if (g == 0) {  // one wave per (chunk, plane): checksum of the plane's scales (written by k_quantize)
-      const u32 cs = scale_checksum(reinterpret_cast<const u16*>(blob0 + bo.scales) + (long long)p * T, T, lane);
+      const BlobOff bo = lmc_blob_off((u32)a.P, (u32)Tc, (u32)a.G);
+      u8* const blob0 = a.blobs + (long long)chunk * a.blob_stride;
+      const u32 cs = scale_checksum(reinterpret_cast<const u16*>(blob0 + bo.scales) + (long long)p * Tc, (u32)Tc, lane);
       if (lane == 0) reinterpret_cast<u32*>(blob0 + bo.scsum)[p] = cs;
-    }
-    // plane p of the counts section = [R][C] (symbol-major): a lane stores its own channel's counts, one coalesced
-    // row per symbol, reading its own column of the histogram
-    const u32 cb = dev_count_bytes(T);
-    u8* const sec_row0 = blob0 + bo.cdf + (long long)a.C * a.bins.rowpre[p] * cb;  // uniform
-    for (u32 i = 0; i < R; i++) {
-      const u32 v = tab[i * 64 + lane];
-      if (active) {
-        if (cb == 1u) (sec_row0 + (long long)i * a.C)[c] = (u8)min(v, 255u);
-        else (reinterpret_cast<u16*>(sec_row0) + (long long)i * a.C)[c] = (u16)v;
-      }
     }
   }
   u32 hreg[16];  // this lane's 32 counts, two per register
 #pragma unroll
   for (int i = 0; i < 16; i++) hreg[i] = (u32)tab[(2 * i) * 64 + lane] | ((u32)tab[(2 * i + 1) * 64 + lane] << 16);
   wave_lds_fence();  // hist is dead from here on: tab aliases it
+
+  // ---- the stream opens with its head: the counts, bit-sliced (a chunk of 256 tokens never comes here, so no count
+  // saturates: T < 256 keeps them below 256, T > 256 stores them as they are) -------------------------------------
+  u16* out = ENCODE ? reinterpret_cast<u16*>(a.scratch + gid * (long long)a.cap) : nullptr;
+  u32 head = 0;
+  if (ENCODE) {
+    u32 pk[16], wor[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) pk[i] = active ? hreg[i] : 0u;
+    head_or_counts<16>(pk, wor);
+    head = head_write<16, 16>(reinterpret_cast<u8*>(out), pk, wor, (u32)a.bins.b[p] - 1u, lane);
+    out += head >> 1;
+  }
 
   // ---- CDF ------------------------------------------------------------------
   const u32 T = (u32)Tc;
@@ -393,7 +380,6 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
   if (!ENCODE) return;
 
   // ---- pass 2: interleaved rANS ---------------------------------------------
-  u16* out = reinterpret_cast<u16*>(a.scratch + gid * (long long)a.cap);
   // Idle lanes (channel >= C) see symbol 0 only (w = 0, start 0): starting them at x = 0 keeps them at 0,
   // so they never satisfy the renormalisation test and the hot loop needs no lane predicate.
   u32 x = active ? LMC_RANS_L : 0u;
@@ -503,10 +489,10 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
   out[wcur + 2 * lane] = (u16)x;
   out[wcur + 2 * lane + 1] = (u16)(x >> 16);
   wcur += 128;
-  const u32 exact = wcur * 2;
+  const u32 exact = head + wcur * 2;  // head is a multiple of 16
   const u32 padw = ((16u - (exact & 15u)) & 15u) >> 1;
   if ((u32)lane < padw) out[wcur + lane] = 0;
   if (lane == 0 && exact + 16 > a.cap) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);
-  t.chunk = chunk; t.pg = p * a.G + g; t.exact = exact; t.T = T; t.out = out;
+  t.chunk = chunk; t.pg = p * a.G + g; t.exact = exact; t.T = T; t.out = out - (head >> 1);
 }
 

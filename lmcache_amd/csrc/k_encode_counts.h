@@ -15,6 +15,14 @@
 //   * the code length is the channel's empirical entropy (0.1-0.2 % below CDF16 on rand / randn data).
 // Token step of a <= 16-symbol plane: 11 VALU (v_cmpx_sdwa, mbcnt x 2, lshl_add, lshr | mul_hi, lshr, lshr, mad,
 // add_sdwa | the next entry's reciprocal address) + 2-3 for the row address of the entry after that.
+//
+// Format v6 splits a stream's life in two, because a counts-model stream is PLACED before it is coded:
+//   counts_hist_stream   pass 1: histogram -> the lane's stored counts (packed, four to a register), their OR over the
+//                        lanes (the widths of the stream's head) and the stream's allocation: an upper bound of its
+//                        length from the counts (lmc_counts_bits);
+//   counts_open_stream   the head (k_head.h) to the stream's place, the coder's table from the counts;
+//   counts_code_stream   pass 2: interleaved rANS, the words leaving for `out` -- the stream's final place in the
+//                        blob (k_fused.h, the normal case) or a scratch slot.
 #pragma once
 #include "k_encode.h"
 
@@ -40,34 +48,31 @@ constexpr RansRtab make_rans_rtab() {
   return t;
 }
 __device__ const RansRtab g_rans_rtab = make_rans_rtab();
+// lmc_counts_bits (lmc_format.h), the stream-length bound's table: read once per symbol and stream, from the
+// workgroup's LDS copy behind the reciprocals (u16 entries)
+#define BITS_DWORDS 132  // 257 u16, rounded up to 16 bytes
+#define RTAB_LDS_DWORDS (RTAB_DWORDS + BITS_DWORDS)
+struct CountsBits {
+  u32 v[BITS_DWORDS];
+};
+constexpr CountsBits make_counts_bits() {
+  constexpr u16 t[257] = {LMC_COUNTS_BITS_LIST};
+  CountsBits r{};
+  for (int i = 0; i < 257; i++) r.v[i >> 1] |= (u32)t[i] << (16 * (i & 1));
+  return r;
+}
+__device__ const CountsBits g_counts_bits = make_counts_bits();
 
-// every thread of the workgroup takes part; the caller synchronises before the first coder step
+// every thread of the workgroup takes part; the caller synchronises before the first use
 __device__ __forceinline__ void rtab_to_lds(u32* rtab_lds) {
   for (u32 i = threadIdx.x; i < RTAB_DWORDS; i += blockDim.x) rtab_lds[i] = g_rans_rtab.v[i];
+  for (u32 i = threadIdx.x; i < BITS_DWORDS; i += blockDim.x) rtab_lds[RTAB_DWORDS + i] = g_counts_bits.v[i];
 }
 
-// how far ahead the token loop requests its table reads (encode_group_stream_counts): 0: one token, in front of the
-// ring store; 1: entry two tokens / reciprocal one token ahead, behind the ring store; 2: four / two tokens ahead
-#ifndef LMC_COUNTS_LDSASM
-#define LMC_COUNTS_LDSASM 2
-#endif
-
-// timing experiments (tools/probes): bit 0 the quantise phase twice, bit 1 the histogram pass twice, bit 2 the
-// coding pass twice (all three leave the blobs unchanged), bit 3 no placement copy (blobs incomplete); bits 4-6 put
-// the raw rows / the symbol workspace / the stream scratch of the fused kernel on a few aliased regions that stay
-// in L2 (what the kernel costs without that HBM traffic; blobs are garbage)
-// the coding pass reads a symbol dword for the last time: with LMC_SYM_NT the load says so (non-temporal)
-#ifndef LMC_SYM_NT
-#define LMC_SYM_NT 1
-#endif
-#if LMC_SYM_NT
+// the coding pass reads a symbol dword for the last time: the load says so (non-temporal), so that what is touched
+// once does not push what is still needed out of L2 / Infinity Cache (same box: 1.017-1.027 -> 0.968-0.975 ms together
+// with the non-temporal raw-KV loads and stream stores of the fused kernel)
 #define LMC_SYM_LAST_LOAD(p) __builtin_nontemporal_load((const LMC_GLOBAL u32*)(p))
-#else
-#define LMC_SYM_LAST_LOAD(p) (*(p))
-#endif
-#ifndef LMC_EXP_TWICE
-#define LMC_EXP_TWICE 0
-#endif
 
 #define CNT_TAB_DWORDS 1024  // per wave: counters, then (aliased) the table: [16][64] u32, or [32][64] u16
 
@@ -98,33 +103,90 @@ __device__ __forceinline__ u32 row_addr_cnt(const u32* w, u32 base) {
   else return row_addr_sh<8 * (I & 3), 8, 7>(w[I >> 2], base);
 }
 
-typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
 
-// One group stream of a 256-token chunk under LMC_MODEL_COUNTS, by one wave.  `tabmem` = the wave's CNT_TAB_DWORDS
-// of LDS, `ring` its staging ring (ENC_RING_DWORDS), `rtab` the workgroup's copy of g_rans_rtab.
-// LDSASM: the token loop requests its table entries two tokens ahead and the reciprocal one token ahead, right
-// behind the step's ring store (see pass2); otherwise one token ahead, in front of it.
-template <int LDSASM>
-__device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, long long gid, u32* tabmem, u16* const ring,
-                                                           const u32* rtab, int lane, PendingTile& t) {
-  typedef __attribute__((address_space(3))) u32* lds_u32w;
-  typedef __attribute__((address_space(3))) u16* lds_u16w;
-  const int g = (int)(gid % a.G);
+// One group stream of a 256-token chunk, as its wave sees it.
+struct CountsStream {
+  int chunk, p, g, c;
+  bool active, nib;  // nib is wave-uniform
+  const u32* symq;   // this lane's column of the plane-chunk's symbol workspace
+  u32 R;             // symbols the plane's quantiser can emit
+};
+__device__ __forceinline__ CountsStream counts_stream_of(const EncodeArgs& a, long long gid, int lane) {
+  CountsStream s;
+  s.g = (int)(gid % a.G);
   const long long pc = gid / a.G;
-  const int p = (int)(pc % a.P);
-  const int chunk = (int)(pc / a.P);
-  constexpr int Tc = (int)LMC_COUNTS_T;
-  const int c = g * 64 + lane;
-  const bool active = c < a.C;
-  const u32* symq = a.sym4 + ((long long)chunk * a.P + p) * a.sym_stride + c;
-  const bool nib = lmc_sym_nibbles((int)a.bins.b[p]);  // wave-uniform
-  const u32 tab_addr = (u32)(size_t)(lds_u32w)tabmem;
-  const u32 rtab_addr = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(lds_u32w) const_cast<u32*>(rtab));
-  u16* const tab16 = reinterpret_cast<u16*>(tabmem);
+  s.p = (int)(pc % a.P);
+  s.chunk = (int)(pc / a.P);
+  s.c = s.g * 64 + lane;
+  s.active = s.c < a.C;
+  s.symq = a.sym4 + ((long long)s.chunk * a.P + s.p) * a.sym_stride + s.c;
+  s.nib = lmc_sym_nibbles((int)a.bins.b[s.p]);
+  s.R = (u32)a.bins.b[s.p] - 1u;
+  return s;
+}
 
-  // ---- pass 1: histogram ----------------------------------------------------------------------------------------
-  // <= 16 symbols: u32 counters [16][64] (bank = lane: conflict free); else u16 counters [32][64], lanes 2i and 2i+1
-  // sharing a dword and adding 1 / 1 << 16 (as the CDF16 coder does).  Both alias the table that replaces them.
+// A stream between its two passes: the lane's STORED counts (lmc_format.h: a count of 256 reads 255; a lane without
+// a channel stores 0), one byte per symbol -- symbol i = byte i % 4 of pk[i / 4], <= 16-symbol planes use pk[0 .. 4) --,
+// their OR over the lanes (wave-uniform: the widths of the head's fields) and the head's size.
+struct CountsState {
+  u32 pk[8];
+  u32 wor[8];
+  u32 head;
+};
+
+// A lane's MODEL counts (lmc_counts_model) from its stored counts: themselves, but a channel whose 256 symbols are
+// equal (stored 255, a unit missing from the sum) is coded with 255 and a count of 1 on symbol 0 (on symbol 1 if its
+// own symbol is 0); a lane without a channel is coded like a constant channel of symbol 0 (it never emits).
+// cnt[i] = count of symbol i, NS = 16 or 32.
+template <int NS>
+__device__ __forceinline__ void counts_model_of(const u32 (&pk)[8], bool active, u32 (&cnt)[NS]) {
+  u32 sum = 0;
+#pragma unroll
+  for (int i = 0; i < NS; i++) {
+    cnt[i] = (pk[i >> 2] >> (8 * (i & 3))) & 0xffu;
+    sum += cnt[i];
+  }
+  const u32 deficit = LMC_COUNTS_T - sum;  // 0, or 1 for a constant channel (256 for a lane without a channel)
+  const bool first = cnt[0] == 255u;
+  cnt[0] += first ? 0u : deficit;
+  cnt[1] += first ? deficit : 0u;
+  if (!active) { cnt[0] = 255u; cnt[1] = 1u; }
+}
+
+// The table of a <= 16-symbol plane from this lane's MODEL counts: entry = count << 23 | 2 * (symbols below) -- the
+// emit threshold's upper half, and the start.
+__device__ __forceinline__ void counts_table_nib(const u32 (&cnt)[16], u32* tabmem, int lane) {
+  u32 acc = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    tabmem[i * 64 + lane] = (cnt[i] << 23) | (acc << 1);
+    acc += cnt[i];
+  }
+}
+// ... of a plane with more symbols: entry = (symbols below) << 8 | count; 255 + 1 keeps both in a byte
+__device__ __forceinline__ void counts_table_byte(const u32 (&cnt)[32], u16* tab16, int lane) {
+  u32 acc = 0;
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    tab16[i * 64 + lane] = (u16)(((acc & 0xffu) << 8) | cnt[i]);
+    acc += cnt[i];
+  }
+}
+
+// ---- pass 1 --------------------------------------------------------------------------------------------------------
+// Histogram of the stream's 256 symbols in the wave's table slice `tabmem` (<= 16 symbols: u32 counters [16][64],
+// bank = lane: conflict free; else u16 counters [32][64], lanes 2i and 2i+1 sharing a dword and adding 1 / 1 << 16).
+// Leaves the stream's CountsState and returns its allocation (lmc_format.h, v6): head + the bound of the words the
+// active lanes can emit -- S = sum of lmc_counts_bits over a lane's model counts (`bits` = the workgroup's LDS copy),
+// lmc_counts_lane_words(S) words per lane -- + the 64 states.  Wave g == 0 also writes the checksum of the plane's
+// scales.  The slice is free again on return.
+__device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const CountsStream& s, u32* tabmem, const u32* bits,
+                                                  int lane, CountsState& cs) {
+  typedef __attribute__((address_space(3))) u32* lds_u32w;
+  typedef const __attribute__((address_space(3))) u16* lds_u16p;
+  constexpr int Tc = (int)LMC_COUNTS_T;
+  const u32 tab_addr = (u32)(size_t)(lds_u32w)tabmem;
+  u16* const tab16 = reinterpret_cast<u16*>(tabmem);
   auto pass1 = [&](auto nib_tag) {
     constexpr bool NIB = decltype(nib_tag)::value;
     constexpr int DPB = NIB ? 4 : 8;  // dwords per 32-token block
@@ -135,11 +197,11 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
     const u32 one = NIB ? 1u : 1u << ((lane & 1) * 16);
     u32 w[DPB], wn[DPB];
 #pragma unroll
-    for (int j = 0; j < DPB; j++) w[j] = active ? symq[(long long)j * a.C] : 0u;
+    for (int j = 0; j < DPB; j++) w[j] = s.active ? s.symq[(long long)j * a.C] : 0u;
     for (int b = 0; b < NB; b++) {
       if (b + 1 < NB) {
 #pragma unroll
-        for (int j = 0; j < DPB; j++) wn[j] = active ? symq[(long long)((b + 1) * DPB + j) * a.C] : 0u;
+        for (int j = 0; j < DPB; j++) wn[j] = s.active ? s.symq[(long long)((b + 1) * DPB + j) * a.C] : 0u;
       }
       static_for<32>([&](auto itag) {
         constexpr int i = decltype(itag)::value;
@@ -150,100 +212,95 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
       for (int j = 0; j < DPB; j++) w[j] = wn[j];
     }
   };
-  if (nib) pass1(BoolTag<true>{});
+  if (s.nib) pass1(BoolTag<true>{});
   else pass1(BoolTag<false>{});
-#if LMC_EXP_TWICE & 2  // timing experiment: the histogram pass a second time (same counts)
-  wave_lds_fence();
-  if (nib) pass1(BoolTag<true>{});
-  else pass1(BoolTag<false>{});
-#endif
   wave_lds_fence();  // every lane's ds_add has landed
 
-  const u32 R = (u32)a.bins.b[p] - 1u;
-  const BlobOff bo = lmc_blob_off((u32)a.P, (u32)Tc, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
-  u8* const blob0 = a.blobs + (long long)chunk * a.blob_stride;
-  if (g == 0) {  // one wave per (chunk, plane): checksum of the plane's scales (written by the quantise stage)
-    const u32 cs = scale_checksum(reinterpret_cast<const u16*>(blob0 + bo.scales) + (long long)p * Tc, (u32)Tc, lane);
-    if (lane == 0) reinterpret_cast<u32*>(blob0 + bo.scsum)[p] = cs;
+  if (s.g == 0) {  // one wave per (chunk, plane): checksum of the plane's scales (written by the quantise stage)
+    const BlobOff bo = lmc_blob_off((u32)a.P, LMC_COUNTS_T, (u32)a.G);
+    u8* const blob0 = a.blobs + (long long)s.chunk * a.blob_stride;
+    const u32 sum = scale_checksum(reinterpret_cast<const u16*>(blob0 + bo.scales) + (long long)s.p * Tc, (u32)Tc, lane);
+    if (lane == 0) reinterpret_cast<u32*>(blob0 + bo.scsum)[s.p] = sum;
   }
-  // counts section of the blob (lmc_format.h): plane p = [R][C] bytes, 256 saturating to 255 -- a lane stores its own
-  // channel's counts straight from its registers, one coalesced 64-byte row per symbol
-  u8* const sec_row0 = blob0 + bo.cdf + (long long)a.C * a.bins.rowpre[p];  // uniform
-  auto store_count = [&](u32 i, u32 v) {
-    if (i < R) {  // uniform
-      u8* row = sec_row0 + (long long)i * a.C;  // uniform base, lane offset c
-      if (active) row[c] = (u8)min(v, 255u);
-    }
-  };
-
-  // ---- table ------------------------------------------------------------------------------------------------------
-  // A channel whose 256 symbols are equal is coded with count 255 and a count of 1 on symbol 0 (symbol 1 if its own
-  // symbol is 0): lmc_counts_model.  Idle lanes (channel >= C) saw symbol 0 only, so they are such channels.
-  u32 x = active ? LMC_COUNTS_L : 0u;
-  if (nib) {
-    u32 cnt[16];
+  // the lane's stored counts: min(count, 255), four to a register; a lane without a channel (it saw symbol 0 only)
+  // stores nothing
 #pragma unroll
-    for (int i = 0; i < 16; i++) cnt[i] = tabmem[i * 64 + lane];
+  for (int k = 0; k < 8; k++) cs.pk[k] = 0u;
+  if (s.nib) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) store_count((u32)i, cnt[i]);
-    u32 orv = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) orv |= cnt[i];
-    if (__ballot((orv & 256u) != 0u)) {  // rare: some lane's channel is constant
-      const u32 first = cnt[0] >> 8;     // 1: the constant symbol is symbol 0
-#pragma unroll
-      for (int i = 0; i < 16; i++) cnt[i] -= cnt[i] >> 8;
-      const u32 any = orv >> 8;          // 0 or 1
-      cnt[0] += any & (first ^ 1u);
-      cnt[1] += any & first;
-    }
-    wave_lds_fence();  // the counters are dead (transposed reads above included): the table takes their place
-    u32 acc = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {  // entry = count << 23 | 2 * (symbols below): the emit threshold's upper half, start
-      tabmem[i * 64 + lane] = (cnt[i] << 23) | (acc << 1);
-      acc += cnt[i];
+    for (int i = 0; i < 16; i++) {
+      const u32 c = tabmem[i * 64 + lane];
+      cs.pk[i >> 2] |= (c - (c >> 8)) << (8 * (i & 3));
     }
   } else {
-    u32 hreg[16];  // this lane's 32 counts, two per register
 #pragma unroll
-    for (int i = 0; i < 16; i++) hreg[i] = (u32)tab16[(2 * i) * 64 + lane] | ((u32)tab16[(2 * i + 1) * 64 + lane] << 16);
-#pragma unroll
-    for (int i = 0; i < 32; i++) store_count((u32)i, (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
-    u32 orv = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) orv |= hreg[i];
-    if (__ballot((orv & 0x01000100u) != 0u)) {
-      const u32 first = (hreg[0] >> 8) & 1u;
-      const u32 any = ((orv >> 8) | (orv >> 24)) & 1u;
-#pragma unroll
-      for (int i = 0; i < 16; i++) hreg[i] -= (hreg[i] >> 8) & 0x00010001u;
-      hreg[0] += (any & (first ^ 1u)) + ((any & first) << 16);
-    }
-    wave_lds_fence();
-    u32 acc = 0;
-#pragma unroll
-    for (int i = 0; i < 32; i++) {  // entry = (symbols below) << 8 | count; 255 + 1 keeps both in a byte
-      const u32 ci = (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-      tab16[i * 64 + lane] = (u16)(((acc & 0xffu) << 8) | ci);
-      acc += ci;
+    for (int i = 0; i < 32; i++) {
+      const u32 c = (u32)tab16[i * 64 + lane];
+      cs.pk[i >> 2] |= (c - (c >> 8)) << (8 * (i & 3));
     }
   }
-  wave_lds_fence();
+  if (!s.active) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) cs.pk[k] = 0u;
+  }
+  wave_lds_fence();  // the counters are dead: every lane holds its counts
+  head_or_counts<8>(cs.pk, cs.wor);
+  cs.head = head_bytes_of<8, 8>(cs.wor, s.R);
+  // the bound: S over the lane's model counts
+  const u32 bits_addr = (u32)(size_t)(lds_u16p) reinterpret_cast<const u16*>(bits);
+  u32 S = 0;
+  auto bound = [&](auto ns_tag) {
+    constexpr int NS = decltype(ns_tag)::value;
+    u32 cnt[NS];
+    counts_model_of<NS>(cs.pk, s.active, cnt);
+#pragma unroll
+    for (int i = 0; i < NS; i++) S += (u32) * (lds_u16p)(size_t)(bits_addr + 2u * cnt[i]);
+  };
+  if (s.nib) bound(IntTag<16>{});
+  else bound(IntTag<32>{});
+  const u32 lw = s.active ? (S + 6u * ((S >> 12) + 2u)) >> 12 : 0u;  // lmc_counts_lane_words
+  const u32 words = (u32)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(lw));
+  return (cs.head + 2u * (words + 128u) + 15u) & ~15u;  // lmc_counts_alloc_bytes
+}
 
-  // ---- pass 2: interleaved rANS, tokens 255 .. 0 -----------------------------------------------------------------
-#if LMC_EXP_TWICE & 64  // timing experiment: 256 scratch slots for the whole job (stay in L2)
-  u16* out = reinterpret_cast<u16*>(a.scratch + (gid % 256) * (long long)a.cap);
-#else
-  u16* out = reinterpret_cast<u16*>(a.scratch + gid * (long long)a.cap);
-#endif
+// The stream opens: its head to `out` (16-byte aligned: the stream's place in the blob, or a scratch slot), the coder's
+// table to the wave's slice (whose previous contents are dead).  The words go to out + cs.head.
+__device__ __forceinline__ void counts_open_stream(const CountsStream& s, const CountsState& cs, u8* out, u32* tabmem, int lane) {
+  (void)head_write<8, 8>(out, cs.pk, cs.wor, s.R, lane);
+  wave_lds_fence();
+  if (s.nib) {
+    u32 cnt[16];
+    counts_model_of<16>(cs.pk, s.active, cnt);
+    counts_table_nib(cnt, tabmem, lane);
+  } else {
+    u32 cnt[32];
+    counts_model_of<32>(cs.pk, s.active, cnt);
+    counts_table_byte(cnt, reinterpret_cast<u16*>(tabmem), lane);
+  }
+  wave_lds_fence();
+}
+
+// ---- pass 2: interleaved rANS, tokens 255 .. 0 -----------------------------------------------------------------
+// `tabmem` holds the stream's table, `ring` is the wave's staging ring (ENC_RING_DWORDS), `rtab` the workgroup's copy
+// of g_rans_rtab.  The words of a step go to the ring (256 slots + a 64-slot extension: a step never wraps); whenever
+// 128 words have gathered they leave with one coalesced 256-byte store to `out` (wave-uniform).  NT: the stores are
+// non-temporal (the stream is at its final place: nobody reads it again).
+// Returns the exact length in bytes of words + states (the head in front of `out` not counted); the 64 states follow
+// the words, then zeros up to a multiple of 16 (`out` is 16-byte aligned).
+template <bool NT>
+__device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const CountsStream& s, u32* tabmem, u16* const ring,
+                                                  const u32* rtab, int lane, u16* const out_v) {
+  typedef __attribute__((address_space(3))) u32* lds_u32w;
+  typedef __attribute__((address_space(3))) u16* lds_u16w;
+  constexpr int Tc = (int)LMC_COUNTS_T;
+  const u32 tab_addr = (u32)(size_t)(lds_u32w)tabmem;
+  const u32 rtab_addr = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(lds_u32w) const_cast<u32*>(rtab));
+  u32 x = s.active ? LMC_COUNTS_L : 0u;  // idle lanes stay at 0 and never emit
   u32 wcur = 0;  // wave-uniform word cursor
   const u32 ring_addr = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(lds_u16w)ring);
   const u64 full_exec = __builtin_amdgcn_read_exec();
-  LMC_GLOBAL u32* const out32 = (LMC_GLOBAL u32*)out;
-  u32 flushed = 0;  // words already in global memory (a multiple of 128), wave-uniform
-  // the words of a step go to the wave's LDS ring (256 slots + a 64-slot extension: a step never wraps); whenever
-  // 128 words have gathered they leave with one coalesced 256-byte store (k_encode.h: code_token)
+  u16* const out = reinterpret_cast<u16*>(uniform_ptr64(out_v));
+  u32 flushed = 0;     // words already in global memory (a multiple of 128), wave-uniform
   auto flush_ring = [&]() {
     if (wcur - flushed >= 128u) {
       wave_lds_fence();
@@ -251,7 +308,10 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
         const u32 over = wcur - flushed - 128u;  // < 64
         if ((u32)lane < over) ring[lane] = ring[ENC_RING_WORDS + lane];
       }
-      (out32 + (flushed >> 1))[lane] = (reinterpret_cast<const u32*>(ring) + ((flushed & (ENC_RING_WORDS - 1)) >> 1))[lane];
+      const u32 v = (reinterpret_cast<const u32*>(ring) + ((flushed & (ENC_RING_WORDS - 1)) >> 1))[lane];
+      LMC_GLOBAL u32* const dst = (LMC_GLOBAL u32*)out + (flushed >> 1) + lane;
+      if (NT) __builtin_nontemporal_store(v, dst);
+      else *dst = v;
       flushed += 128u;
     }
   };
@@ -290,232 +350,104 @@ __device__ __forceinline__ void encode_group_stream_counts(const EncodeArgs& a, 
     };
     u32 w[DPB], wn[DPB];
 #pragma unroll
-    for (int j = 0; j < DPB; j++) w[j] = active ? LMC_SYM_LAST_LOAD(symq + (long long)((NB - 1) * DPB + j) * a.C) : 0u;
-    if constexpr (LDSASM == 0) {
-      // plain form: loads and waits left to the compiler, the entry and its reciprocal fetched a token ahead
-      u32 e_n = entry_at(row_addr_cnt<NIB, 31>(w, col));
-      u32x2_t r_n = rtab_of(e_n);
-      for (int b = NB - 1; b >= 0; b--) {
+    for (int j = 0; j < DPB; j++) w[j] = s.active ? LMC_SYM_LAST_LOAD(s.symq + (long long)((NB - 1) * DPB + j) * a.C) : 0u;
+    // The table pipeline: the entry of a token is requested FOUR steps ahead, its reciprocal TWO (from an entry that
+    // landed two steps earlier), so the wait in front of a step's block covers requests that are two steps old and
+    // leaves the previous step's three LDS operations in flight.  The step's asm block works out the address of the
+    // reciprocal and appends the step's words -- under exec = emitting lanes: v_cmpx on the state's upper half against
+    // the entry's (count << 7), mbcnt rank, ds_write_b16 into the ring, x >>= 16, exec restored -- and the loads are
+    // plain loads the compiler tracks, issued right behind the block (behind the ring store in the LDS queue).
+    u32 E0 = entry_at(row_addr_cnt<NIB, 31>(w, col));
+    u32 E1 = entry_at(row_addr_cnt<NIB, 30>(w, col));
+    u32 E2 = entry_at(row_addr_cnt<NIB, 29>(w, col));
+    u32 E3 = entry_at(row_addr_cnt<NIB, 28>(w, col));
+    u32x2_t R0 = rtab_of(E0);
+    u32x2_t R1 = rtab_of(E1);
+    for (int b = NB - 1; b >= 0; b--) {
 #pragma unroll
-        for (int j = 0; j < DPB; j++) wn[j] = (b > 0 && active) ? LMC_SYM_LAST_LOAD(symq + (long long)((b - 1) * DPB + j) * a.C) : 0u;
-        static_for<32>([&](auto itag) {
-          constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
-          const u32 e = e_n;
-          const u32x2_t r = r_n;
-          if constexpr (i > 0) e_n = entry_at(row_addr_cnt<NIB, i - 1>(w, col));
-          else e_n = entry_at(row_addr_cnt<NIB, 31>(wn, col));  // after the last block: row 0, read and never used
-          r_n = rtab_of(e_n);
-          const u32 wbase = ring_addr + ((wcur & (ENC_RING_WORDS - 1)) << 1);  // scalar
-          u32 tt, cnt;
-          if constexpr (NIB) {
-            // emit <=> x >= count << 23: the state's upper half against the entry's upper half (count << 7)
-            asm volatile("v_cmpx_ge_u32_sdwa vcc, %[x], %[e] src0_sel:WORD_1 src1_sel:WORD_1\n\t"
-                         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                         "s_nop 0\n\t"
-                         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                         "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
-                         "ds_write_b16 %[t], %[x]\n\t"
-                         "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                         "s_mov_b64 exec, %[full]"
-                         : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt)
-                         : [e] "v"(e), [wb] "s"(wbase), [full] "s"(full_exec)
-                         : "vcc", "scc", "memory");
-          } else {
-            asm volatile("v_lshlrev_b32_sdwa %[t], 23, %[e] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-                         "v_cmpx_ge_u32_e32 vcc, %[x], %[t]\n\t"
-                         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                         "s_nop 0\n\t"
-                         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                         "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
-                         "ds_write_b16 %[t], %[x]\n\t"
-                         "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                         "s_mov_b64 exec, %[full]"
-                         : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt)
-                         : [e] "v"(e), [wb] "s"(wbase), [full] "s"(full_exec)
-                         : "vcc", "scc", "memory");
-          }
-          wcur += cnt;
-          flush_ring();
-          if constexpr (NIB) rans_put_nib(e, r.x, r.y);
-          else rans_put_byte(e, r.x, r.y);
-        });
+      for (int j = 0; j < DPB; j++) wn[j] = (b > 0 && s.active) ? LMC_SYM_LAST_LOAD(s.symq + (long long)((b - 1) * DPB + j) * a.C) : 0u;
+      static_for<32>([&](auto itag) {
+        constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
+        u32 ad4;  // row address of the token four further on (past the last block: row 0, read and never used)
+        if constexpr (i >= 4) ad4 = row_addr_cnt<NIB, i - 4>(w, col);
+        else ad4 = row_addr_cnt<NIB, 28 + i>(wn, col);
+        const u32 wbase = ring_addr + ((wcur & (ENC_RING_WORDS - 1)) << 1);  // scalar
+        u32 tt, cnt, ra;
+        if constexpr (NIB) {
+          asm volatile("v_lshrrev_b32_e32 %[ra], 20, %[e2]\n\t"
+                       "v_cmpx_ge_u32_sdwa vcc, %[x], %[e0] src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+                       "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                       "s_nop 0\n\t"
+                       "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                       "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                       "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
+                       "ds_write_b16 %[t], %[x]\n\t"
+                       "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                       "s_mov_b64 exec, %[full]"
+                       : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
+                       : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wbase), [full] "s"(full_exec)
+                       : "vcc", "scc", "memory");
+        } else {
+          asm volatile("v_lshlrev_b32_sdwa %[ra], 3, %[e2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                       "v_lshlrev_b32_sdwa %[t], 23, %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                       "v_cmpx_ge_u32_e32 vcc, %[x], %[t]\n\t"
+                       "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                       "s_nop 0\n\t"
+                       "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                       "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                       "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
+                       "ds_write_b16 %[t], %[x]\n\t"
+                       "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                       "s_mov_b64 exec, %[full]"
+                       : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
+                       : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wbase), [full] "s"(full_exec)
+                       : "vcc", "scc", "memory");
+        }
+        const u32x2_t R2 = *(const __attribute__((address_space(3))) u32x2_t*)(size_t)(rtab_addr + ra);
+        const u32 E4 = entry_at(ad4);
+        wcur += cnt;
+        flush_ring();
+        if constexpr (NIB) rans_put_nib(E0, R0.x, R0.y);
+        else rans_put_byte(E0, R0.x, R0.y);
+        E0 = E1; E1 = E2; E2 = E3; E3 = E4;
+        R0 = R1; R1 = R2;
+      });
 #pragma unroll
-        for (int j = 0; j < DPB; j++) w[j] = wn[j];
-      }
-    } else if constexpr (LDSASM == 2) {
-      // Deep form of the pipeline below: the entry of a token is requested FOUR steps ahead, its reciprocal TWO (from
-      // an entry that landed two steps earlier), so the wait in front of a step's block covers requests that are two
-      // steps old and leaves the previous step's three LDS operations in flight.  The one-step distance of the form
-      // below is enough at 8 waves per SIMD; in the fused kernel the coding waves share their CU with workgroups that
-      // fetch (k_cdf_encode at half occupancy: +28 %), and there the extra distance is what hides the LDS latency.
-      u32 E0 = entry_at(row_addr_cnt<NIB, 31>(w, col));
-      u32 E1 = entry_at(row_addr_cnt<NIB, 30>(w, col));
-      u32 E2 = entry_at(row_addr_cnt<NIB, 29>(w, col));
-      u32 E3 = entry_at(row_addr_cnt<NIB, 28>(w, col));
-      u32x2_t R0 = rtab_of(E0);
-      u32x2_t R1 = rtab_of(E1);
-      for (int b = NB - 1; b >= 0; b--) {
-#pragma unroll
-        for (int j = 0; j < DPB; j++) wn[j] = (b > 0 && active) ? LMC_SYM_LAST_LOAD(symq + (long long)((b - 1) * DPB + j) * a.C) : 0u;
-        static_for<32>([&](auto itag) {
-          constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
-          u32 ad4;  // row address of the token four further on (past the last block: row 0, read and never used)
-          if constexpr (i >= 4) ad4 = row_addr_cnt<NIB, i - 4>(w, col);
-          else ad4 = row_addr_cnt<NIB, 28 + i>(wn, col);
-          const u32 wbase = ring_addr + ((wcur & (ENC_RING_WORDS - 1)) << 1);  // scalar
-          u32 tt, cnt, ra;
-          if constexpr (NIB) {
-            asm volatile("v_lshrrev_b32_e32 %[ra], 20, %[e2]\n\t"
-                         "v_cmpx_ge_u32_sdwa vcc, %[x], %[e0] src0_sel:WORD_1 src1_sel:WORD_1\n\t"
-                         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                         "s_nop 0\n\t"
-                         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                         "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
-                         "ds_write_b16 %[t], %[x]\n\t"
-                         "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                         "s_mov_b64 exec, %[full]"
-                         : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
-                         : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wbase), [full] "s"(full_exec)
-                         : "vcc", "scc", "memory");
-          } else {
-            asm volatile("v_lshlrev_b32_sdwa %[ra], 3, %[e2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-                         "v_lshlrev_b32_sdwa %[t], 23, %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-                         "v_cmpx_ge_u32_e32 vcc, %[x], %[t]\n\t"
-                         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                         "s_nop 0\n\t"
-                         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                         "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
-                         "ds_write_b16 %[t], %[x]\n\t"
-                         "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                         "s_mov_b64 exec, %[full]"
-                         : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
-                         : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wbase), [full] "s"(full_exec)
-                         : "vcc", "scc", "memory");
-          }
-          const u32x2_t R2 = *(const __attribute__((address_space(3))) u32x2_t*)(size_t)(rtab_addr + ra);
-          const u32 E4 = entry_at(ad4);
-          wcur += cnt;
-          flush_ring();
-          if constexpr (NIB) rans_put_nib(E0, R0.x, R0.y);
-          else rans_put_byte(E0, R0.x, R0.y);
-          E0 = E1; E1 = E2; E2 = E3; E3 = E4;
-          R0 = R1; R1 = R2;
-        });
-#pragma unroll
-        for (int j = 0; j < DPB; j++) w[j] = wn[j];
-      }
-    } else {
-      // Pipelined form.  On entry to a step: E0 = entry of the token to code, R0 = its reciprocal, E1 = entry of the
-      // next token -- requested one (R0, E1) and two (E0) steps ago.  The step's first asm block works out the address
-      // of E1's reciprocal (so the wait for E1 sits in FRONT of the block, where everything outstanding is a step
-      // old) and appends the step's words; R1 = rtab[E1] and E2 = the entry of the token after next are requested
-      // right behind it -- behind the ring store in the LDS queue, so the wait for them at the top of the next step
-      // never waits for that store on its own account -- then the state update runs on E0 / R0.  All of the reads
-      // are plain loads the compiler tracks.
-      u32 E0 = entry_at(row_addr_cnt<NIB, 31>(w, col));
-      u32 E1 = entry_at(row_addr_cnt<NIB, 30>(w, col));
-      u32x2_t R0 = rtab_of(E0);
-      for (int b = NB - 1; b >= 0; b--) {
-#pragma unroll
-        for (int j = 0; j < DPB; j++) wn[j] = (b > 0 && active) ? LMC_SYM_LAST_LOAD(symq + (long long)((b - 1) * DPB + j) * a.C) : 0u;
-        static_for<32>([&](auto itag) {
-          constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
-          u32 ad2;  // row address of the token after next (past the last block: row 0, read and never used)
-          if constexpr (i >= 2) ad2 = row_addr_cnt<NIB, i - 2>(w, col);
-          else ad2 = row_addr_cnt<NIB, 30 + i>(wn, col);
-          const u32 wbase = ring_addr + ((wcur & (ENC_RING_WORDS - 1)) << 1);  // scalar
-          u32 tt, cnt, ra;
-          if constexpr (NIB) {
-            asm volatile("v_lshrrev_b32_e32 %[ra], 20, %[e1]\n\t"
-                         "v_cmpx_ge_u32_sdwa vcc, %[x], %[e0] src0_sel:WORD_1 src1_sel:WORD_1\n\t"
-                         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                         "s_nop 0\n\t"
-                         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                         "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
-                         "ds_write_b16 %[t], %[x]\n\t"
-                         "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                         "s_mov_b64 exec, %[full]"
-                         : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
-                         : [e0] "v"(E0), [e1] "v"(E1), [wb] "s"(wbase), [full] "s"(full_exec)
-                         : "vcc", "scc", "memory");
-          } else {
-            asm volatile("v_lshlrev_b32_sdwa %[ra], 3, %[e1] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-                         "v_lshlrev_b32_sdwa %[t], 23, %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-                         "v_cmpx_ge_u32_e32 vcc, %[x], %[t]\n\t"
-                         "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                         "s_nop 0\n\t"
-                         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                         "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
-                         "ds_write_b16 %[t], %[x]\n\t"
-                         "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                         "s_mov_b64 exec, %[full]"
-                         : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
-                         : [e0] "v"(E0), [e1] "v"(E1), [wb] "s"(wbase), [full] "s"(full_exec)
-                         : "vcc", "scc", "memory");
-          }
-          const u32x2_t R1 = *(const __attribute__((address_space(3))) u32x2_t*)(size_t)(rtab_addr + ra);
-          const u32 E2 = entry_at(ad2);
-          wcur += cnt;
-          flush_ring();
-          if constexpr (NIB) rans_put_nib(E0, R0.x, R0.y);
-          else rans_put_byte(E0, R0.x, R0.y);
-          E0 = E1;
-          E1 = E2;
-          R0 = R1;
-        });
-#pragma unroll
-        for (int j = 0; j < DPB; j++) w[j] = wn[j];
-      }
+      for (int j = 0; j < DPB; j++) w[j] = wn[j];
     }
   };
-  if (nib) pass2(BoolTag<true>{});
+  if (s.nib) pass2(BoolTag<true>{});
   else pass2(BoolTag<false>{});
-#if LMC_EXP_TWICE & 4  // timing experiment: the coding pass a second time (same stream)
-  wave_lds_fence();
-  x = active ? LMC_COUNTS_L : 0u;
-  wcur = 0;
-  flushed = 0;
-  asm volatile("" : "+v"(x), "+s"(wcur), "+s"(flushed) : : "memory");
-  if (nib) pass2(BoolTag<true>{});
-  else pass2(BoolTag<false>{});
-#endif
-  x = active ? x : LMC_COUNTS_L;  // idle lanes (channel >= C) carry the initial state
+  x = s.active ? x : LMC_COUNTS_L;  // idle lanes (channel >= C) carry the initial state
   // the words still in the ring (< 128 + 64)
   wave_lds_fence();
   for (u32 k = flushed + lane; k < wcur; k += 64) out[k] = ring[k & (ENC_RING_WORDS - 1)];
-  // tail: states, pad, length
+  // tail: states, pad
   out[wcur + 2 * lane] = (u16)x;
   out[wcur + 2 * lane + 1] = (u16)(x >> 16);
   wcur += 128;
   const u32 exact = wcur * 2;
   const u32 padw = ((16u - (exact & 15u)) & 15u) >> 1;
   if ((u32)lane < padw) out[wcur + lane] = 0;
-  if (lane == 0 && exact + 16 > a.cap) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);
-  t.chunk = chunk; t.pg = p * a.G + g; t.exact = exact; t.T = (u32)Tc; t.out = out;
+  return exact;
 }
 
-// ---- the two-kernel path's coder launch: one wave per group stream, NW streams per workgroup ----------------
+// ---- the two-kernel path's coder launch: one wave per group stream, NW consecutive streams per workgroup ----------
 // <.., ENC_WAVES, false>: any chunk length (CDF16 or counts per stream), 4 waves and 21.5 KB of LDS per workgroup:
 //     7 workgroups = 28 waves per CU.
 // <.., 8, true>: launches whose chunks are all 256 tokens long (the counts model only: 4 KiB tables, one 2 KiB
 //     reciprocal table shared by 8 waves): 39.9 KB per workgroup, 4 workgroups = 32 waves per CU -- the coder's time
 //     falls with every wave there is to interleave.
+// Every stream is coded into its scratch slot and placed afterwards: the allocations (lmc_format.h, v6 -- the bound for
+// a counts stream, the exact length for a CDF16 one) are prefix-summed over the chunk by a single-pass look-back, one
+// granule per workgroup.  (The fused kernel, k_fused.h, runs the look-back between the two passes and codes straight
+// into the blob.)
 template <bool QUADSYM, bool ENCODE, int NW = ENC_WAVES, bool COUNTS_ONLY = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 8 : 4, 8))) void k_cdf_encode(EncodeArgs a) {
   static_assert(!COUNTS_ONLY || (QUADSYM && ENCODE), "the counts coder reads the workspace and places its streams");
   constexpr int TAB_DWORDS = COUNTS_ONLY ? CNT_TAB_DWORDS : ENC_TAB_DWORDS;
   __shared__ __attribute__((aligned(16))) u32 lds_all[NW * (ENC_RING_DWORDS + TAB_DWORDS)];  // the staging rings, then the tables
-  __shared__ __attribute__((aligned(16))) u32 rtab_lds[ENCODE ? RTAB_DWORDS : 4];         // counts model: reciprocals
-#ifdef LMC_EXP_CDF_LDS_PAD  // timing experiment: fewer workgroups per CU (occupancy sweep of the coder)
-  __shared__ u32 lds_pad[LMC_EXP_CDF_LDS_PAD];
-  if (threadIdx.x == 0 && a.nchunks < 0) lds_pad[a.P] = 1;
-#endif
+  __shared__ __attribute__((aligned(16))) u32 rtab_lds[ENCODE ? RTAB_LDS_DWORDS : 4];     // counts model: reciprocals, bound table
   if (ENCODE && QUADSYM) {
     rtab_to_lds(rtab_lds);
     __syncthreads();
@@ -544,38 +476,51 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
   if (gid >= ngroups_total) return;
   PendingTile t;
   u16* const wring = reinterpret_cast<u16*>(lds_all + wave * (ENC_RING_DWORDS));
+  u32 alloc = 0;  // the stream's allocation in the blob
+  auto counts_stream = [&]() {
+    const CountsStream s = counts_stream_of(a, gid, lane);
+    CountsState cs;
+    alloc = counts_hist_stream(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
+    u8* const slot = a.scratch + gid * (long long)a.cap;
+    counts_open_stream(s, cs, slot, hist, lane);
+    t.exact = cs.head + counts_code_stream<false>(a, s, hist, wring, rtab_lds, lane, reinterpret_cast<u16*>(slot + cs.head));
+    t.chunk = s.chunk; t.pg = s.p * a.G + s.g; t.T = LMC_COUNTS_T; t.out = reinterpret_cast<const u16*>(slot);
+    if (lane == 0 && (t.exact > alloc || t.exact + 16 > a.cap)) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);
+  };
   if constexpr (COUNTS_ONLY) {
-    encode_group_stream_counts<LMC_COUNTS_LDSASM>(a, gid, hist, wring, rtab_lds, lane, t);
+    counts_stream();
   } else if constexpr (ENCODE && QUADSYM) {
     // 256-token chunks are coded on their symbol counts (LMC_MODEL_COUNTS), every other length on the 16-bit CDF
     const int chunk_of = (int)(gid / ((long long)a.P * a.G));
     const bool counts_model =
         min(a.chunk_tokens, a.tok_end - (a.tok_begin + chunk_of * a.chunk_tokens)) == (int)LMC_COUNTS_T;  // wave-uniform
-    if (counts_model) encode_group_stream_counts<LMC_COUNTS_LDSASM>(a, gid, hist, wring, rtab_lds, lane, t);
-    else encode_group_stream<QUADSYM, ENCODE>(a, gid, hist, wring, lane, t);
+    if (counts_model) counts_stream();
+    else {
+      encode_group_stream<QUADSYM, ENCODE>(a, gid, hist, wring, lane, t);
+      alloc = (t.exact + 15u) & ~15u;
+    }
   } else {
     encode_group_stream<QUADSYM, ENCODE>(a, gid, hist, wring, lane, t);
+    alloc = (t.exact + 15u) & ~15u;
   }
   if (!ENCODE) return;
-  // ---- compaction: where does this stream go? ------------------------------------------------------------
+  // ---- placement: where does this stream go? ------------------------------------------------------------
   const int n = a.P * a.G;
   const int chunk = t.chunk;
-  const u32 padded = (t.exact + 15u) & ~15u;
   unsigned long long* agg = a.agg + (long long)chunk * n;
   if (n % NW == 0) {
-    // The waves of a workgroup hold consecutive streams of one chunk: they add their lengths up in LDS and
+    // The waves of a workgroup hold consecutive streams of one chunk: they add their allocations up in LDS and
     // ONE wave runs the look-back over workgroup-level granules -- 1/NW of the granules, and of the
     // walk when a whole chunk finishes at once and nobody has an inclusive prefix yet.
-    __shared__ u32 wg_len[NW];
+    __shared__ u32 wg_alloc[NW];
     __shared__ u32 wg_excl;
-    if (lane == 0) wg_len[wave] = padded;
+    if (lane == 0) wg_alloc[wave] = alloc;
     __syncthreads();
-    u32 intra = 0, wg_total = 0;
+    u32 before = 0, wg_total = 0;
 #pragma unroll
     for (int w = 0; w < NW; w++) {
-      const u32 l = wg_len[w];
-      intra += w < wave ? l : 0u;
-      wg_total += l;
+      before += w < wave ? wg_alloc[w] : 0u;
+      wg_total += wg_alloc[w];
     }
     if (wave == 0) {
       const int wgi = t.pg / NW;
@@ -587,12 +532,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
       }
     }
     __syncthreads();
-    place_stream(a, t, wg_excl + intra, hist, lane);
+    place_stream(a, t, wg_excl + before, alloc, wg_excl + wg_total, hist, lane);
   } else {
     // streams of a chunk do not fill whole workgroups: every wave publishes and looks back for itself
-    if (lane == 0 && t.pg > 0) agg_store(agg + t.pg, AGG_A, padded);
+    if (lane == 0 && t.pg > 0) agg_store(agg + t.pg, AGG_A, alloc);
     const u32 excl = lookback_exclusive(agg, t.pg, lane, a.status);
-    if (lane == 0) agg_store(agg + t.pg, AGG_P, excl + padded);
-    place_stream(a, t, excl, hist, lane);
+    if (lane == 0) agg_store(agg + t.pg, AGG_P, excl + alloc);
+    place_stream(a, t, excl, alloc, excl + alloc, hist, lane);
   }
 }

@@ -1,19 +1,22 @@
 // k_fused.h -- the whole encode of a (chunk, plane) in ONE workgroup: quantise, then code (rows a5-a11).
 //
 // The two-kernel encode (k_quantize, then k_cdf_encode) runs an HBM-bound phase and a VALU-bound phase one after
-// the other.  Here a workgroup of FUSED_WAVES waves owns one plane-chunk from the raw KV to the placed streams:
-//   phase A  its waves quantise the plane-chunk's row octs (quantize_oct_fused, a wave = 8 token rows x all
-//            channels: the row max never leaves the wave), symbols to the plane-chunk's workspace region, scales
-//            to the blob;
-//   barrier  (workgroup scope is enough: the region is written and read by waves of one CU)
-//   phase B  wave w codes the group streams w, w + FUSED_WAVES, ... exactly as k_cdf_encode does
-//            (encode_group_stream_counts: histogram, counts, table, interleaved rANS on the counts model -- this
-//            kernel takes 256-token chunks only, lmc_api.hip hands a ragged last chunk to the two-kernel path) --
-//            the symbols come back from L2;
-//   placement: ONE look-back per plane-chunk over P granules per chunk, then every wave moves its own streams.
-// Several workgroups share a CU (4.6 KiB of LDS per wave + 2 KiB of reciprocals, <= 64 VGPRs: 8 waves per SIMD) and are in different
-// phases at any time, so the loads of one hide under the coding of the others.  Blobs are byte-identical to the
-// two-kernel path (same device functions; tests/test_gpu_parity.py runs both).
+// the other.  Here a workgroup of FUSED_WAVES waves owns one plane-chunk from the raw KV to the streams in the blob:
+//   phase A   its waves quantise the plane-chunk's row octs (quantize_oct_fused, a wave = 8 token rows x all
+//             channels: the row max never leaves the wave), symbols to the plane-chunk's workspace region, scales
+//             to the blob;
+//   barrier   (workgroup scope is enough: the region is written and read by waves of one CU)
+//   pass 1    wave w takes the histograms of the group streams w, w + FUSED_WAVES (counts_hist_stream): the counts stay
+//             in its registers, and every stream's ALLOCATION in the blob follows from them (lmc_format.h, v6: an
+//             upper bound of its length);
+//   placement ONE look-back per plane-chunk over P granules per chunk on the sum of the allocations: every stream of
+//             the plane-chunk knows its final place BEFORE it is coded;
+//   pass 2    head, table, interleaved rANS (counts_open_stream, counts_code_stream) -- the symbols come back from L2,
+//             the words leave in 256-byte pieces for the blob itself.  No stream scratch, no second placement pass
+//             (v5 wrote every stream three times and read it twice: 1 GB of fabric traffic per 16 k context).
+// Several workgroups share a CU (4.6 KiB of LDS per wave + 2.5 KiB of reciprocals and bound table, <= 64 VGPRs: 8
+// waves per SIMD) and are in different phases at any time, so the loads of one hide under the coding of the others.
+// Blobs are byte-identical to the two-kernel path (same device functions; tests/test_gpu_parity.py runs both).
 //
 // The look-back granules carry the launch's epoch (flag << 62 | epoch << 32 | value): a granule of another
 // launch reads as "not published", so nothing has to zero them between jobs.
@@ -28,21 +31,12 @@
 #ifndef FUSED_WAVES
 #define FUSED_WAVES 8  // waves per workgroup: 4 workgroups per CU
 #endif
-// Cache policy of the fused encode's streams.  The symbol workspace and the stream scratch are written and read back
-// within a workgroup's life, and 1024 workgroups' worth of them (~300 MB) is about what L2 + Infinity Cache hold --
-// so everything that is touched ONCE says so: the raw KV is loaded non-temporal (LMC_FUSED_NT_IN), the placed streams
-// are stored non-temporal (LMC_PLACE_NT_OUT, k_encode.h), the coding pass reads its symbols for the last time
-// non-temporal (LMC_SYM_NT, k_encode_counts.h).  Same box, alternating processes: 1.017-1.027 ms without, 0.982-0.988
-// with the first, 0.968-0.975 with all three; a non-temporal re-read of the scratch slot on top changes nothing.
-#ifndef LMC_FUSED_NT_IN
-#define LMC_FUSED_NT_IN 1
-#endif
-#ifndef LMC_FUSED_PRIO_A
-#define LMC_FUSED_PRIO_A 3  // wave priority while a wave fetches / quantises (phase A) ...
-#endif
-#ifndef LMC_FUSED_PRIO_B
-#define LMC_FUSED_PRIO_B 0  // ... and while it codes (phase B)
-#endif
+// Cache policy.  The symbol workspace is written and read back within a workgroup's life, and 1024 workgroups' worth
+// of it is what L2 + Infinity Cache should hold -- so everything that is touched ONCE says so: the raw KV is loaded
+// non-temporal, the streams are stored non-temporal (counts_code_stream<true>), the coding pass reads its symbols for
+// the last time non-temporal (LMC_SYM_LAST_LOAD, k_encode_counts.h).  Round 3, same box, alternating processes:
+// 1.017-1.027 ms without, 0.968-0.975 with.
+#define LMC_FUSED_PRIO_A 3  // wave priority while a wave fetches / quantises (phase A): its few instructions go first
 
 struct FusedArgs {
   KvAddr src;
@@ -50,14 +44,6 @@ struct FusedArgs {
   u8* scale_base;
   long long scale_stride;
   u32 epoch;  // 1 .. 2^30 - 1
-  // Head start (an experiment that did NOT pay; off by default, LMC_FUSED_PRE_STEP=n switches it on).  Doubling phase A
-  // costs a whole k_quantize (+0.44 ms), as if the phases of different workgroups never overlapped; the hypothesis
-  // was lock-step generations (every CU fetches, then every CU codes).  Here the plane-chunks of every `pre_step`-th
-  // workgroup below `pre_limit` (the first generation) are quantised by a k_quantize launch in front of this kernel,
-  // so that those workgroups start coding at once and the generations run out of phase.  Measured: 1.056 ms
-  // without, 1.064-1.09 ms with pre_step 4 / 2 / 3 / 1 -- the phases were not in lock-step; what the fetch phase
-  // costs is the wave slots its waves hold while they wait.
-  u32 pre_limit, pre_step;
   // Staggered start (lmc_api.hip: 50 us, LMC_FUSED_STAGGER_US): every workgroup of a launch takes the same time, so
   // the four workgroups a CU holds tend to run their phases in lock-step for the whole launch -- all fetch (HBM busy,
   // VALU idle), then all code (VALU busy, HBM idle).  A first-generation workgroup (ticket < stagger_limit) draws its
@@ -138,18 +124,10 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
       for (int r = 0; r < 2; r++) {
         const int t = t_first + 4 * hq + r0 + r;
         tv[r] = t < Tc;
-#if LMC_EXP_TWICE & 16  // timing experiment: every row is the chunk's first row (L2 hits instead of HBM reads)
-        const u16* rowp = pbase + (tv[r] ? lmc_tok_off(src, tok0 + (t & 7)) : 0);
-#else
         const u16* rowp = pbase + (tv[r] ? lmc_tok_off(src, tok0 + t) : 0);
-#endif
 #pragma unroll
         for (int it = 0; it < NITER; it++) {
-#if LMC_FUSED_NT_IN
-          if (tv[r] && (FULL || cval[it])) v[r][it] = ld_global_u4_nt(rowp + coff[it]);
-#else
-          if (tv[r] && (FULL || cval[it])) v[r][it] = ld_global_u4(rowp + coff[it]);
-#endif
+          if (tv[r] && (FULL || cval[it])) v[r][it] = ld_global_u4_nt(rowp + coff[it]);  // streamed once
           else v[r][it] = make_uint4(0, 0, 0, 0);
         }
       }
@@ -245,10 +223,11 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
 
 template <int NITER, int DT, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_fused(FusedArgs fa) {
+  static_assert(FUSED_MAX_G <= 2 * NW, "a wave takes at most two streams");
   const EncodeArgs& a = fa.e;
   __shared__ __attribute__((aligned(16))) u32 lds_all[NW * (ENC_RING_DWORDS + CNT_TAB_DWORDS)];  // the staging rings, then the tables
-  __shared__ __attribute__((aligned(16))) u32 rtab_lds[RTAB_DWORDS];  // reciprocals of the counts model's frequencies
-  __shared__ u32 st_len[FUSED_MAX_G];  // exact byte length of the plane-chunk's group streams
+  __shared__ __attribute__((aligned(16))) u32 rtab_lds[RTAB_LDS_DWORDS];  // reciprocals of the counts model's frequencies, bound table
+  __shared__ u32 st_alloc[FUSED_MAX_G];  // allocation of the plane-chunk's group streams
   __shared__ u32 wg_excl;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -258,7 +237,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   const u32 item = (u32)__builtin_amdgcn_readfirstlane((int)draw_ticket(a.ticket, a.ticket_base));
   const int chunk = (int)(item % (unsigned)a.nchunks), p = (int)(item / (unsigned)a.nchunks);
   const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
-  const int Tc = min(a.chunk_tokens, a.tok_end - tok0);
+  constexpr int Tc = (int)LMC_COUNTS_T;  // lmc_api.hip hands this kernel full 256-token chunks only
   u32* const hist = lds_all + NW * ENC_RING_DWORDS + wave * CNT_TAB_DWORDS;  // this wave's table slice ...
   u16* const ring = reinterpret_cast<u16*>(lds_all + wave * ENC_RING_DWORDS);  // ... and staging ring
 
@@ -277,24 +256,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     while ((u32)__builtin_amdgcn_s_memrealtime() - t0 < hold) __builtin_amdgcn_s_sleep(32);
   }
   // ---- phase A: quantise the plane-chunk ----------------------------------------------------------------
-  const bool head_start = item < fa.pre_limit && item % fa.pre_step == 0u;  // quantised by k_quantize already
-  if (!head_start) {
+  {
     const int bins = (int)a.bins.b[p];
     const float maxf = (float)(bins / 2 - 1);
     const bool nib = lmc_sym_nibbles(bins);
     const bool full = a.C == NITER * 512;  // no absent channels: the variant without per-lane validity
     u32* const sym_pc = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.sym_stride;
     u16* const scl = reinterpret_cast<u16*>(fa.scale_base + (long long)chunk * fa.scale_stride) + (long long)p * Tc;
-    const int TO = (Tc + 7) >> 3;
+    constexpr int TO = (Tc + 7) >> 3;
     const u16* const pbase = lmc_plane_base(fa.src, p);
-    uint4* const park = reinterpret_cast<uint4*>(hist);  // the wave's table slice is idle until phase B
+    uint4* const park = reinterpret_cast<uint4*>(hist);  // the wave's table slice is idle until pass 1
     // Waves that fetch run at raised priority: their (few) instructions go first, so the loads are out early and
     // return under the other workgroups' coding.
     __builtin_amdgcn_s_setprio(LMC_FUSED_PRIO_A);
-#if LMC_EXP_TWICE & 1
-#pragma unroll 1
-    for (int rep = 0; rep < 2; rep++)
-#endif
 #pragma unroll 1
     for (int oct = wave; oct < TO; oct += NW) {
       const bool q1valid = 2 * oct + 1 < a.TQ;
@@ -312,61 +286,65 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         quantize_oct_fused<NITER, DT, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
                                              sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
     }
-    __builtin_amdgcn_s_setprio(LMC_FUSED_PRIO_B);
+    __builtin_amdgcn_s_setprio(0);
   }
   __syncthreads();  // symbols and scales of the plane-chunk are visible to the workgroup
-#if LMC_EXP_TWICE & 128  // timing experiment: phase A only
-  return;
-#endif
 
-  // ---- phase B: code this wave's group streams -----------------------------------------------------------
+  // ---- pass 1: the counts of this wave's group streams, and from them the streams' allocations ----------------
   const long long gid0 = ((long long)chunk * a.P + p) * a.G;
-#pragma unroll 1
-  for (int g = wave; g < a.G; g += NW) {
-    PendingTile t;
-    encode_group_stream_counts<LMC_COUNTS_LDSASM>(a, gid0 + g, hist, ring, rtab_lds, lane, t);
-    if (lane == 0) st_len[g] = t.exact;
-    wave_lds_fence();  // the next stream reuses this wave's LDS slices
-  }
+  CountsState cs0, cs1;  // of stream `wave`, and of stream `wave + NW`
+  auto pass1 = [&](int g, CountsState& cs) {
+    if (g < a.G) {  // wave-uniform
+      const CountsStream s = counts_stream_of(a, gid0 + g, lane);
+      const u32 alloc = counts_hist_stream(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
+      if (lane == 0) st_alloc[g] = alloc;
+    }
+  };
+  pass1(wave, cs0);
+  pass1(wave + NW, cs1);
   __syncthreads();
 
-  // ---- placement: one look-back per plane-chunk --------------------------------------------------------------
+  // ---- placement: one look-back per plane-chunk, BEFORE the streams are coded --------------------------------
   u32 wg_total = 0;
-  for (int g = 0; g < a.G; g++) wg_total += (st_len[g] + 15u) & ~15u;
+  for (int g = 0; g < a.G; g++) wg_total += st_alloc[g];
   if (wave == 0) {
     unsigned long long* agg = a.agg + (long long)chunk * a.P;
     if (lane == 0 && p > 0) aggE_store(agg + p, AGG_A, fa.epoch, wg_total);
-#if LMC_EXP_TWICE & 256  // timing experiment: no look-back (the streams land at offset 0 of their chunk: blobs are wrong)
-    const u32 e = 0;
-#else
     const u32 e = lookback_exclusive_epoch(agg, p, fa.epoch, lane, a.status);
-#endif
     if (lane == 0) {
       aggE_store(agg + p, AGG_P, fa.epoch, e + wg_total);
       wg_excl = e;
     }
   }
   __syncthreads();
-#pragma unroll 1
-  for (int g = wave; g < a.G; g += NW) {
-    u32 intra = 0;
-    for (int k = 0; k < g; k++) intra += (st_len[k] + 15u) & ~15u;
-    PendingTile t;
-    t.chunk = chunk; t.pg = p * a.G + g; t.exact = st_len[g]; t.T = (u32)Tc;
-#if LMC_EXP_TWICE & 64
-    t.out = reinterpret_cast<const u16*>(a.scratch + ((gid0 + g) % 256) * (long long)a.cap);
-#else
-    t.out = reinterpret_cast<const u16*>(a.scratch + (gid0 + g) * (long long)a.cap);
-#endif
-#if !(LMC_EXP_TWICE & 8)
-    place_stream<false>(a, t, wg_excl + intra, hist, lane);
-#endif
-  }
-  // The chunk's last plane knows the chunk's size: header, static sections, size word (kept out of the stream loop:
-  // inlined there, its loop invariants were hoisted over the loop and spilled by every wave).
-  if (p == a.P - 1 && wave == 0) {
-    const BlobOff bo = lmc_blob_off((u32)a.P, (u32)Tc, (u32)a.C, (u32)a.G, (u32)a.bins.rowpre[a.P]);
-    u8* blob = a.blobs + (long long)chunk * a.blob_stride;
+
+  // ---- pass 2: every stream is coded at its final place -----------------------------------------------------------
+  const BlobOff bo = lmc_blob_off((u32)a.P, (u32)Tc, (u32)a.G);
+  u8* const blob = a.blobs + (long long)chunk * a.blob_stride;
+  auto pass2 = [&](int g, const CountsState& cs) {
+    if (g < a.G) {
+      u32 beg = wg_excl;
+      for (int j = 0; j < g; j++) beg += st_alloc[j];
+      const u32 alloc = st_alloc[g];
+      const CountsStream s = counts_stream_of(a, gid0 + g, lane);
+      u8* const out = blob + bo.streams + beg;
+      counts_open_stream(s, cs, out, hist, lane);
+      const u32 exact = cs.head + counts_code_stream<true>(a, s, hist, ring, rtab_lds, lane, reinterpret_cast<u16*>(out + cs.head));
+      const u32 padded = (exact + 15u) & ~15u;
+      if (alloc > padded) zero_fill16(out + padded, alloc - padded, lane);
+      if (lane == 0) {
+        u32* d = reinterpret_cast<u32*>(blob + bo.gdir) + 2 * (p * a.G + g);
+        d[0] = beg;
+        d[1] = beg + exact;
+        if (exact > alloc) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);  // the bound is a theorem: never
+      }
+      wave_lds_fence();  // the next stream reuses this wave's LDS slices
+    }
+  };
+  pass2(wave, cs0);
+  pass2(wave + NW, cs1);
+  // The chunk's last plane knows the chunk's size: header, static sections, size word.
+  if (p == a.P - 1 && wave == NW - 1) {
     write_blob_static(blob, bo, a, (u32)Tc, wg_excl + wg_total, lane);
     if (lane == 0) a.sizes[chunk] = bo.streams + wg_excl + wg_total;
   }

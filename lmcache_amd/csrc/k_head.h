@@ -1,0 +1,149 @@
+// k_head.h -- the head of a group stream (include/lmc_format.h, v6): the symbol counts of the stream's 64 channels,
+// bit-sliced.  Takes the place of the container's [2L, C, 33] `cdf` tensor (cachegen_basics.py:109-142,
+// cachegen_encoder.py:287-290): a channel's CDF is a function of its counts (lmc_device.h: cdf_column_to_lds).
+//
+//   widths u8[R8] | planes u64[W] | zeros to 16 B        R8 = R rounded up to 8, W = sum of the widths
+//
+// A plane is one bit of one symbol's stored count across the 64 lanes -- what a wave64 produces with one ballot and
+// takes apart again by testing bit `lane`; widths[i] is wave-uniform (an OR over the lanes), so every loop below runs
+// on scalar trip counts.
+#pragma once
+#include "lmc_device.h"
+
+// v_writelane_b32: lane `sel` of `old` <- the wave-uniform `val`.  Data and lane select are both scalar operands and
+// gfx9 reads one SGPR per VALU instruction, so the select travels in M0 (saved and restored: the compiler keeps its own
+// values there, e.g. the LDS base of global_load_lds); the s_nop covers the wait states a lane select needs behind a
+// write of its register (the compiler does not look inside the block).
+__device__ __forceinline__ int writelane_i32(int val, u32 sel, int old) {
+  u32 keep;
+  asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+      : "+v"(old), "=&s"(keep)
+      : "s"(__builtin_amdgcn_readfirstlane(val)), "s"(__builtin_amdgcn_readfirstlane((int)sel)));
+  return old;
+}
+__device__ __forceinline__ void writelane2_i32(u64 val, u32 sel, int& lo, int& hi) {
+  u32 keep;
+  asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\ts_nop 3\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\t"
+      "s_mov_b32 m0, %2"
+      : "+v"(lo), "+v"(hi), "=&s"(keep)
+      : "s"(__builtin_amdgcn_readfirstlane((int)(u32)val)), "s"(__builtin_amdgcn_readfirstlane((int)(u32)(val >> 32))),
+        "s"(__builtin_amdgcn_readfirstlane((int)sel)));
+}
+
+// Significant bits of the wave-uniform value v (0 for 0).
+__device__ __forceinline__ u32 bit_width_u32(u32 v) { return v ? 32u - (u32)__builtin_clz(v) : 0u; }
+
+// The widths of the symbols' fields from the lanes' stored counts, packed FB bits per field in pk[0 .. NREG) (symbol i
+// = field i % (32 / FB) of pk[i / (32 / FB)]): wor[k] = OR over the lanes of pk[k] (wave-uniform), from which
+// field_width() reads a symbol's width.
+template <int NREG>
+__device__ __forceinline__ void head_or_counts(const u32 (&pk)[NREG], u32 (&wor)[NREG]) {
+  static_assert(NREG % 2 == 0, "pairs");
+#pragma unroll
+  for (int k = 0; k < NREG; k += 2) {
+    u32 a = pk[k], b = pk[k + 1];
+    wave_or2_u32(a, b);
+    wor[k] = a;
+    wor[k + 1] = b;
+  }
+}
+template <int FB, int NREG>
+__device__ __forceinline__ u32 field_width(const u32 (&wor)[NREG], int i) {
+  constexpr int PER = 32 / FB;
+  return bit_width_u32((wor[i / PER] >> (FB * (i % PER))) & ((1u << FB) - 1u));
+}
+// Bytes of the head of a plane with R symbols whose counts OR to `wor` (lmc_head_bytes).
+template <int FB, int NREG>
+__device__ __forceinline__ u32 head_bytes_of(const u32 (&wor)[NREG], u32 R) {
+  u32 W = 0;
+  static_for<NREG * (32 / FB)>([&](auto itag) {
+    constexpr int i = decltype(itag)::value;
+    if ((u32)i < R) W += field_width<FB, NREG>(wor, i);
+  });
+  return (((R + 7u) & ~7u) + 8u * W + 15u) & ~15u;
+}
+
+// Write the head to `out` (16-byte aligned, wave-uniform); returns its size.  pk: this lane's stored counts (0 for a
+// lane without a channel), wor: their OR over the lanes (head_or_counts).
+template <int FB, int NREG>
+__device__ __forceinline__ u32 head_write(u8* out_v, const u32 (&pk)[NREG], const u32 (&wor)[NREG], u32 R, int lane) {
+  constexpr int PER = 32 / FB, NSYM = NREG * PER;
+  u8* const out = reinterpret_cast<u8*>(uniform_ptr64(out_v));
+  const u32 R8 = (R + 7u) & ~7u;
+  LMC_GLOBAL u32x2_t* const planes = (LMC_GLOBAL u32x2_t*)(out + R8);
+  int wv = 0;          // lane i: widths[i]
+  int lo = 0, hi = 0;  // lane l: plane jbase + l
+  u32 j = 0;           // planes made so far (wave-uniform)
+  static_for<NSYM>([&](auto itag) {  // (a compile-time loop: pk and wor stay in registers)
+    constexpr int i = decltype(itag)::value;
+    const u32 w = (u32)i < R ? field_width<FB, NREG>(wor, i) : 0u;  // uniform
+    wv = writelane_i32((int)w, (u32)i, wv);
+    u32 t = ((pk[i / PER] >> (FB * (i % PER))) & ((1u << FB) - 1u)) << ((32u - w) & 31u);  // the field's top bit at bit 31
+#pragma unroll 1
+    for (u32 b = 0; b < w; b++) {
+      const u64 m = __ballot((int)t < 0);
+      t <<= 1;
+      writelane2_i32(m, j & 63u, lo, hi);
+      j++;
+      if ((j & 63u) == 0u) planes[j - 64u + (u32)lane] = u32x2_t{(u32)lo, (u32)hi};
+    }
+  });
+  if ((u32)lane < (j & 63u)) planes[(j & ~63u) + (u32)lane] = u32x2_t{(u32)lo, (u32)hi};
+  if ((u32)lane < R8) ((LMC_GLOBAL u8*)out)[lane] = (u8)wv;  // widths[R .. R8) = 0: wv starts at 0
+  const u32 raw = R8 + 8u * j;
+  if ((raw & 8u) && lane == 0) planes[j] = u32x2_t{0u, 0u};  // zeros to 16 bytes
+  return (raw + 15u) & ~15u;
+}
+
+// Read a head back: `head` (wave-uniform, 16-byte aligned) -> this lane's stored counts cv[0 .. NSYM), NSYM = 32 or 16
+// (symbols >= R read 0).  `stage` = at least 2 KiB of this wave's LDS (the planes pass through it); `limit` = bytes the
+// head may take.  Returns the head's size, 0 if it is malformed (a width above 16, a head longer than `limit`).
+template <int NSYM>
+__device__ __forceinline__ u32 head_read(const u8* head_v, u32 limit, u32 R, u32* stage, u32 (&cv)[NSYM], int lane) {
+  typedef __attribute__((address_space(3))) u32* lds_u32w;
+  const u8* const head = reinterpret_cast<const u8*>(uniform_ptr64(head_v));
+  const u32 R8 = (R + 7u) & ~7u;
+  const u32 wv = ((u32)lane < R8 && R8 <= limit) ? (u32)((const LMC_GLOBAL u8*)head)[lane] : 0u;
+  u32 W = 0;
+  bool bad = R8 > limit || R > (u32)NSYM;
+  u32 w[NSYM];
+  static_for<NSYM>([&](auto itag) {
+    constexpr int i = decltype(itag)::value;
+    w[i] = (u32)i < R ? (u32)__builtin_amdgcn_readlane((int)wv, i) : 0u;
+    bad |= w[i] > 16u;
+    W += w[i];
+  });
+  const u32 hb = (R8 + 8u * W + 15u) & ~15u;
+  if (bad || hb > limit || W > 16u * (u32)NSYM) {
+#pragma unroll
+    for (int i = 0; i < NSYM; i++) cv[i] = 0u;
+    return 0u;
+  }
+  // planes -> LDS (one coalesced 8-byte load per lane and batch of 64), then every lane picks its bit of plane j from
+  // dword 2 j + lane / 32
+  const LMC_GLOBAL u32x2_t* const planes = (const LMC_GLOBAL u32x2_t*)(head + R8);
+  wave_lds_fence();
+  for (u32 j0 = 0; j0 < W; j0 += 64u) {
+    if (j0 + (u32)lane < W) {
+      const u32x2_t v = planes[j0 + (u32)lane];
+      stage[2u * (j0 + (u32)lane)] = v.x;
+      stage[2u * (j0 + (u32)lane) + 1u] = v.y;
+    }
+  }
+  wave_lds_fence();
+  const u32 my = (u32)(size_t)(lds_u32w)stage + 4u * ((u32)lane >> 5);
+  const u32 sh = (u32)lane & 31u;
+  u32 j = 0;
+  static_for<NSYM>([&](auto itag) {
+    constexpr int i = decltype(itag)::value;
+    u32 c = 0;
+#pragma unroll 1
+    for (u32 b = 0; b < w[i]; b++, j++) {
+      const u32 dw = *(lds_u32w)(size_t)(my + 8u * j);
+      c = (c << 1) | ((dw >> sh) & 1u);
+    }
+    cv[i] = c;
+  });
+  wave_lds_fence();  // the staging is dead
+  return hb;
+}

@@ -97,16 +97,27 @@ struct PackArgs {
   u32* status;
 };
 
+// Bytes of segment idx = (layer, kv, chunk) -- the streams of one plane of one chunk: from the beginning of the plane's
+// first stream to the beginning of the next plane's (the end of the streams section for the last plane) -- and where
+// it begins in the blob.  Every header word is checked before it is used as an offset: a chunk whose encode did not
+// finish (size word 0: lmc_encode_chunks zeroes the words in front of the job) or whose header is not a v6 header of
+// this geometry gives 0 bytes, and k_pack_scan fails the pack.
 __device__ __forceinline__ u32 pack_seg_bytes(const PackArgs& a, int idx, u32* begin) {
   const int lk = idx / a.n, chunk = idx - lk * a.n;
-  const int p = (lk & 1) * a.L + (lk >> 1);
+  const int P = 2 * a.L, p = (lk & 1) * a.L + (lk >> 1);
   const u8* blob = a.blobs + (long long)chunk * a.stride;
   const u32* hd = reinterpret_cast<const u32*>(blob);
-  const u32* gend = reinterpret_cast<const u32*>(blob + hd[14]);
-  const u32 s = p ? (gend[p * a.G - 1] + 15u) & ~15u : 0u;
-  const u32 e = (gend[(p + 1) * a.G - 1] + 15u) & ~15u;
-  if (begin) *begin = hd[15] + s;
-  return a.sizes_d[chunk] != 0u && e >= s && (unsigned long long)hd[15] + e <= (unsigned long long)a.stride ? e - s : 0u;
+  if (begin) *begin = 0u;
+  if (a.sizes_d[chunk] == 0u || hd[0] != LMC_BLOB_MAGIC || (hd[1] & 0xffffu) != LMC_BLOB_VERSION || hd[8] != (u32)P ||
+      hd[9] != (u32)a.G)
+    return 0u;
+  const BlobOff bo = lmc_blob_off((u32)P, hd[4], (u32)a.G);
+  if (hd[14] != bo.gdir || hd[15] != bo.streams || (unsigned long long)bo.streams + hd[16] > (unsigned long long)a.stride) return 0u;
+  const u32* gdir = reinterpret_cast<const u32*>(blob + bo.gdir);
+  const u32 s = gdir[2 * (p * a.G)];
+  const u32 e = p + 1 < P ? gdir[2 * ((p + 1) * a.G)] : hd[16];
+  if (begin) *begin = bo.streams + s;
+  return e >= s && e <= hd[16] && !(s & 15u) && !(e & 15u) ? e - s : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_pack_scan(PackArgs a) {
@@ -114,16 +125,19 @@ __global__ __launch_bounds__(256) void k_pack_scan(PackArgs a) {
   const int N = 2 * a.L * a.n, K = (N + 255) / 256;
   const int t = (int)threadIdx.x, i0 = t * K, i1 = min(N, i0 + K);
   unsigned long long mine = 0;
-  for (int i = i0; i < i1; i++) mine += pack_seg_bytes(a, i, nullptr);
+  int empty = 0;  // a segment of no bytes: its chunk's encode did not finish, or its header does not check out
+  for (int i = i0; i < i1; i++) {
+    const u32 b = pack_seg_bytes(a, i, nullptr);
+    empty |= b == 0u;
+    mine += b;
+  }
   sums[t] = mine;
-  __syncthreads();
+  const bool bad = __syncthreads_or(empty) != 0;
   unsigned long long off = 0, total = 0;
   for (int j = 0; j < 256; j++) {  // 256 adds per thread: one launch per store
     off += j < t ? sums[j] : 0ull;
     total += sums[j];
   }
-  bool bad = false;
-  for (int j = 0; j < a.n; j++) bad |= a.sizes_d[j] == 0u;
   const bool fits = !bad && a.hdr.off_streams + total <= a.cap;
   unsigned long long* table_h = reinterpret_cast<unsigned long long*>(a.host + a.hdr.off_table);
   for (int i = i0; i < i1; i++) {

@@ -35,8 +35,6 @@ struct QuantArgs {
   long long scale_stride;
   unsigned long long* agg;  // the coder's look-back granules, zeroed here (saves a memset dispatch), or NULL
   long long agg_n;
-  int lin_step;          // > 0: blockIdx.z = j stands for plane-chunk b = j * lin_step, chunk = b % nchunks, plane = b / nchunks
-                         // (the fused encode's head start: lmc_api.hip), blockIdx.y unused
 };
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -260,12 +258,7 @@ __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int sub = lane / G, sl = lane % G;
-  int p = (int)blockIdx.y, chunk = (int)blockIdx.z;
-  if (QUAD && a.lin_step > 0) {
-    const unsigned b = blockIdx.z * (unsigned)a.lin_step;
-    chunk = (int)(b % (unsigned)a.nchunks);
-    p = (int)(b / (unsigned)a.nchunks);
-  }
+  const int p = (int)blockIdx.y, chunk = (int)blockIdx.z;
   if (QUAD && a.agg) {  // the launch has at least 256 threads per plane-chunk, a plane-chunk at most 64 granules
     const long long i = (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
     if (i < a.agg_n) a.agg[i] = 0ull;

@@ -39,32 +39,10 @@ struct lmc_ctx {
   unsigned long long* agg = nullptr; size_t agg_bytes = 0;  // look-back granules of the in-kernel compaction
   hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
   bool ws_used = false;
-  // Workspace placement search.  The fused encode takes 1.03 or 1.13 ms for the same job depending on where hipMalloc
-  // put the workspace (tools/probes/encode_modes: deterministic per allocation, cause unknown -- DESIGN.md section 6).
-  // So a workspace for a large job is allocated ws_cands times, the first fused jobs run on each candidate in turn
-  // (4 jobs each, the last two timed with events on the caller's stream -- no host wait), and once the timings are in
-  // the fastest stays and the others are freed.  LMC_WS_CANDIDATES=1 turns it off.
-  struct WsCand { u32* sym4; u8* scratch; unsigned long long* agg; hipEvent_t t0, t1; };
-  WsCand wsc[4] = {};
-  int ws_cands = 3, ws_n = 0;   // candidates wanted / alive (wsc[0 .. ws_n))
-  int ws_jobs = 0;              // fused jobs measured so far
-  int ws_cur = 0;               // the candidate sym4 / scratch / agg point to
-  bool ws_search = false;
   int num_cus = 256;
   int enc_path = LMC_ENCODE_PATH_AUTO;  // lmc_ctx_set_encode_path
-  bool pre_all = false;
-  // Optional skew of the library's own buffers (LMC_SYM_PAD / LMC_SCRATCH_PAD, bytes, multiples of 16; default none).
-  // The fused encode takes 1.03 or 1.14 ms for the same job depending on WHERE hipMalloc put the workspace and the
-  // caller's blob arena (tools/probes/encode_modes: deterministic per placement, one process holds fast and slow
-  // ones).  Consecutive work items are the same plane of consecutive chunks and every natural stride between them is
-  // a multiple of 512 KiB (256 tokens of KV, 64 symbol regions, 1024 stream slots), so channel aliasing was the first
-  // suspect -- but padded strides did not remove the slow placements (13 / 13 fast in one process, 2 / 13 in the
-  // next, like without), and the input's placement does not matter at all.  DESIGN.md section 6.
-  size_t sym_pad = 0, scr_pad = 0;
   int stagger_us = 50;                  // fused encode: staggered start of a CU's first workgroups (k_fused.h), microseconds; LMC_FUSED_STAGGER_US=0: off
   u32* cu_rank = nullptr;
-  int pre_step = 0;                     // fused encode: every pre_step-th workgroup of the first generation gets a head start
-                                        // (0: none -- measured 1.06 ms without, 1.07-1.09 with 2 / 3 / 4: k_fused.h)
   u32 epoch = 0;                        // of the last fused launch (tags its look-back granules)
   unsigned long long* pack_table = nullptr;  // device copy of a pack's offset table while it is written (lmc_store_pack)
   size_t pack_table_bytes = 0;
@@ -109,24 +87,6 @@ const char* lmc_strerror(int code) {
 int lmc_last_hip_error(void) { return g_last_hip; }
 int lmc_abi_version(void) { return LMC_ABI_VERSION; }
 
-// The workspace candidates other than the current one go (the caller made sure nothing queued uses them), and the
-// search state with them.
-static void ws_drop_candidates(lmc_ctx* c) {
-  const int cur = c->ws_cur;
-  for (int k = 0; k < c->ws_n; k++) {
-    lmc_ctx::WsCand& w = c->wsc[k];
-    if (k != cur) {
-      if (w.sym4) (void)hipFree(w.sym4);
-      if (w.scratch) (void)hipFree(w.scratch);
-      if (w.agg) (void)hipFree(w.agg);
-    }
-    if (w.t0) (void)hipEventDestroy(w.t0);
-    if (w.t1) (void)hipEventDestroy(w.t1);
-    w = lmc_ctx::WsCand{};
-  }
-  c->ws_n = 0; c->ws_jobs = 0; c->ws_cur = 0; c->ws_search = false;
-}
-
 int lmc_ctx_create(int device, lmc_ctx** out) {
   if (!out) return LMC_ERR_INVALID;
   HIP_TRY(hipSetDevice(device));
@@ -143,11 +103,6 @@ int lmc_ctx_create(int device, lmc_ctx** out) {
   e = hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming);
   if (e != hipSuccess) { g_last_hip = (int)e; (void)hipHostFree(c->status_h); delete c; return LMC_ERR_HIP; }
   if (const char* e = getenv("LMC_FUSED_STAGGER_US")) c->stagger_us = atoi(e);
-  if (const char* e = getenv("LMC_WS_CANDIDATES")) c->ws_cands = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
-  if (const char* e = getenv("LMC_SYM_PAD")) c->sym_pad = (size_t)atoll(e) & ~(size_t)15;
-  if (const char* e = getenv("LMC_SCRATCH_PAD")) c->scr_pad = (size_t)atoll(e) & ~(size_t)15;
-  if (const char* e = getenv("LMC_FUSED_PRE_STEP")) c->pre_step = atoi(e);  // A/B switch of the head start (tools/probes)
-  if (const char* e = getenv("LMC_FUSED_PRE_ALL")) c->pre_all = atoi(e) != 0;  // experiment: EVERY plane-chunk quantised up front
   *out = c;
   return LMC_OK;
 }
@@ -156,7 +111,6 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   if (!c) return LMC_OK;
   (void)hipSetDevice(c->device);
   if (c->ws_used) (void)hipEventSynchronize(c->ws_free);
-  ws_drop_candidates(c);
   if (c->sym4) (void)hipFree(c->sym4);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->agg) (void)hipFree(c->agg);
@@ -239,15 +193,11 @@ static KvAddr to_addr(const lmc_kv_layout* l) {
 static bool bins_ok(const int32_t* bins_h, int P, BinsArg* out) {
   if (!bins_h) return false;
   memset(out, 0, sizeof *out);
-  u32 acc = 0;
   for (int p = 0; p < P; p++) {
     // MAX = bins//2 - 1 >= 1 and symbols 0..2*MAX must fit the 32-entry CDF
     if (bins_h[p] < 4 || bins_h[p] > LMC_MAX_BINS) return false;
     out->b[p] = (u8)bins_h[p];
-    out->rowpre[p] = (u16)acc;
-    acc += lmc_cdf_row((uint32_t)bins_h[p]);
   }
-  out->rowpre[P] = (u16)acc;
   return true;
 }
 
@@ -298,82 +248,24 @@ static int ws_grow(void** p, size_t* have, size_t need) {
   return LMC_OK;
 }
 
-// caller holds ctx->mu
-static int reserve_locked(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_chunks) {
+// caller holds ctx->mu.  The symbol workspace and the look-back granules of `max_chunks` chunks; the stream scratch
+// too when `scratch` (the two-kernel path codes into scratch slots; the fused kernel codes straight into the blobs).
+static int reserve_locked(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_chunks, bool scratch) {
   const size_t P = 2 * (size_t)L, C = (size_t)H * D, G = (C + 63) / 64, TQ = ((size_t)chunk_tokens + 3) / 4;
-  const size_t need_sym = (size_t)max_chunks * P * (TQ * C * 4 + c->sym_pad);
-  const size_t need_scr = (size_t)max_chunks * P * G * (lmc_group_cap_bytes((uint32_t)chunk_tokens) + c->scr_pad);
-  const size_t need_len = (size_t)max_chunks * P * G * 4;
-  if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && 2 * need_len <= c->agg_bytes) return LMC_OK;
+  const size_t need_sym = (size_t)max_chunks * P * TQ * C * 4;
+  const size_t need_scr = scratch ? (size_t)max_chunks * P * G * lmc_group_cap_bytes((uint32_t)chunk_tokens) : 0;
+  const size_t need_agg = (size_t)max_chunks * P * G * 8;
+  if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && need_agg <= c->agg_bytes) return LMC_OK;
   // growing frees memory that queued kernels may still use: wait for them (this call only)
   if (c->ws_used) HIP_TRY(hipEventSynchronize(c->ws_free));
   int rc;
   if ((rc = ws_grow((void**)&c->sym4, &c->sym4_bytes, need_sym))) return rc;
   if ((rc = ws_grow((void**)&c->scratch, &c->scratch_bytes, need_scr))) return rc;
   const size_t agg_before = c->agg_bytes;
-  if ((rc = ws_grow((void**)&c->agg, &c->agg_bytes, 2 * need_len))) return rc;
+  if ((rc = ws_grow((void**)&c->agg, &c->agg_bytes, need_agg))) return rc;
   // fresh granules must not look like a published value of some epoch (k_fused.h)
   if (c->agg_bytes != agg_before) HIP_TRY(hipMemset(c->agg, 0, c->agg_bytes));
-  // a new workspace: the old candidates go, and a large one gets rivals (see lmc_ctx::WsCand)
-  ws_drop_candidates(c);
-  if (c->ws_cands > 1 && c->sym4_bytes + c->scratch_bytes >= ((size_t)256 << 20)) {
-    c->wsc[0].sym4 = c->sym4; c->wsc[0].scratch = c->scratch; c->wsc[0].agg = c->agg;
-    c->ws_n = 1;
-    for (int k = 1; k < c->ws_cands; k++) {
-      lmc_ctx::WsCand w{};
-      if (hipMalloc((void**)&w.sym4, c->sym4_bytes) != hipSuccess || hipMalloc((void**)&w.scratch, c->scratch_bytes) != hipSuccess ||
-          hipMalloc((void**)&w.agg, c->agg_bytes) != hipSuccess || hipMemset(w.agg, 0, c->agg_bytes) != hipSuccess) {
-        if (w.sym4) (void)hipFree(w.sym4);   // no room for a rival: the search runs over what there is
-        if (w.scratch) (void)hipFree(w.scratch);
-        if (w.agg) (void)hipFree(w.agg);
-        (void)hipGetLastError();
-        break;
-      }
-      c->wsc[c->ws_n++] = w;
-    }
-    for (int k = 0; k < c->ws_n; k++) {
-      if (hipEventCreate(&c->wsc[k].t0) != hipSuccess || hipEventCreate(&c->wsc[k].t1) != hipSuccess) { ws_drop_candidates(c); return LMC_OK; }
-    }
-    c->ws_search = c->ws_n > 1;
-    if (!c->ws_search) ws_drop_candidates(c);
-  }
   return LMC_OK;
-}
-
-// One step of the workspace placement search, for a job that takes the fused kernel.  Returns the candidate whose
-// events bracket this job (-1: none) and which of them to record: bit 0 = t0 before the launch, bit 1 = t1 after it.
-#define LMC_WS_REPS 4
-static int ws_search_step(lmc_ctx* c, int* record) {
-  *record = 0;
-  if (!c->ws_search) return -1;
-  const int k = c->ws_jobs / LMC_WS_REPS, r = c->ws_jobs % LMC_WS_REPS;
-  if (k < c->ws_n) {  // measuring: this job runs on candidate k
-    c->ws_cur = k;
-    c->sym4 = c->wsc[k].sym4; c->scratch = c->wsc[k].scratch; c->agg = c->wsc[k].agg;
-    c->ws_jobs++;
-    if (r == LMC_WS_REPS - 2) *record = 1;
-    if (r == LMC_WS_REPS - 1) *record = 2;
-    return k;
-  }
-  // every candidate has been timed: are the timings in?  (never wait for them: the job runs on the last candidate
-  // until they are)
-  int best = -1;
-  float best_ms = 0.f;
-  for (int j = 0; j < c->ws_n; j++) {
-    if (hipEventQuery(c->wsc[j].t1) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->wsc[j].t0, c->wsc[j].t1) != hipSuccess) { (void)hipGetLastError(); ms = 1e30f; }
-    if (best < 0 || ms < best_ms) { best = j; best_ms = ms; }
-  }
-  // t1 of the last candidate has fired, so no queued kernel uses any candidate but the current one (every job waits
-  // for its predecessor's ws_free): the losers can go now, unless the current one loses -- then wait until it is idle
-  if (best != c->ws_cur) {
-    if (hipEventQuery(c->ws_free) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    c->ws_cur = best;
-    c->sym4 = c->wsc[best].sym4; c->scratch = c->wsc[best].scratch; c->agg = c->wsc[best].agg;
-  }
-  ws_drop_candidates(c);
-  return -1;
 }
 
 extern "C" {
@@ -382,7 +274,7 @@ int lmc_ctx_reserve(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_c
   if (!c || L < 1 || H < 1 || D < 8 || chunk_tokens < 1 || max_chunks < 1) return LMC_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   std::lock_guard<std::mutex> lk(c->mu);
-  return reserve_locked(c, L, H, D, chunk_tokens, max_chunks);
+  return reserve_locked(c, L, H, D, chunk_tokens, max_chunks, true);
 }
 
 int lmc_quantize(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t ntok, const int32_t* bins_h,
@@ -439,14 +331,26 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   hipStream_t s = (hipStream_t)stream;
 
   std::lock_guard<std::mutex> lk(c->mu);
-  int rc = reserve_locked(c, L, H, D, chunk_tokens, nchunks);
+  // k_fused.h codes 256-token chunks (the counts model) of 256 < C <= 1024 channels (64-lane quantise tasks, G <= 16)
+  const int nfull = (tok_end - tok_begin) / chunk_tokens;  // chunks of exactly chunk_tokens tokens; a ragged one may follow
+  const bool fused_fits = C > 256 && C <= 1024 && chunk_tokens == (int)LMC_COUNTS_T && nfull > 0;
+  // AUTO: the fused kernel pays once its (chunk, plane) workgroups outnumber the slots of the chip (4 per CU):
+  // measured on MI355X with 64 planes, 4 / 8 / 12 / 16 / 32 / 64 chunks: fused / two-kernel time = 1.27 / 1.16 /
+  // 1.05 / 1.00 / 0.91 / 0.90 (tools/probes/encode_ab.hip)
+  const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
+                                    (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * P > 4ll * c->num_cus));
+  const bool two_kernel_part = !fused || nfull < nchunks;  // chunks that code into scratch slots
+  int rc = reserve_locked(c, L, H, D, chunk_tokens, nchunks, two_kernel_part);
   if (rc) return rc;
   if (c->ws_used) HIP_TRY(hipStreamWaitEvent(s, c->ws_free, 0));
+  // A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next (k_offload, k_pack_scan,
+  // the host): no stale word of an earlier job may stand in for it.
+  HIP_TRY(hipMemsetAsync(sizes, 0, sizeof(uint32_t) * (size_t)nchunks, s));
 
   const int TQ = (chunk_tokens + 3) / 4;
-  const u32 cap = lmc_group_cap_bytes((uint32_t)chunk_tokens) + (u32)c->scr_pad;  // slot stride (and capacity)
+  const u32 cap = lmc_group_cap_bytes((uint32_t)chunk_tokens);  // scratch slot stride (and capacity)
   lmc_blob_header hl;
-  lmc_blob_layout((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D, bins.rowpre[P], &hl);
+  lmc_blob_layout((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)H, (uint32_t)D, &hl);
   const long long PG = (long long)P * G;
 
   EncodeArgs ea;
@@ -454,7 +358,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   ea.sym4 = c->sym4;
   ea.tok_begin = tok_begin; ea.tok_end = tok_end; ea.chunk_tokens = chunk_tokens; ea.nchunks = nchunks;
   ea.P = P; ea.C = C; ea.G = G; ea.TQ = TQ;
-  ea.sym_stride = (long long)TQ * C + (long long)(c->sym_pad / 4);
+  ea.sym_stride = (long long)TQ * C;
   ea.blobs = (u8*)blobs; ea.blob_stride = (long long)blob_stride;
   ea.scratch = c->scratch; ea.cap = cap;
   ea.status = job_status ? job_status : c->status_h;
@@ -470,14 +374,11 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   }
   ea.ticket = c->ticket;
   c->pn = 0;
-  // k_fused.h codes 256-token chunks (the counts model) of 256 < C <= 1024 channels (64-lane quantise tasks, G <= 16)
-  const int nfull = (tok_end - tok_begin) / chunk_tokens;  // chunks of exactly chunk_tokens tokens; a ragged one may follow
-  const bool fused_fits = C > 256 && C <= 1024 && chunk_tokens == (int)LMC_COUNTS_T && nfull > 0;
-  // AUTO: the fused kernel pays once its (chunk, plane) workgroups outnumber the slots of the chip (4 per CU):
-  // measured on MI355X with 64 planes, 4 / 8 / 12 / 16 / 32 / 64 chunks: fused / two-kernel time = 1.27 / 1.16 /
-  // 1.05 / 1.00 / 0.91 / 0.90 (tools/probes/encode_ab.hip)
-  const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
-                                    (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * P > 4ll * c->num_cus));
+  // A launch that draws tickets and fails leaves the host's count and the device counter apart: both start over.
+  auto tickets_reset = [&]() {
+    (void)hipMemsetAsync(c->ticket, 0, 64, s);
+    c->tickets_drawn = 0;
+  };
   // the chunks [c0, c0 + n) of the job with the two kernels: k_quantize, then k_cdf_encode (CDF or counts table +
   // coder + in-kernel compaction of the streams into the blobs).  Measured alternatives that lost: HISTORY.md.
   auto two_kernels = [&](int c0, int n) -> int {
@@ -507,18 +408,15 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     const int nw = counts_only ? 8 : ENC_WAVES;
     const unsigned nwg = (unsigned)((ngroups + nw - 1) / nw);
     e2.ticket_base = c->tickets_drawn;
-    c->tickets_drawn += nwg;
     if (counts_only) hipLaunchKernelGGL((k_cdf_encode<true, true, 8, true>), dim3(nwg), dim3(64 * 8), 0, s, e2);
     else hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3(nwg), dim3(64 * ENC_WAVES), 0, s, e2);
-    HIP_TRY(hipGetLastError());
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { g_last_hip = (int)le; tickets_reset(); return LMC_ERR_HIP; }
+    c->tickets_drawn += nwg;  // only a launch that went out has drawn
     return prof_mark(c, s);
   };
-  int ws_rec = 0;
-  const int ws_k = fused ? ws_search_step(c, &ws_rec) : -1;  // may move sym4 / scratch / agg to another candidate
-  ea.sym4 = c->sym4; ea.scratch = c->scratch; ea.agg = c->agg;
-  if (ws_rec & 1) HIP_TRY(hipEventRecord(c->wsc[ws_k].t0, s));
   if (fused) {
-    // One launch for the full chunks: a workgroup per (chunk, plane) quantises, then codes and places its streams.
+    // One launch for the full chunks: a workgroup per (chunk, plane) quantises, then codes its streams into the blob.
     FusedArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.src = to_addr(src); fa.e = ea;
@@ -530,34 +428,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     fa.epoch = c->epoch;
     const dim3 grid((unsigned)((long long)nfull * P)), block(64 * FUSED_WAVES);
     fa.e.ticket_base = c->tickets_drawn;
-    c->tickets_drawn += grid.x;
     if ((rc = prof_mark(c, s))) return rc;
-    // head start (k_fused.h): with at least three generations of workgroups, every pre_step-th plane-chunk of the
-    // first generation (4 workgroups per CU) is quantised by k_quantize in front of the fused launch
-    const long long gen1 = c->pre_all ? (long long)nfull * P : 4ll * c->num_cus;
-    if (c->pre_step > 0 && (c->pre_all || (long long)nfull * P >= 3 * gen1)) {
-      fa.pre_limit = (u32)gen1; fa.pre_step = (u32)c->pre_step;
-      QuantArgs qa;
-      memset(&qa, 0, sizeof qa);
-      qa.src = to_addr(src); qa.bins = bins;
-      qa.tok_begin = tok_begin; qa.tok_end = fa.e.tok_end; qa.chunk_tokens = chunk_tokens; qa.nchunks = nfull;
-      qa.P = P; qa.C = C; qa.TQ = TQ; qa.pc_limit = nfull * P; qa.sym_stride = ea.sym_stride;
-      qa.sym4 = c->sym4;
-      qa.scale_base = scale_base; qa.scale_stride = (long long)blob_stride;
-      qa.lin_step = c->pre_step;
-      const int TO = (TQ + 1) / 2;
-      const dim3 qgrid((unsigned)((TO + 3) / 4), 1u, (unsigned)((gen1 + c->pre_step - 1) / c->pre_step));
-      if (src->dtype == LMC_DTYPE_BF16) {
-        if (C <= 512) hipLaunchKernelGGL((k_quantize<64, 1, LMC_DTYPE_BF16, true>), qgrid, dim3(256), 0, s, qa);
-        else hipLaunchKernelGGL((k_quantize<64, 2, LMC_DTYPE_BF16, true>), qgrid, dim3(256), 0, s, qa);
-      } else {
-        if (C <= 512) hipLaunchKernelGGL((k_quantize<64, 1, LMC_DTYPE_FP16, true>), qgrid, dim3(256), 0, s, qa);
-        else hipLaunchKernelGGL((k_quantize<64, 2, LMC_DTYPE_FP16, true>), qgrid, dim3(256), 0, s, qa);
-      }
-      HIP_TRY(hipGetLastError());
-    } else {
-      fa.pre_limit = 0; fa.pre_step = 1;
-    }
     if (c->stagger_us > 0 && (long long)nfull * P >= 8ll * c->num_cus) {
       if (!c->cu_rank) {  // zeroed once; every launch leaves it zero
         HIP_TRY(hipMalloc((void**)&c->cu_rank, 4096 * sizeof(u32)));
@@ -572,7 +443,9 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
       if (C <= 512) hipLaunchKernelGGL((k_encode_fused<1, LMC_DTYPE_FP16, FUSED_WAVES>), grid, block, 0, s, fa);
       else hipLaunchKernelGGL((k_encode_fused<2, LMC_DTYPE_FP16, FUSED_WAVES>), grid, block, 0, s, fa);
     }
-    HIP_TRY(hipGetLastError());
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { g_last_hip = (int)le; tickets_reset(); return LMC_ERR_HIP; }
+    c->tickets_drawn += grid.x;
     if ((rc = prof_mark(c, s))) return rc;
     if (nfull < nchunks && (rc = two_kernels(nfull, nchunks - nfull))) return rc;  // the ragged last chunk
   } else if (nfull > 0 && nfull < nchunks && chunk_tokens == (int)LMC_COUNTS_T) {
@@ -582,7 +455,6 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     if ((rc = two_kernels(0, nchunks))) return rc;
   }
 
-  if (ws_rec & 2) HIP_TRY(hipEventRecord(c->wsc[ws_k].t1, s));
   HIP_TRY(hipEventRecord(c->ws_free, s));
   c->ws_used = true;
   return LMC_OK;
@@ -896,15 +768,11 @@ int lmc_store_pack(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int3
   const int nchunks = (tok_end - tok_begin + chunk_tokens - 1) / chunk_tokens;
   const int L = src->num_layers, P = 2 * L;
   if (nchunks > 65535 || (long long)P * nchunks > (1ll << 22)) return LMC_ERR_INVALID;
-  uint32_t rows = 0;
-  for (int p = 0; p < P; p++) {
+  for (int p = 0; p < P; p++)
     if (bins_h[p] < 4 || bins_h[p] > LMC_MAX_BINS) return LMC_ERR_INVALID;
-    rows += lmc_cdf_row((uint32_t)bins_h[p]);
-  }
   PackArgs pa;
   memset(&pa, 0, sizeof pa);
-  lmc_pack_layout((uint32_t)nchunks, (uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)src->num_heads, (uint32_t)src->head_size, rows,
-                  &pa.hdr);
+  lmc_pack_layout((uint32_t)nchunks, (uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)src->num_heads, (uint32_t)src->head_size, &pa.hdr);
   pa.hdr.ntokens = (uint32_t)(tok_end - tok_begin);
   if (pa.hdr.off_streams > pack_cap) return LMC_ERR_INVALID;
   const uint64_t stride = (lmc_blob_bound((uint32_t)L, (uint32_t)chunk_tokens, (uint32_t)src->num_heads,
@@ -1084,16 +952,14 @@ int lmc_blob_info(const void* blob_h, size_t nbytes, lmc_blob_header* out) {
   memcpy(&h, blob_h, sizeof h);
   if (h.magic != LMC_BLOB_MAGIC || h.version != LMC_BLOB_VERSION || h.header_bytes != LMC_HEADER_BYTES) return LMC_ERR_INVALID;
   if (h.num_layers == 0 || h.ntokens == 0 || h.num_heads == 0 || h.head_size == 0) return LMC_ERR_INVALID;
-  if (h.num_layers > LMC_MAX_PLANES / 2 || h.cdf_rows > 31u * 2u * h.num_layers || h.count_bytes != lmc_count_bytes(h.ntokens) ||
-      h.model != lmc_model_for(h.ntokens))
-    return LMC_ERR_INVALID;
+  if (h.num_layers > LMC_MAX_PLANES / 2 || h.ntokens > 65535u || h.model != lmc_model_for(h.ntokens)) return LMC_ERR_INVALID;
+  if ((uint64_t)h.num_heads * h.head_size > LMC_MAX_CHANNELS) return LMC_ERR_INVALID;
   lmc_blob_header ref;
   memset(&ref, 0, sizeof ref);
-  lmc_blob_layout(h.num_layers, h.ntokens, h.num_heads, h.head_size, h.cdf_rows, &ref);
+  lmc_blob_layout(h.num_layers, h.ntokens, h.num_heads, h.head_size, &ref);
   if (h.nchannels != ref.nchannels || h.nplanes != ref.nplanes || h.ngroups != ref.ngroups || h.lp != ref.lp ||
-      h.off_bins != ref.off_bins || h.off_rowpre != ref.off_rowpre || h.off_scales != ref.off_scales ||
-      h.off_scsum != ref.off_scsum || h.off_cdf != ref.off_cdf || h.off_gend != ref.off_gend ||
-      h.off_streams != ref.off_streams)
+      h.off_bins != ref.off_bins || h.off_scales != ref.off_scales || h.off_scsum != ref.off_scsum ||
+      h.off_gdir != ref.off_gdir || h.off_streams != ref.off_streams)
     return LMC_ERR_INVALID;
   if (h.total_bytes != h.off_streams + h.stream_bytes || h.total_bytes > nbytes) return LMC_ERR_INVALID;
   *out = h;

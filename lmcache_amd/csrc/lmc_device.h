@@ -35,7 +35,6 @@ struct KvAddr {
 
 struct BinsArg {
   u8 b[LMC_MAX_PLANES];
-  u16 rowpre[LMC_MAX_PLANES + 1];  // rowpre[p] = sum over planes before p of (bins - 1): symbol counts stored per channel
 };
 
 __device__ __forceinline__ const u16* lmc_plane_base(const KvAddr& a, int p) {
@@ -58,22 +57,17 @@ __device__ __forceinline__ long long lmc_tok_off(const KvAddr& a, int t) {
 // (k_quantize.h writes, k_encode.h reads).
 __device__ __forceinline__ bool lmc_sym_nibbles(int bins) { return bins <= 17; }
 
-// device twin of lmc_count_bytes (lmc_format.h): bytes per stored symbol count
-__device__ __forceinline__ u32 dev_count_bytes(u32 T) { return T <= 256u ? 1u : 2u; }
-
 // Section offsets of a chunk blob with T tokens (mirror of lmc_blob_layout).
 struct BlobOff {
-  u32 bins, rowpre, scales, scsum, cdf, gend, streams;
+  u32 bins, scales, scsum, gdir, streams;
 };
-__device__ __forceinline__ BlobOff lmc_blob_off(u32 P, u32 T, u32 C, u32 G, u32 cdf_rows) {
+__device__ __forceinline__ BlobOff lmc_blob_off(u32 P, u32 T, u32 G) {
   BlobOff o;
   o.bins = LMC_HEADER_BYTES;
-  o.rowpre = o.bins + ((P + 15u) & ~15u);
-  o.scales = o.rowpre + ((2u * (P + 1u) + 15u) & ~15u);
+  o.scales = o.bins + ((P + 15u) & ~15u);
   o.scsum = o.scales + ((2u * P * T + 15u) & ~15u);
-  o.cdf = o.scsum + ((4u * P + 15u) & ~15u);
-  o.gend = o.cdf + ((dev_count_bytes(T) * C * cdf_rows + 15u) & ~15u);
-  o.streams = o.gend + ((4u * P * G + 15u) & ~15u);
+  o.gdir = o.scsum + ((4u * P + 15u) & ~15u);
+  o.streams = o.gdir + ((8u * P * G + 15u) & ~15u);  // directory entries are {beg, end} pairs
   return o;
 }
 
@@ -89,6 +83,7 @@ __device__ __forceinline__ void divmod_small(u32 e, u32 R, float rcpR, u32& q, u
 // in global memory, so say so.
 #define LMC_GLOBAL __attribute__((address_space(1)))
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint4 ld_global_u4(const u16* p) {
   const u32x4_t v = *reinterpret_cast<const LMC_GLOBAL u32x4_t*>((const LMC_GLOBAL u16*)p);
   return make_uint4(v.x, v.y, v.z, v.w);
@@ -210,6 +205,36 @@ __device__ __forceinline__ void wave_max2_u32(u32& a, u32& b) {
       "v_readlane_b32 %[sa], %[a], 63\n\t"
       "v_readlane_b32 %[sb], %[b], 63\n\t"
       "s_nop 4"  // whatever follows may read the two SGPRs at once (the compiler does not look inside the block)
+      : [a] "+v"(a), [b] "+v"(b), [sa] "=s"(sa), [sb] "=s"(sb));
+  a = sa;
+  b = sb;
+}
+
+// bitwise OR over the 64 lanes for TWO values at once, the same DPP ladder; wave-uniform results
+__device__ __forceinline__ void wave_or2_u32(u32& a, u32& b) {
+  u32 sa, sb;
+  asm("s_nop 1\n\t"
+      "v_or_b32_dpp %[a], %[a], %[a] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_or_b32_dpp %[b], %[b], %[b] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_or_b32_dpp %[a], %[a], %[a] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_or_b32_dpp %[b], %[b], %[b] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_or_b32_dpp %[a], %[a], %[a] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_or_b32_dpp %[b], %[b], %[b] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_or_b32_dpp %[a], %[a], %[a] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_or_b32_dpp %[b], %[b], %[b] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_or_b32_dpp %[a], %[a], %[a] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_or_b32_dpp %[b], %[b], %[b] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_or_b32_dpp %[a], %[a], %[a] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_or_b32_dpp %[b], %[b], %[b] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_readlane_b32 %[sa], %[a], 63\n\t"
+      "v_readlane_b32 %[sb], %[b], 63\n\t"
+      "s_nop 4"
       : [a] "+v"(a), [b] "+v"(b), [sa] "=s"(sa), [sb] "=s"(sb));
   a = sa;
   b = sb;

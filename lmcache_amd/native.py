@@ -55,10 +55,10 @@ class BlobHeader(ctypes.Structure):
                 ("dtype", ctypes.c_uint32), ("num_layers", ctypes.c_uint32), ("ntokens", ctypes.c_uint32),
                 ("num_heads", ctypes.c_uint32), ("head_size", ctypes.c_uint32), ("nchannels", ctypes.c_uint32),
                 ("nplanes", ctypes.c_uint32), ("ngroups", ctypes.c_uint32), ("lp", ctypes.c_uint32),
-                ("off_bins", ctypes.c_uint32), ("off_scales", ctypes.c_uint32), ("off_cdf", ctypes.c_uint32),
-                ("off_gend", ctypes.c_uint32), ("off_streams", ctypes.c_uint32), ("stream_bytes", ctypes.c_uint32),
-                ("total_bytes", ctypes.c_uint32), ("off_rowpre", ctypes.c_uint32), ("cdf_rows", ctypes.c_uint32),
-                ("count_bytes", ctypes.c_uint32), ("off_scsum", ctypes.c_uint32), ("model", ctypes.c_uint32),
+                ("off_bins", ctypes.c_uint32), ("off_scales", ctypes.c_uint32), ("zero13", ctypes.c_uint32),
+                ("off_gdir", ctypes.c_uint32), ("off_streams", ctypes.c_uint32), ("stream_bytes", ctypes.c_uint32),
+                ("total_bytes", ctypes.c_uint32), ("zero18", ctypes.c_uint32 * 3),
+                ("off_scsum", ctypes.c_uint32), ("model", ctypes.c_uint32),
                 ("reserved", ctypes.c_uint32 * 9)]
 
 
@@ -137,7 +137,7 @@ def lib() -> ctypes.CDLL:
             for name, (res, args) in SYMBOLS.items():
                 fn = getattr(L, name)  # AttributeError if the ABI and this binding drift apart
                 fn.restype, fn.argtypes = res, args
-            if L.lmc_abi_version() != 5:
+            if L.lmc_abi_version() != 6:
                 raise NativeError("liblmc_hip.so ABI version mismatch; rebuild")
             _lib = L
     return _lib
@@ -191,22 +191,20 @@ def r16(x: int) -> int:
 
 
 def group_cap_bytes(T: int) -> int:
-    return r16(LANES * (T + 8))
+    """lmc_group_cap_bytes: the largest head (31 symbols, every width at its maximum) + words and states."""
+    stored = 255 if T == 256 else T
+    return r16(32 + 8 * 31 * stored.bit_length()) + r16(LANES * (T + 8))
 
 
-def blob_static_bytes(L: int, T: int, H: int, D: int, bins: Optional[Sequence[int]] = None) -> int:
-    """Bytes in front of the streams section (lmc_blob_layout): header, bins, rowpre, scales, their checksums, the symbol
-    counts (bins - 1 per channel, one byte each for T <= 256 else two; every plane at 32 bins when `bins` is
-    None) and gend."""
+def blob_static_bytes(L: int, T: int, H: int, D: int) -> int:
+    """Bytes in front of the streams section (lmc_blob_layout): header, bins, scales, their checksums, the stream
+    directory."""
     C, P = H * D, 2 * L
     G = (C + LANES - 1) // LANES
-    rows = 31 * P if bins is None else sum(int(b) - 1 for b in bins)
     off = HEADER_BYTES + r16(P)
-    off += r16(2 * (P + 1))
     off += r16(2 * P * T)
     off += r16(4 * P)
-    off += r16((1 if T <= 256 else 2) * C * rows)
-    off += r16(4 * P * G)
+    off += r16(8 * P * G)
     return off
 
 

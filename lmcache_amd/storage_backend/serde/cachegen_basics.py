@@ -111,22 +111,42 @@ class CacheGenGPUEncoderOutput:
     def bins(self) -> List[int]:
         return self._section(self.header.off_bins, self.header.nplanes, np.uint8).tolist()
 
+    def _stream_dir(self) -> np.ndarray:
+        """[P * G, 2] = {beg, end} of every group stream, relative to the streams section."""
+        h = self.header
+        return self._section(h.off_gdir, 2 * h.nplanes * h.ngroups, np.uint32).astype(np.int64).reshape(-1, 2)
+
+    def _stream_counts(self, pg: int, R: int) -> np.ndarray:
+        """Stored counts [64 lanes, R] of group stream pg, from the bit planes of its head (include/lmc_format.h)."""
+        h = self.header
+        base = int(h.off_streams) + int(self._stream_dir()[pg, 0])
+        R8 = (R + 7) & ~7
+        widths = self._section(base, R8, np.uint8)
+        if widths[R:].any() or (widths > 16).any():
+            raise ValueError("malformed stream head")
+        planes = self._section(base + R8, int(widths.sum()), np.uint64)
+        bits = ((planes[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64)
+        cnt = np.zeros((64, R), np.int64)
+        j = 0
+        for i in range(R):
+            for _ in range(int(widths[i])):
+                cnt[:, i] = (cnt[:, i] << 1) | bits[j]
+                j += 1
+        return cnt
+
     @property
     def cdf(self) -> torch.Tensor:
-        """int16 [2L, C, 33] -- the reference's `cdf` tensor, rebuilt from the blob: the container stores the
-        symbol counts of every channel, and cdf[i] = RNE(N_i * 65504 / T) + i with N_i the number of symbols
+        """int16 [2L, C, 33] -- the reference's `cdf` tensor, rebuilt from the blob: every stream opens with the
+        symbol counts of its 64 channels, and cdf[i] = RNE(N_i * 65504 / T) + i with N_i the number of symbols
         < i (cachegen_encoder.py:95-126; include/lmc_format.h)."""
         h = self.header
-        P, C, LP, T = int(h.nplanes), int(h.nchannels), int(h.lp), int(h.ntokens)
-        rowpre = self._section(h.off_rowpre, P + 1, np.uint16).astype(np.int64)
-        dt = np.uint8 if int(h.count_bytes) == 1 else np.uint16
-        stored = self._section(h.off_cdf, C * int(rowpre[P]), dt).astype(np.int64)
+        P, C, G, LP, T = int(h.nplanes), int(h.nchannels), int(h.ngroups), int(h.lp), int(h.ntokens)
         full = np.empty((P, C, LP), np.uint16)
         i = np.arange(LP, dtype=np.int64)
         for p, b in enumerate(self.bins):
             R = b - 1
-            cnt = stored[C * rowpre[p]:C * rowpre[p + 1]].reshape(R, C).T.copy()  # stored symbol-major
-            if dt is np.uint8:  # a count of 256 reads 255: the counts of a channel sum to T
+            cnt = np.concatenate([self._stream_counts(p * G + g, R) for g in range(G)])[:C]
+            if T <= 256:  # a count of 256 reads 255: the counts of a channel sum to T
                 short = T - cnt.sum(axis=1)
                 rows, cols = np.nonzero((cnt == 255) & (short[:, None] > 0))
                 cnt[rows, cols] += short[rows]
@@ -155,9 +175,8 @@ class CacheGenGPUEncoderOutput:
     @property
     def data_chunks(self) -> List[CacheGenGPUBytestream]:
         h = self.header
-        gend = self._section(h.off_gend, h.nplanes * h.ngroups, np.uint32).astype(np.int64)
-        starts = np.concatenate([[0], (gend[:-1] + 15) & ~15])
-        lens = (gend - starts).astype(np.int32).reshape(h.nplanes, h.ngroups)
+        d = self._stream_dir()
+        lens = (d[:, 1] - d[:, 0]).astype(np.int32).reshape(h.nplanes, h.ngroups)
         streams = self._section(h.off_streams, h.stream_bytes, np.uint8).copy()
         return [CacheGenGPUBytestream(torch.from_numpy(streams), torch.from_numpy(lens), self.ntokens)]
 

@@ -135,7 +135,10 @@ def cdf(sym: np.ndarray, max_bins: int = MAX_BINS) -> np.ndarray:
 
 
 def group_cap_bytes(T: int) -> int:
-    return (LANES * (T + 8) + 15) & ~15
+    """lmc_group_cap_bytes: the largest head + words and states."""
+    stored = 255 if T == 256 else T
+    head = (32 + 8 * 31 * stored.bit_length() + 15) & ~15
+    return head + ((LANES * (T + 8) + 15) & ~15)
 
 
 def encode_group(sym_plane: np.ndarray, g: int, cdf_plane: np.ndarray) -> bytes:
@@ -176,13 +179,40 @@ def encode_blob(kv_bits: np.ndarray, dtype: int, H: int, D: int, bins: np.ndarra
 
 def parse_header(blob: bytes) -> dict:
     names = ["dtype", "num_layers", "ntokens", "num_heads", "head_size", "nchannels", "nplanes", "ngroups",
-             "lp", "off_bins", "off_scales", "off_cdf", "off_gend", "off_streams", "stream_bytes",
-             "total_bytes", "off_rowpre", "cdf_rows", "count_bytes", "off_scsum", "model"]
+             "lp", "off_bins", "off_scales", "zero13", "off_gdir", "off_streams", "stream_bytes",
+             "total_bytes", "zero18", "zero19", "zero20", "off_scsum", "model"]
     head = np.frombuffer(blob[:128], dtype=np.uint32)
     assert head[0] == 0x31434D4C, "bad magic"
     d = {n: int(v) for n, v in zip(names, head[2:2 + len(names)])}
     d["version"] = int(head[1] & 0xffff)
     return d
+
+
+def stream_dir(blob: bytes) -> np.ndarray:
+    """The stream directory [P * G, 2] = {beg, end} relative to the streams section."""
+    h = parse_header(blob)
+    return np.frombuffer(blob, np.uint32, 2 * h["nplanes"] * h["ngroups"], h["off_gdir"]).reshape(-1, 2).astype(np.int64)
+
+
+def stream_head(blob: bytes, pg: int):
+    """(widths uint8 [R], stored counts int64 [R, 64], head bytes) of stream pg, parsed in numpy (lmc_format.h: head)."""
+    h = parse_header(blob)
+    beg, end = stream_dir(blob)[pg]
+    R = blob[h["off_bins"] + pg // h["ngroups"]] - 1
+    R8 = (R + 7) & ~7
+    base = h["off_streams"] + int(beg)
+    widths = np.frombuffer(blob, np.uint8, R8, base)
+    assert not widths[R:].any() and widths.max(initial=0) <= 16
+    W = int(widths.sum())
+    planes = np.frombuffer(blob, np.uint64, W, base + R8)
+    cnt = np.zeros((R, 64), np.int64)
+    j = 0
+    lanes = np.arange(64, dtype=np.uint64)
+    for i in range(R):
+        for b in range(int(widths[i]) - 1, -1, -1):
+            cnt[i] |= ((planes[j] >> lanes) & np.uint64(1)).astype(np.int64) << b
+            j += 1
+    return widths[:R].copy(), cnt, (R8 + 8 * W + 15) & ~15
 
 
 def blob_cdf(blob: bytes) -> np.ndarray:
@@ -259,13 +289,10 @@ def pack_from_blobs(blobs, chunk_tokens: int) -> bytes:
     r16 = lambda x: (x + 15) & ~15
     # lmc_blob_layout for a chunk_tokens-token blob of this geometry: where its streams would start
     P, C = 2 * L, H * D
-    cb = 1 if chunk_tokens <= 256 else 2
     off = 128 + r16(P)                       # header | bins
-    off += r16(2 * (P + 1))                  # rowpre
     off += r16(2 * P * chunk_tokens)         # scales
     off += r16(4 * P)                        # scale checksums
-    off += r16(cb * C * h0["cdf_rows"])      # symbol counts
-    off += r16(4 * P * G)                    # stream directory
+    off += r16(8 * P * G)                    # stream directory {beg, end}
     static_stride = r16(off)
     assert all(h["ntokens"] == chunk_tokens for h in hs[:-1]) and all(h["off_streams"] <= static_stride for h in hs)
     assert any(h["ntokens"] != chunk_tokens for h in hs) or h0["off_streams"] == off
@@ -278,15 +305,15 @@ def pack_from_blobs(blobs, chunk_tokens: int) -> bytes:
         for kv in range(2):
             p = kv * L + layer
             for c, (b, h) in enumerate(zip(blobs, hs)):
-                gend = np.frombuffer(b, dtype=np.uint32, count=2 * L * G, offset=h["off_gend"])
-                s0 = r16(int(gend[p * G - 1])) if p else 0
-                s1 = r16(int(gend[(p + 1) * G - 1]))
+                gdir = np.frombuffer(b, dtype=np.uint32, count=2 * P * G, offset=h["off_gdir"])
+                s0 = int(gdir[2 * p * G])  # beg of stream (p, 0) ... of stream (p + 1, 0), or the end of the section
+                s1 = int(gdir[2 * (p + 1) * G]) if p + 1 < P else h["stream_bytes"]
                 table.append(at)
                 segs.append(b[h["off_streams"] + s0:h["off_streams"] + s1])
                 at += s1 - s0
     table.append(at)
     ntok = sum(h["ntokens"] for h in hs)
-    head = struct.pack("<12I4Q", 0x4b504d4c, 1, 256, n, L, H, D, chunk_tokens, G, static_stride, ntok, 0,
+    head = struct.pack("<12I4Q", 0x4b504d4c, 2, 256, n, L, H, D, chunk_tokens, G, static_stride, ntok, 0,
                        off_table, off_static, off_streams, off_streams + at)
     out = bytearray(off_streams + at)
     out[:len(head)] = head

@@ -481,16 +481,21 @@ def test_corrupt_blob_is_flagged(nat, ctx):
     ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T - 1)
     torch.cuda.synchronize()
     assert ctx.status(clear=True) & 2
-    # garbage in the count section or in the stream directory: flagged, nothing hangs or faults
+    # garbage in a stream's head (widths, count planes) or in the stream directory: flagged, nothing hangs or faults
     g = torch.Generator().manual_seed(3)
+    for n in (8, 32, 600):  # the widths alone; widths and the first planes; the whole head and the first words
+        bad = blob_dev.clone()
+        bad[hdr.off_streams:hdr.off_streams + n] = torch.randint(0, 256, (n,), generator=g, dtype=torch.uint8).to(DEV)
+        ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+        torch.cuda.synchronize()
+        assert ctx.status(clear=True) & 4
     bad = blob_dev.clone()
-    n = hdr.off_gend - hdr.off_cdf
-    bad[hdr.off_cdf:hdr.off_gend] = torch.randint(0, 256, (n,), generator=g, dtype=torch.uint8).to(DEV)
+    bad[hdr.off_streams:hdr.off_streams + 8] = torch.tensor([3] * 8, dtype=torch.uint8, device=DEV)  # legal widths, wrong ones
     ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
     torch.cuda.synchronize()
     assert ctx.status(clear=True) & 4
     bad = blob_dev.clone()
-    bad[hdr.off_gend:hdr.off_gend + 8] = torch.tensor([0xff] * 8, dtype=torch.uint8, device=DEV)
+    bad[hdr.off_gdir:hdr.off_gdir + 8] = torch.tensor([0xff] * 8, dtype=torch.uint8, device=DEV)
     ctx.decode_chunks(bad.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
     torch.cuda.synchronize()
     assert ctx.status(clear=True) & 4
@@ -524,7 +529,7 @@ def test_fuzzed_blobs_never_fault_and_are_flagged(nat, ctx):
     flagged = 0
     for it in range(40):
         bad = blob_dev.clone()
-        lo = (hdr.off_scales, hdr.off_cdf, hdr.off_streams)[it % 3]
+        lo = (hdr.off_scales, hdr.off_gdir, hdr.off_streams)[it % 3]
         npos = int(torch.randint(1, 17, (1,), generator=g))
         pos = torch.randint(lo, total, (npos,), generator=g)
         if it % 5 == 4:  # a run of garbage instead of single bytes

@@ -159,12 +159,14 @@ def test_c_abi_exports_every_declared_symbol():
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(lmc_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"lmc_r16", "lmc_blob_layout", "lmc_group_cap_bytes", "lmc_blob_bound"}  # static inline (lmc_format.h)
+    declared -= {n for n in declared if n not in native.SYMBOLS and re.search(r"static inline[^;{]*\b" + n + r"\s*\(",
+                 open(os.path.join(ROOT, "include", "lmc_format.h")).read())}
     assert declared == set(native.SYMBOLS), declared ^ set(native.SYMBOLS)
     L = native.lib()  # raises if any symbol is missing
     out = subprocess.check_output(["nm", "-D", "--defined-only", native.SO_PATH], text=True)
     exported = set(re.findall(r" T (lmc_[a-z0-9_]+)", out))
     assert declared <= exported
-    assert L.lmc_abi_version() == 5
+    assert L.lmc_abi_version() == 6
     assert L.lmc_strerror(-1).decode().startswith("invalid")
 
 
@@ -248,9 +250,10 @@ def test_pipelined_remote_backend_keeps_one_result_per_key():
 
 @pytest.mark.parametrize("T", [256, 255, 300, 1])
 def test_blob_counts_section_rebuilds_the_reference_cdf(oracle, T):
-    """Format v3 stores symbol COUNTS (one byte for T <= 256, a count of 256 saturating to 255) and the CDF is a
-    function of them: the numpy rebuild of CacheGenEncoderOutput.cdf and the oracle's C rebuild must both give the
-    CDF computed from the symbols, including channels whose every token carries the same symbol."""
+    """The blob stores symbol COUNTS (format v6: bit-sliced in the head of every group stream; for T <= 256 a count of
+    256 saturates to 255) and the CDF is a function of them: the numpy rebuild of CacheGenEncoderOutput.cdf and the
+    oracle's C rebuild must both give the CDF computed from the symbols, including channels whose every token carries
+    the same symbol."""
     from lmcache_amd import native
     from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenEncoderOutput
     torch.manual_seed(T)
@@ -262,17 +265,17 @@ def test_blob_counts_section_rebuilds_the_reference_cdf(oracle, T):
     bins = np.array([32, 16, 32, 16], np.int32)
     blob = oracle.encode_blob(bits, code, H, D, bins)
     h = native.blob_info(blob)
-    assert h.version == 5 and h.count_bytes == (1 if T <= 256 else 2) and h.model == (1 if T == 256 else 0)
-    assert h.off_gend - h.off_cdf == native.r16(h.count_bytes * H * D * sum(int(b) - 1 for b in bins))
-    assert native.blob_static_bytes(L, T, H, D, bins) == h.off_streams
+    assert h.version == 6 and h.model == (1 if T == 256 else 0)
+    assert h.off_streams - h.off_gdir == native.r16(8 * 2 * L * ((H * D + 63) // 64))
+    assert native.blob_static_bytes(L, T, H, D) == h.off_streams
     sym, _ = oracle.quantize(bits, code, bins)
     want = oracle.cdf(sym)
     assert np.array_equal(CacheGenEncoderOutput.from_bytes(blob).cdf.numpy().view(np.uint16), want)
     assert np.array_equal(oracle.blob_cdf(blob), want)
     assert np.array_equal(oracle.decode_blob_symbols(blob), sym)
-    if T == 256:  # the saturated count is really there
-        sec = np.frombuffer(blob, np.uint8, count=H * D * 31, offset=h.off_cdf).reshape(31, H * D).T  # [symbol][channel]
-        assert sec[5].max() == 255 and sec[5].sum() == 255
+    if T == 256:  # the saturated count is really there: channel 5 of plane 0 = lane 5 of its first stream
+        _, cnt, _ = oracle.stream_head(blob, 0)
+        assert cnt[:, 5].max() == 255 and cnt[:, 5].sum() == 255
 
 
 def test_divmod_small_is_exact_for_every_row_length():

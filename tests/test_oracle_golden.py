@@ -146,7 +146,7 @@ def test_blob_roundtrip_random_geometries(oracle):
         assert len(blob) <= oracle.blob_bound(L, T, H, D)
         # the scales carry a per-plane checksum (format v4): a flipped scale bit, or a flipped checksum bit, fails
         h = oracle.parse_header(blob)
-        assert h["version"] == 5 and h["off_scsum"] == h["off_scales"] + ((2 * 2 * L * T + 15) & ~15)
+        assert h["version"] == 6 and h["off_scsum"] == h["off_scales"] + ((2 * 2 * L * T + 15) & ~15)
         for where in (h["off_scales"] + int(rng.integers(0, 2 * 2 * L * T)), h["off_scsum"] + int(rng.integers(0, 8 * L))):
             bad = bytearray(blob)
             bad[where] ^= 1 << int(rng.integers(0, 8))
@@ -178,3 +178,98 @@ def test_rans_magic_gives_the_exact_quotient_for_every_count(oracle):
         xs = xs[xs < np.uint64(2**31)]
         q = ((xs * np.uint64(magic)) >> np.uint64(32)) >> np.uint64(shift)
         assert np.array_equal(q, xs // np.uint64(f)), count
+
+
+def test_counts_bound_table_and_adversarial_streams(oracle):
+    """Format v6 places a counts-model stream BEFORE it is coded, in an allocation computed from the channels' counts
+    (lmc_format.h: lmc_counts_bits, lmc_counts_lane_words, lmc_counts_alloc_bytes).  (1) the table is what its comment says; (2) the bound
+    holds -- lmco_encode_blob fails if a stream outgrows its allocation -- on channels built to stress it: one
+    dominant symbol (the state idles near 2^15, where the per-step excess is largest), symbols in sorted order (every
+    renormalisation pattern a lane can have), two-symbol and constant channels; (3) the slack it costs on iid data
+    stays below 1.5 % of the streams."""
+    import math, re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "include", "lmc_format.h")).read()
+    body = re.search(r"#define LMC_COUNTS_BITS_LIST(.*?)\nstatic const", src, re.S).group(1)
+    tab = [int(v) for v in body.replace("\\", " ").replace("\n", " ").split(",")]
+    assert len(tab) == 257 and tab[0] == 0 and tab[256] == 0
+    for c in range(1, 256):
+        bits = c * math.log2(256 / c) + c * math.log2(1 + 2 * c / 32768)
+        assert tab[c] == math.ceil(256 * bits) + 1, c
+    rng = np.random.default_rng(11)
+    L, T, H, D = 1, 256, 1, 64
+    bins = np.array([32, 16], np.int32)
+
+    def encode_symbols(sym_k, sym_v):
+        # KV whose quantised symbols are exactly the wanted ones: x = (s - M) with one full-scale element per row
+        out = np.zeros((L, 2, T, H * D), np.float32)
+        for kv, (sy, b) in enumerate(((sym_k, 32), (sym_v, 16))):
+            M = b // 2 - 1
+            out[0, kv] = (sy.astype(np.float32) - M)
+            out[0, kv, :, 0] = M  # row max = M: factor 1, symbol of lane 0 is 2 M
+        import torch
+        kvt = torch.from_numpy(out).to(torch.bfloat16)
+        bits, code = oracle.torch_to_bits(kvt)
+        blob = oracle.encode_blob(bits, code, H, D, bins)   # asserts rc == 0: no stream outgrew its allocation
+        sym, _ = oracle.quantize(bits, code, bins)
+        assert np.array_equal(oracle.decode_blob_symbols(blob), sym)
+        return blob
+
+    cases = []
+    for dom in (1, 2, 3, 5, 9, 17, 40, 100, 200, 254):          # `dom` rare tokens, the rest one symbol
+        for order in ("front", "back", "spread"):
+            s = np.full((T, 64), 7, np.int64)
+            idx = {"front": np.arange(dom), "back": np.arange(T - dom, T),
+                   "spread": np.linspace(0, T - 1, dom).astype(int)}[order]
+            s[idx] = rng.integers(0, 14, (len(idx), 64))
+            cases.append(s)
+    for k in (2, 3, 5, 8, 14):                                   # k symbols, sorted either way / random
+        base = rng.integers(0, k, (T, 64))
+        cases += [np.sort(base, axis=0), np.sort(base, axis=0)[::-1].copy(), base]
+    cases.append(np.zeros((T, 64), np.int64))
+    for s in cases:
+        s = np.clip(s, 0, 14)
+        encode_symbols(np.clip(s * 2, 0, 30), s)
+    # slack of the bound on iid symbols
+    s = rng.integers(0, 15, (T, 64))
+    blob = encode_symbols(s * 2, s)
+    h = oracle.parse_header(blob)
+    gdir = oracle.stream_dir(blob)
+    used = int((gdir[:, 1] - gdir[:, 0]).sum())
+    assert used <= h["stream_bytes"] <= used * 1.015 + 32
+    # every stream begins where the allocations in front of it end, and what lies between a stream and the next is zero
+    raw = np.frombuffer(blob, np.uint8, h["stream_bytes"], h["off_streams"])
+    ends = np.concatenate([gdir[1:, 0], [h["stream_bytes"]]])
+    assert gdir[0, 0] == 0 and (gdir[:, 0] % 16 == 0).all() and (gdir[:, 1] <= ends).all()
+    assert all(not raw[e:n].any() for e, n in zip(gdir[:, 1], ends))
+
+
+def test_stream_head_is_the_bit_sliced_counts(oracle):
+    """lmc_format.h "head": widths = significant bits of the largest stored count of a symbol over the 64 lanes, the
+    counts as 8-byte bit planes, most significant first; a count of 256 is stored as 255 (T <= 256); idle lanes store 0;
+    T > 256 takes wider planes.  Parsed here in numpy, independently of the C parser."""
+    import torch
+    rng = np.random.default_rng(3)
+    for T, H, D, bins in ((256, 1, 72, [32, 16]), (256, 2, 64, [16, 8]), (300, 1, 64, [32, 4]), (7, 1, 8, [6, 32])):
+        L = 1
+        x = rng.standard_normal((L, 2, T, H * D)).astype(np.float32)
+        x[:, :, :, 1] = 1.0   # a constant channel: count T on one symbol
+        kv = torch.from_numpy(x).to(torch.bfloat16)
+        bits, code = oracle.torch_to_bits(kv)
+        blob = oracle.encode_blob(bits, code, H, D, np.array(bins, np.int32))
+        sym, _ = oracle.quantize(bits, code, np.array(bins, np.int32))
+        h = oracle.parse_header(blob)
+        G, C = h["ngroups"], H * D
+        gdir = oracle.stream_dir(blob)
+        for pg in range(2 * G):
+            p, g = divmod(pg, G)
+            R = bins[p] - 1
+            widths, cnt, hb = oracle.stream_head(blob, pg)
+            want = np.zeros((R, 64), np.int64)
+            for lane in range(64):
+                c = g * 64 + lane
+                if c < C:
+                    want[:, lane] = np.bincount(sym[p, :, c].astype(np.int64), minlength=R)[:R]
+            stored = np.where((want > 255) & (T <= 256), 255, want)
+            assert np.array_equal(cnt, stored), (T, pg)
+            assert np.array_equal(widths, [int(v).bit_length() for v in stored.max(axis=1)]), (T, pg)
+            assert hb % 16 == 0 and gdir[pg, 1] - gdir[pg, 0] >= hb + 256
