@@ -105,29 +105,32 @@ def load_latest_profile():
 # ---------------------------------------------------------------------------------------------- CPU baselines
 def cpu_baseline(nchunks_sample):
     """The CPU oracle (port of the reference's quantise + CDF + our entropy coder) timed on the host cores over a
-    bounded sample of the same workload, and beside it the reference's own formula (torch_quant_vectorized +
-    do_dequantize, cachegen_encoder.py:40-61 / cachegen_decoder.py:24-35) as CPU torch ops."""
+    bounded sample of the same workload, ONE CHUNK PER CORE (lmco_encode_blobs_parallel: a 16 k context is 64
+    independent chunks, a store of several contexts any number of them), and beside it the reference's own formula
+    (torch_quant_vectorized + do_dequantize, cachegen_encoder.py:40-61 / cachegen_decoder.py:24-35) as CPU torch ops."""
     from oracle import lmc_oracle as orc
     orc.build()
     ncores = len(os.sched_getaffinity(0))
-    # the oracle parallelises inside one chunk (64 planes, then 1024 group streams): on a many-core host several
-    # chunks are encoded at once, each by its own OpenMP team, so that every core has work
-    workers = 4 if ncores >= 32 else 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, ncores // workers)))
+    threads = orc.set_threads(ncores)
     g = torch.Generator().manual_seed(0)
     kv = torch.rand((L, 2, CHUNK, H * D), generator=g).to(torch.bfloat16)
     bits, code = orc.torch_to_bits(kv)
     bins = np.array(cachegen_bins_llama8b(), np.int32)
-    orc.encode_blob(bits, code, H, D, bins)  # warm
-    from concurrent.futures import ThreadPoolExecutor
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=workers) as pool:  # the ctypes call releases the GIL
-        list(pool.map(lambda _: orc.encode_blob(bits, code, H, D, bins), range(nchunks_sample)))
+    orc.encode_blobs_parallel(bits, code, H, D, bins, 1)  # warm, and what ONE core takes for a chunk
+    one = time.perf_counter() - t0
+    # rounds of one chunk per thread until the sample is spent or ~20 s have gone
+    per_round = max(1, min(threads, nchunks_sample))
+    done, t0 = 0, time.perf_counter()
+    while done < nchunks_sample and (done == 0 or time.perf_counter() - t0 < 20.0):
+        orc.encode_blobs_parallel(bits, code, H, D, bins, per_round)
+        done += per_round
     dt = time.perf_counter() - t0
-    raw = kv.numel() * 2 * nchunks_sample
-    out = {"value": round(raw / dt / 1e9, 4), "unit": "GB/s", "cores": ncores, "kind": "port",
-           "sample": f"{nchunks_sample} chunks of 256 tokens (Llama-3-8B shape, {raw / 1e6:.0f} MB raw KV), "
-                     f"oracle/lmc_oracle.c lmco_encode_blob, {workers} chunks at a time x OpenMP over planes/groups"}
+    raw = kv.numel() * 2 * done
+    out = {"value": round(raw / dt / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
+           "one_chunk_one_core_s": round(one, 3),
+           "sample": f"{done} chunks of 256 tokens (Llama-3-8B shape, {raw / 1e6:.0f} MB raw KV) in rounds of {per_round}, "
+                     f"oracle/lmc_oracle.c lmco_encode_blobs_parallel: one chunk per OpenMP thread, {threads} threads"}
     out["reference_formula"] = cpu_reference_formula(kv)
     out["torch_serde"] = cpu_torch_serde()
     return out
@@ -190,7 +193,9 @@ def cpu_reference_formula(kv_chunk):
         for kvi in range(2):
             for l in range(L):
                 t = x[l, kvi]                                  # [T, C] bf16
-                MAX = bins[kvi * L + l] // 2 - 1
+                # the reference's bins are a float32 tensor (torch.zeros(n).fill_(..), cachegen_encoder.py:339-350), so
+                # MAX is fp32 [.., 1, 1] and MAX / max1 and x * factor are fp32 (cachegen_encoder.py:54-59)
+                MAX = torch.tensor(float(bins[kvi * L + l] // 2 - 1), dtype=torch.float32).reshape(1, 1)
                 max1 = torch.amax(torch.abs(t), dim=-1, keepdim=True)
                 q = torch.round(t * (MAX / max1) + MAX).to(torch.int8)
                 d = ((q.float() - MAX) / MAX) * max1.float()
@@ -362,6 +367,11 @@ def main(argv=None):
                     help="synthetic KV distribution of the timed workload (SURVEY.md section 8d)")
     ap.add_argument("--ramp-ms", type=float, default=250.0,
                     help="untimed clock ramp before the warm-up steps: full steps for this many ms (0 = none)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every rank encodes a 16 k context of its own (the default, what the driver's per-N "
+                         "values assume); strong = ONE 16 k context, rank r takes chunks r, r + N, ... (SURVEY.md 8e: the "
+                         "replicated-instance split, lmcache_amd.distributed.shard_chunks), value = the context's bytes / "
+                         "max-over-ranks time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region and the roofline")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the cpu_baseline sample (0 = auto)")
@@ -398,6 +408,11 @@ def main(argv=None):
     dev = torch.device("cpu") if STUB else torch.device(f"cuda:{local_rank}")
     raw_bytes = L * 2 * CTX * H * D * 2
     nchunks = CTX // CHUNK
+    strong = args.scaling == "strong" and world > 1
+    from lmcache_amd.distributed import shard_chunks
+    my_chunks = shard_chunks(nchunks, rank, world) if strong else list(range(nchunks))
+    # how many ranks the process group's backend really spans (an all_reduce of ones: on the GPU box that is RCCL)
+    ranks_seen = int(round(sum_over_ranks(1.0, dev))) if use_dist else 1
 
     def sync():
         if not STUB:
@@ -415,7 +430,7 @@ def main(argv=None):
         from lmcache_amd import native
         ctx = native.get_context(local_rank)
         bins = cachegen_bins_llama8b()
-        kv = make_kv(dev, rank, args.dist)
+        kv = make_kv(dev, 0 if strong else rank, args.dist)  # strong: every rank holds the SAME context
         layout = native.KVLayout.from_kv_tuple(kv, "vllm")
         stride = native.r16(native.blob_bound(L, CHUNK, H, D))
         blobs = torch.empty(nchunks * stride, dtype=torch.uint8, device=dev)
@@ -424,8 +439,14 @@ def main(argv=None):
         stream = torch.cuda.Stream(device=dev)
         sp = stream.cuda_stream
 
-        def step():
-            ctx.encode_chunks(layout, 0, CTX, CHUNK, bins, blobs.data_ptr(), stride, sizes.data_ptr(), stream=sp)
+        if strong:
+            def step():  # this rank's chunks of the shared context: i mod world == rank, one job per chunk
+                for k, i in enumerate(my_chunks):
+                    ctx.encode_chunks(layout, i * CHUNK, (i + 1) * CHUNK, CHUNK, bins, blobs.data_ptr() + k * stride, stride,
+                                      sizes.data_ptr() + 4 * k, stream=sp)
+        else:
+            def step():
+                ctx.encode_chunks(layout, 0, CTX, CHUNK, bins, blobs.data_ptr(), stride, sizes.data_ptr(), stream=sp)
 
     # Clock ramp, before the W warm-up steps and outside every timed region: a GPU that has just left idle runs its
     # first ~50 ms of work below its sustained clock (tools/probes/encode_ab.hip, alternating rounds: the first 40
@@ -465,17 +486,21 @@ def main(argv=None):
         ctx.raise_on_status("bench")
     elapsed = max_over_ranks(elapsed, dev)
     ms_per_step = elapsed * 1e3 / args.steps
-    value = world * raw_bytes * args.steps / elapsed / 1e9
+    # weak: every rank encoded a context of its own; strong: all ranks together encoded ONE context
+    value = (1 if strong else world) * raw_bytes * args.steps / elapsed / 1e9
 
     res = {"metric": "KV encode+offload GB/s per GPU -- value = CacheGen encode, HBM -> HBM (raw 16-bit KV bytes consumed, "
                      "PCIe never inside value); the PCIe-inclusive encode+offload rate is offload.encode_plus_offload_GBps_raw_kv",
            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+           "vs_baseline": None, "rccl_ranks_seen": ranks_seen,
            "dtype": "bf16->u8 symbols (fp32 quantise, u32 rANS)", "data": f"synthetic ({args.dist})",
            "config": {"workload": "Llama-3-8B bf16 KV, 16384-token context, CacheGen encode, chunk_size=256 "
                                   "(BASELINE configs[1])",
                       "layers": L, "kv_heads": H, "head_dim": D, "context_tokens": CTX, "chunk_tokens": CHUNK,
-                      "chunks": nchunks, "raw_kv_bytes": raw_bytes, "sharding": f"{world} x independent contexts",
+                      "chunks": nchunks, "raw_kv_bytes": raw_bytes,
+                      "sharding": (f"one context, chunks i mod {world} == rank ({len(my_chunks)} chunks on rank 0)" if strong
+                                   else f"{world} x independent contexts"),
                       "numa_node": numa},
            "clock_ramp": {"untimed_steps_before_warmup": ramp_steps, "ms": args.ramp_ms,
                           "why": "a GPU fresh out of idle runs its first ~50 ms below its sustained clock; W + K steps "
@@ -513,7 +538,7 @@ def main(argv=None):
     sz = sizes.cpu().numpy().astype(np.int64)
     blob_bytes = int(sz.sum())
     # algorithmic bytes per step (with OUR container): raw KV read once + blobs written once
-    algo_bytes = raw_bytes + blob_bytes
+    algo_bytes = raw_bytes * len(my_chunks) // nchunks + blob_bytes  # (strong scaling: this rank's share of the context)
 
     # per-kernel HIP-event timing on the launch stream (lmc_ctx_profile).  At this size lmc_encode_chunks launches
     # the fused kernel (one entry); k_quantize + k_cdf_encode is timed beside it as `encode_paths` below.
@@ -553,17 +578,37 @@ def main(argv=None):
                         "(FETCH_SIZE doubled for the 16-B/lane streams per MI355X_MICROARCH.md)"}
     res["roofline"] = roofline
     res["encode_paths"] = encode_paths_ab(ctx, step, stream, max(5, min(20, args.steps)))
+    # what ONE store() out of idle costs (the timed region above is steady state: the clock ramp is outside it)
+    cold = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(stream)
+        step()
+        c1.record(stream)
+        torch.cuda.synchronize()
+        cold.append(round(c0.elapsed_time(c1), 4))
+    res["cold_single_store_ms"] = {"median": median(cold), "runs": cold,
+                                   "note": "one lmc_encode_chunks of the whole context after 1 s of idle GPU (HIP events on "
+                                           "the launch stream): the clock ramp and the launch's first and last generation "
+                                           "of workgroups are all inside; ms_per_step is the steady state"}
 
     if not args.no_extras and world == 1:  # the single-GPU legs (store / retrieve / TTFT proxies, other geometries)
         extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, stream, sp, raw_bytes, blob_bytes,
                algo_bytes, gpu_ms_per_step)
+    if isinstance(res.get("offload"), dict) and "encode_plus_offload_GBps_raw_kv" in res["offload"]:
+        # the metric's PCIe-inclusive form next to `value` (encode, then every blob over PCIe into pinned host DRAM)
+        res["value_with_offload"] = {"GBps_raw_kv": res["offload"]["encode_plus_offload_GBps_raw_kv"],
+                                     "GBps_blob_over_pcie": res["offload"]["pcie_GBps_blob"],
+                                     "ms_per_context": res["offload"]["ms_per_context"]}
     if offload_all is not None:
         res["offload_all_ranks"] = offload_all
     if exchange is not None:
         res["exchange"] = exchange
     if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line
         os.sched_setaffinity(0, cpus_before)  # the CPU baseline gets every host core, not only the GPU's NUMA node
-        res["cpu_baseline"] = cpu_baseline(args.cpu_chunks or 128)
+        res["cpu_baseline"] = cpu_baseline(args.cpu_chunks or 4 * len(os.sched_getaffinity(0)))
     print(json.dumps(res))
     if use_dist:
         dist.barrier()

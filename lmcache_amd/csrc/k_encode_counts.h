@@ -111,12 +111,12 @@ struct CountsStream {
   const u32* symq;   // this lane's column of the plane-chunk's symbol workspace
   u32 R;             // symbols the plane's quantiser can emit
 };
-__device__ __forceinline__ CountsStream counts_stream_of(const EncodeArgs& a, long long gid, int lane) {
+// (chunk, p, g wave-uniform.  No division here: a 64-bit gid / G costs more than a hundred instructions.)
+__device__ __forceinline__ CountsStream counts_stream_of(const EncodeArgs& a, int chunk, int p, int g, int lane) {
   CountsStream s;
-  s.g = (int)(gid % a.G);
-  const long long pc = gid / a.G;
-  s.p = (int)(pc % a.P);
-  s.chunk = (int)(pc / a.P);
+  s.g = g;
+  s.p = p;
+  s.chunk = chunk;
   s.c = s.g * 64 + lane;
   s.active = s.c < a.C;
   s.symq = a.sym4 + ((long long)s.chunk * a.P + s.p) * a.sym_stride + s.c;
@@ -467,18 +467,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
   // below only ever waits for workgroups that are running already
   u32 item = blockIdx.x;
   if constexpr (ENCODE) item = (u32)__builtin_amdgcn_readfirstlane((int)draw_ticket(a.ticket, a.ticket_base));
-  long long gid = (long long)item * NW + wave;
-  if (ENCODE && (a.P * a.G) % NW == 0) {
-    const int wpc = a.P * a.G / NW;  // workgroups per chunk
-    const int ch = (int)(item % (unsigned)a.nchunks), pos = (int)(item / (unsigned)a.nchunks);
-    gid = ((long long)ch * wpc + pos) * NW + wave;
+  // stream = (chunk_i, pg_i), pg_i = p * G + g; all 32-bit (nchunks <= 65535, P * G <= 2^14): a 64-bit division costs
+  // more than a hundred instructions
+  const u32 npg = (u32)(a.P * a.G);
+  u32 chunk_i, pg_i;
+  if (ENCODE && npg % NW == 0) {
+    chunk_i = item % (unsigned)a.nchunks;
+    pg_i = (item / (unsigned)a.nchunks) * NW + (u32)wave;
+  } else {
+    const u32 lin = item * NW + (u32)wave;
+    chunk_i = lin / npg;
+    pg_i = lin - chunk_i * npg;
   }
+  const long long gid = (long long)chunk_i * npg + pg_i;
   if (gid >= ngroups_total) return;
   PendingTile t;
   u16* const wring = reinterpret_cast<u16*>(lds_all + wave * (ENC_RING_DWORDS));
   u32 alloc = 0;  // the stream's allocation in the blob
   auto counts_stream = [&]() {
-    const CountsStream s = counts_stream_of(a, gid, lane);
+    const u32 p_i = pg_i / (u32)a.G;
+    const CountsStream s = counts_stream_of(a, (int)chunk_i, (int)p_i, (int)(pg_i - p_i * (u32)a.G), lane);
     CountsState cs;
     alloc = counts_hist_stream(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
     u8* const slot = a.scratch + gid * (long long)a.cap;
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
     counts_stream();
   } else if constexpr (ENCODE && QUADSYM) {
     // 256-token chunks are coded on their symbol counts (LMC_MODEL_COUNTS), every other length on the 16-bit CDF
-    const int chunk_of = (int)(gid / ((long long)a.P * a.G));
+    const int chunk_of = (int)chunk_i;
     const bool counts_model =
         min(a.chunk_tokens, a.tok_end - (a.tok_begin + chunk_of * a.chunk_tokens)) == (int)LMC_COUNTS_T;  // wave-uniform
     if (counts_model) counts_stream();

@@ -291,11 +291,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   __syncthreads();  // symbols and scales of the plane-chunk are visible to the workgroup
 
   // ---- pass 1: the counts of this wave's group streams, and from them the streams' allocations ----------------
-  const long long gid0 = ((long long)chunk * a.P + p) * a.G;
   CountsState cs0, cs1;  // of stream `wave`, and of stream `wave + NW`
   auto pass1 = [&](int g, CountsState& cs) {
     if (g < a.G) {  // wave-uniform
-      const CountsStream s = counts_stream_of(a, gid0 + g, lane);
+      const CountsStream s = counts_stream_of(a, chunk, p, g, lane);
       const u32 alloc = counts_hist_stream(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
       if (lane == 0) st_alloc[g] = alloc;
     }
@@ -326,7 +325,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       u32 beg = wg_excl;
       for (int j = 0; j < g; j++) beg += st_alloc[j];
       const u32 alloc = st_alloc[g];
-      const CountsStream s = counts_stream_of(a, gid0 + g, lane);
+      const CountsStream s = counts_stream_of(a, chunk, p, g, lane);
       u8* const out = blob + bo.streams + beg;
       counts_open_stream(s, cs, out, hist, lane);
       const u32 exact = cs.head + counts_code_stream<true>(a, s, hist, ring, rtab_lds, lane, reinterpret_cast<u16*>(out + cs.head));

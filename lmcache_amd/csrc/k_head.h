@@ -11,23 +11,27 @@
 #include "lmc_device.h"
 
 // v_writelane_b32: lane `sel` of `old` <- the wave-uniform `val`.  Data and lane select are both scalar operands and
-// gfx9 reads one SGPR per VALU instruction, so the select travels in M0 (saved and restored: the compiler keeps its own
-// values there, e.g. the LDS base of global_load_lds); the s_nop covers the wait states a lane select needs behind a
-// write of its register (the compiler does not look inside the block).
-__device__ __forceinline__ int writelane_i32(int val, u32 sel, int old) {
-  u32 keep;
-  asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-      : "+v"(old), "=&s"(keep)
-      : "s"(__builtin_amdgcn_readfirstlane(val)), "s"(__builtin_amdgcn_readfirstlane((int)sel)));
+// gfx9 reads one SGPR per VALU instruction, so a select that is not a constant travels in M0 (saved and restored: the
+// compiler keeps its own values there, e.g. the LDS base of global_load_lds).
+template <int SEL>
+__device__ __forceinline__ int writelane_const(int val, int old) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(__builtin_amdgcn_readfirstlane(val)), "n"(SEL));
   return old;
 }
-__device__ __forceinline__ void writelane2_i32(u64 val, u32 sel, int& lo, int& hi) {
+// One bit plane: vcc = the top bits of t over the lanes (the carry of t + t, which also moves the next bit up), and
+// lane `sel` of {lo, hi} <- vcc.
+__device__ __forceinline__ void plane_step(u32& t, u32 sel, int& lo, int& hi) {
   u32 keep;
-  asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\ts_nop 3\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\t"
-      "s_mov_b32 m0, %2"
-      : "+v"(lo), "+v"(hi), "=&s"(keep)
-      : "s"(__builtin_amdgcn_readfirstlane((int)(u32)val)), "s"(__builtin_amdgcn_readfirstlane((int)(u32)(val >> 32))),
-        "s"(__builtin_amdgcn_readfirstlane((int)sel)));
+  asm volatile("s_mov_b32 %[k], m0\n\t"
+               "s_mov_b32 m0, %[sel]\n\t"
+               "v_add_co_u32_e32 %[t], vcc, %[t], %[t]\n\t"
+               "s_nop 0\n\t"
+               "v_writelane_b32 %[lo], vcc_lo, m0\n\t"
+               "v_writelane_b32 %[hi], vcc_hi, m0\n\t"
+               "s_mov_b32 m0, %[k]"
+               : [t] "+v"(t), [lo] "+v"(lo), [hi] "+v"(hi), [k] "=&s"(keep)
+               : [sel] "s"(__builtin_amdgcn_readfirstlane((int)sel))
+               : "vcc");
 }
 
 // Significant bits of the wave-uniform value v (0 for 0).
@@ -77,13 +81,11 @@ __device__ __forceinline__ u32 head_write(u8* out_v, const u32 (&pk)[NREG], cons
   static_for<NSYM>([&](auto itag) {  // (a compile-time loop: pk and wor stay in registers)
     constexpr int i = decltype(itag)::value;
     const u32 w = (u32)i < R ? field_width<FB, NREG>(wor, i) : 0u;  // uniform
-    wv = writelane_i32((int)w, (u32)i, wv);
+    wv = writelane_const<i>((int)w, wv);
     u32 t = ((pk[i / PER] >> (FB * (i % PER))) & ((1u << FB) - 1u)) << ((32u - w) & 31u);  // the field's top bit at bit 31
 #pragma unroll 1
     for (u32 b = 0; b < w; b++) {
-      const u64 m = __ballot((int)t < 0);
-      t <<= 1;
-      writelane2_i32(m, j & 63u, lo, hi);
+      plane_step(t, j & 63u, lo, hi);
       j++;
       if ((j & 63u) == 0u) planes[j - 64u + (u32)lane] = u32x2_t{(u32)lo, (u32)hi};
     }

@@ -56,6 +56,10 @@ def lib() -> ctypes.CDLL:
         L.lmco_decode_group.restype = i32
         L.lmco_encode_blob.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, sz, vp]
         L.lmco_encode_blob.restype = i32
+        L.lmco_set_threads.argtypes = [i32]
+        L.lmco_set_threads.restype = i32
+        L.lmco_encode_blobs_parallel.argtypes = [vp, sz, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp]
+        L.lmco_encode_blobs_parallel.restype = i32
         L.lmco_blob_cdf.argtypes = [vp, sz, vp]
         L.lmco_blob_cdf.restype = i32
         L.lmco_decode_blob_symbols.argtypes = [vp, sz, vp]
@@ -175,6 +179,26 @@ def encode_blob(kv_bits: np.ndarray, dtype: int, H: int, D: int, bins: np.ndarra
                                 cap, ctypes.byref(nbytes))
     assert rc == 0, f"lmco_encode_blob rc={rc}"
     return blob[:nbytes.value].tobytes()
+
+
+def set_threads(n: int) -> int:
+    """OpenMP threads for the calls that follow (0: leave as is); returns what a parallel region will get."""
+    return int(lib().lmco_set_threads(n))
+
+
+def encode_blobs_parallel(kv_bits: np.ndarray, dtype: int, H: int, D: int, bins: np.ndarray, n: int) -> List[int]:
+    """The same chunk n times, one chunk per OpenMP thread (OMP_NUM_THREADS): the CPU baseline's timed call.
+    Returns the blob sizes."""
+    L, two, T, C = kv_bits.shape
+    assert two == 2 and C == H * D
+    bins = np.ascontiguousarray(bins, dtype=np.int32)
+    stride = (blob_bound(L, T, H, D) + 63) & ~63
+    blobs = np.empty(n * stride, np.uint8)
+    sizes = np.zeros(n, np.uint64)
+    rc = lib().lmco_encode_blobs_parallel(_p(np.ascontiguousarray(kv_bits)), 0, dtype, L, T, H, D, _p(bins), n, _p(blobs),
+                                          stride, _p(sizes))
+    assert rc == 0, f"{rc} chunks failed"
+    return sizes.astype(np.int64).tolist()
 
 
 def parse_header(blob: bytes) -> dict:

@@ -147,6 +147,33 @@ def test_bench_launch_plumbing_world2_stub():
     raw = 32 * 2 * 16384 * 8 * 128 * 2
     assert abs(r["value"] - 2 * raw * 4 / (r["ms_per_step"] * 4 / 1e3) / 1e9) / r["value"] < 1e-3
     assert 2.0 <= r["ms_per_step"] < 50.0
+    assert r["rccl_ranks_seen"] == 2
+
+
+def test_bench_launch_plumbing_world8_strong_stub():
+    """The same rehearsal at the size of the node the driver's scaling run uses -- 8 ranks -- with SURVEY.md 8e's own
+    split (--scaling strong: ONE context, rank r takes chunks r, r + 8, ...): every rank of the process group is seen
+    by the all_reduce, and value is the context's bytes over the max-over-ranks time."""
+    import json
+    import subprocess
+    port = 27700 + os.getpid() % 2000
+    env = dict(os.environ, LMC_BENCH_STUB="1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "8", "--steps", "3", "--warmup", "1", "--scaling", "strong"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["rccl_ranks_seen"] == 8
+    assert "chunks i mod 8 == rank (8 chunks on rank 0)" in r["config"]["sharding"]
+    raw = 32 * 2 * 16384 * 8 * 128 * 2
+    assert abs(r["value"] - raw * 3 / (r["ms_per_step"] * 3 / 1e3) / 1e9) / r["value"] < 1e-3
+
+
+def test_shard_exchange_world8():
+    assert _run_world(_exchange_worker, 8, 35533 + os.getpid() % 2000) == list(range(8))
 
 
 def test_numa_topology_helpers(tmp_path):
