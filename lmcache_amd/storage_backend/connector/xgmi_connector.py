@@ -65,7 +65,11 @@ _RECS_OFF = _HDR_BYTES + 16 * _MAX_RANKS
 _REC = struct.Struct("<IIQQQII")      # state, owner, offset, size, capacity, key length, arena generation  (+ key bytes)
 _REC_BYTES = 256                      # one directory record: 40 B of fields + up to 216 B of key
 _KEY_MAX = _REC_BYTES - _REC.size
-_EMPTY, _FULL, _DEAD = 0, 1, 2        # _DEAD: a retired record (its arena is gone); probing walks past it
+_EMPTY, _FULL, _DEAD, _PENDING = 0, 1, 2, 3  # _DEAD: a retired record (its arena is gone, or its writer failed): probing
+                                      # walks past it and an insertion may take it.  _PENDING: a new key whose first
+                                      # bytes are on their way -- a miss for readers; its `size` field holds the
+                                      # writer's stamp (pid << 32 | seconds) so that a writer that died can be replaced
+_PENDING_TIMEOUT_S = 20
 SHM_DIR = "/dev/shm"
 
 # export record of a CUDA arena: magic, version, generation, device, storage bytes, storage offset, ref-counter
@@ -169,7 +173,7 @@ class XgmiConnector(RemoteConnector):
             for slot in range(self.nslots):
                 off = self._rec_off(slot)
                 state, owner = struct.unpack_from("<II", self._dir, off)
-                if state == _FULL and owner == self.rank:
+                if state in (_FULL, _PENDING) and owner == self.rank:
                     struct.pack_into("<I", self._dir, off, _DEAD)
         if self.device.type == "cuda":
             arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=self.device)
@@ -269,25 +273,57 @@ class XgmiConnector(RemoteConnector):
         return _RECS_OFF + slot * _REC_BYTES
 
     def _find(self, key: str) -> Tuple[Optional[tuple], int]:
-        """(record fields or None, slot index where the key is / would go).  Caller holds the lock."""
+        """(record fields or None, slot index where the key is / would go).  The fields are (owner, offset, size,
+        capacity, generation, state); an insertion goes to the first retired slot of the probe sequence if there is one,
+        else to the empty slot that ends it.  Caller holds the lock."""
         slot, kb = self._slot_of(key)
+        first_dead = None
         for _ in range(self.nslots):
             off = self._rec_off(slot)
             state, owner, offset, size, cap, klen, gen = _REC.unpack_from(self._dir, off)
             if state == _EMPTY:
-                return None, slot
-            if state == _FULL and klen == len(kb) and self._dir[off + _REC.size:off + _REC.size + klen] == kb:
-                return (owner, offset, size, cap, gen), slot
+                return None, slot if first_dead is None else first_dead
+            if state == _DEAD and first_dead is None:
+                first_dead = slot
+            if state in (_FULL, _PENDING) and klen == len(kb) and self._dir[off + _REC.size:off + _REC.size + klen] == kb:
+                return (owner, offset, size, cap, gen, state), slot
             slot = (slot + 1) % self.nslots
+        if first_dead is not None:
+            return None, first_dead
         raise RuntimeError(f"xgmi://{self.name}: directory full ({self.nslots} keys)")
+
+    @staticmethod
+    def _stamp() -> int:
+        return (os.getpid() << 32) | (int(time.time()) & 0xffffffff)
+
+    @staticmethod
+    def _stamp_is_stale(stamp: int) -> bool:
+        """The writer behind a pending record is gone (no such process on this node) or has held it for too long."""
+        pid, t = stamp >> 32, stamp & 0xffffffff
+        if ((int(time.time()) & 0xffffffff) - t) & 0xffffffff > _PENDING_TIMEOUT_S:
+            return True
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return True
+        except OSError:
+            pass
+        return False
 
     def _reserve(self, key: str, nbytes: int) -> Optional[Tuple[int, int, int, int, int]]:
         """A fresh extent of nbytes for `key` -> (owner, offset, slot, generation, capacity); the record points to it
-        (and the key becomes visible, or its new bytes do) with _publish once the bytes are in place.  None when
-        another writer holds the key unpublished.  Caller holds the lock."""
+        (and the key becomes visible, or its new bytes do) with _publish once the bytes are in place.  None when there
+        is nothing to write: another live writer holds the key unpublished, or the key is published with exactly this
+        many bytes (keys are content hashes, cache_engine.py:58-96: the bytes would be the same).  A pending record
+        whose writer died, or has not published for _PENDING_TIMEOUT_S, is taken over.  Caller holds the lock."""
         rec, slot = self._find(key)
-        if rec is not None and rec[2] == 0:
-            return None  # being written right now
+        if rec is not None:
+            if rec[5] == _PENDING and not self._stamp_is_stale(rec[2]):
+                return None  # being written right now
+            if rec[5] == _FULL and rec[2] == nbytes:
+                cur = struct.unpack_from("<Q", self._dir, _GEN_OFF + 8 * rec[0])[0] & 0xffffffff
+                if rec[4] == cur:
+                    return None  # already there
         owner = owner_rank(key, self.world) if rec is None else rec[0]
         gen = struct.unpack_from("<Q", self._dir, _GEN_OFF + 8 * owner)[0]
         if gen == 0:
@@ -299,12 +335,20 @@ class XgmiConnector(RemoteConnector):
             raise RuntimeError(f"xgmi://{self.name}: the arena of rank {owner} is full ({self.arena_bytes >> 20} MiB; "
                                f"LMC_XGMI_ARENA_MB sizes it)")
         struct.pack_into("<Q", self._dir, boff, used + cap)
-        if rec is None:  # a new key takes its slot now (size 0 reads as a miss)
+        if rec is None or rec[5] == _PENDING:  # a new key takes its slot now, pending (a miss for readers)
             kb = key.encode("utf-8")
             off = self._rec_off(slot)
             self._dir[off + _REC.size:off + _REC.size + len(kb)] = kb
-            _REC.pack_into(self._dir, off, _FULL, owner, used, 0, cap, len(kb), gen & 0xffffffff)
+            _REC.pack_into(self._dir, off, _PENDING, owner, used, self._stamp(), cap, len(kb), gen & 0xffffffff)
         return owner, used, slot, gen, cap
+
+    def _abandon(self, slot: int, offset: int) -> None:
+        """A write that failed between _reserve and _publish: a pending record (still ours: same extent) is retired so
+        that the key can be written again at once; a published record still points to its old bytes and stays."""
+        off = self._rec_off(slot)
+        state, _, roff, _, _, _, _ = _REC.unpack_from(self._dir, off)
+        if state == _PENDING and roff == offset:
+            struct.pack_into("<I", self._dir, off, _DEAD)
 
     def _publish(self, slot: int, offset: int, nbytes: int, cap: int, gen: int) -> None:
         off = self._rec_off(slot)
@@ -314,12 +358,12 @@ class XgmiConnector(RemoteConnector):
     def _lookup(self, key: str) -> Optional[tuple]:
         with self._locked():
             rec, _ = self._find(key)
-        if rec is None or rec[2] == 0:
+        if rec is None or rec[5] != _FULL or rec[2] == 0:
             return None
         # a record of an arena generation that is gone (its owner restarted and has not retired it yet) is a miss
         with self._locked():
             cur = struct.unpack_from("<Q", self._dir, _GEN_OFF + 8 * rec[0])[0] & 0xffffffff
-        return rec if rec[4] == cur else None
+        return rec[:5] if rec[4] == cur else None
 
     # ------------------------------------------------------------------ RemoteConnector
     def exists(self, key: str) -> bool:
@@ -399,14 +443,19 @@ class XgmiConnector(RemoteConnector):
                     raise RuntimeError(f"xgmi://{self.name}: rank {e.args[0]} never created its arena")
                 time.sleep(0.01)
         if res is None:
-            return  # another rank is writing this key right now: keys are content hashes, the bytes would be the same
+            return  # the key is there, or another rank is writing it right now: content hashes, the bytes would be the same
         owner, offset, slot, gen, cap = res
-        dst = self._arena(owner, gen)[offset:offset + n]
-        dst.copy_(blob)
-        if dst.is_cuda:  # the bytes must have landed before the entry becomes visible to the other ranks
-            torch.cuda.current_stream(self.device).synchronize()
-            if dst.device != self.device:
-                torch.cuda.current_stream(dst.device).synchronize()
+        try:
+            dst = self._arena(owner, gen)[offset:offset + n]
+            dst.copy_(blob)
+            if dst.is_cuda:  # the bytes must have landed before the entry becomes visible to the other ranks
+                torch.cuda.current_stream(self.device).synchronize()
+                if dst.device != self.device:
+                    torch.cuda.current_stream(dst.device).synchronize()
+        except BaseException:
+            with self._locked():
+                self._abandon(slot, offset)  # the key is not left "being written" for ever
+            raise
         with self._locked():
             self._publish(slot, offset, n, cap, gen)
 

@@ -51,10 +51,10 @@ class LMCHybridBackend(LMCBackendInterface):
     def contains(self, key: CacheEngineKey) -> bool:
         return self.local_store.contains(key) or self.remote_store.contains(key)
 
-    def put(self, key: CacheEngineKey, kv_chunk: torch.Tensor, blocking: bool = True) -> None:
+    def put(self, key: CacheEngineKey, value: torch.Tensor, blocking: bool = True) -> None:
         # write-through: the local copy is there when put returns, the remote one follows `blocking`
-        self.local_store.put(key, kv_chunk, blocking=True)
-        self.remote_store.put(key, kv_chunk, blocking)
+        self.local_store.put(key, value, blocking=True)
+        self.remote_store.put(key, value, blocking)
 
     @_lmcache_nvtx_annotate
     def get(self, key: CacheEngineKey) -> Optional[torch.Tensor]:

@@ -260,12 +260,17 @@ class LMCLocalBackend(LMCBackendInterface):
             T = entry.shape[2] if fmt == "vllm" else entry.shape[3]
             codec = self._codec()
             try:
-                blob = self._own_blob(entry) if isinstance(entry, _PackChunk) else entry.blob
-                codec.finish_decode(codec.decode([blob], native.KVLayout.from_chunk(out, fmt), 0, T))
+                lay = native.KVLayout.from_chunk(out, fmt)
+                if isinstance(entry, _PackChunk) and entry.pack.chunk_tokens >= T:
+                    # a chunk of a pack is read where it lies (lmc_load_pack over one chunk): nothing is reassembled on
+                    # the host, no pinned memory is taken
+                    with torch.cuda.device(dev):
+                        codec.finish_decode(codec.load_pack(entry.pack, entry.index, 1, lay, 0, None))
+                else:
+                    blob = self._own_blob(entry) if isinstance(entry, _PackChunk) else entry.blob
+                    codec.finish_decode(codec.decode([blob], lay, 0, T))
             except native.NativeError:
                 logger.exception("stored chunk does not decode: treated as a miss")
-                if isinstance(entry, _PackChunk):
-                    entry.blob = None  # reassembled again from the pack next time
                 return None
         else:
             cur = torch.cuda.current_stream(dev)
@@ -389,30 +394,46 @@ class LMCLocalBackend(LMCBackendInterface):
                 codec.finish_decode(job)
             return len(entries)
         if self.mode == "cachegen":
+            # The entries split into maximal RUNS: consecutive chunks of one pack (what one put_kv_range stored) are one
+            # lmc_load_pack -- a transfer and a decode per range of layers, straight from the pack --, a run of chunks
+            # with blobs of their own is one decode over those blobs.  A retrieve that spans several stores (every turn
+            # of a conversation, every prompt behind a shared prefix adds a pack) is a few such jobs on the same
+            # streams, one behind the other; nothing is reassembled on the host and no pinned memory is allocated.
             codec = self._codec()
-            e0 = entries[0]
-            if isinstance(e0, _PackChunk) and all(isinstance(e, _PackChunk) and e.pack is e0.pack and e.index == e0.index + i
-                                                  for i, e in enumerate(entries)) and e0.pack.chunk_tokens == chunk_tokens:
-                # consecutive chunks of ONE pack: a transfer and a decode per range of layers (lmc_load_pack)
+            runs, i = [], 0
+            while i < len(entries):
+                e = entries[i]
+                j = i + 1
+                if isinstance(e, _PackChunk) and e.pack.chunk_tokens == chunk_tokens:
+                    while (j < len(entries) and isinstance(entries[j], _PackChunk) and entries[j].pack is e.pack
+                           and entries[j].index == e.index + (j - i)):
+                        j += 1
+                    runs.append(("pack", i, j))
+                else:
+                    while j < len(entries) and not (isinstance(entries[j], _PackChunk)
+                                                    and entries[j].pack.chunk_tokens == chunk_tokens):
+                        j += 1
+                    runs.append(("blobs", i, j))
+                i = j
+            layerwise = bool(layers_per_launch) and jobs_out is not None
+            for kind, i, j in runs:
+                tok0 = dst_tok0 + i * chunk_tokens
                 with torch.cuda.device(dev):
-                    job = codec.load_pack(e0.pack, e0.index, len(entries), dst, dst_tok0, layers_per_launch)
-                if layers_per_launch and jobs_out is not None:
+                    if kind == "pack":
+                        job = codec.load_pack(entries[i].pack, entries[i].index, j - i, dst, tok0, layers_per_launch)
+                    else:
+                        # (a pack chunk of another chunk length -- never stored by this engine -- takes its blob from the pack)
+                        blobs = [self._own_blob(e) if isinstance(e, _PackChunk) else e.blob for e in entries[i:j]]
+                        if layerwise:
+                            # pinned tier cut by layers (engine.retrieve_layerwise): one lmc_load_chunks call gathers and
+                            # decodes range after range; the caller's layers wait for their range's event only
+                            job = codec.decode_host_layerwise(blobs, dst, tok0, chunk_tokens, layers_per_launch)
+                        else:
+                            job = codec.decode(blobs, dst, tok0, chunk_tokens)
+                if layerwise:
                     jobs_out.append((codec, job))
                 else:
-                    codec.finish_decode(job)
-                return len(entries)
-            entries = [_HostChunk(self._own_blob(e), None, e.shape, e.dtype, True) if isinstance(e, _PackChunk) else e
-                       for e in entries]
-            if layers_per_launch and jobs_out is not None:
-                # pinned tier cut by layers (engine.retrieve_layerwise): one lmc_load_chunks call gathers and decodes
-                # range after range; the caller's layers wait for their range's event only
-                with torch.cuda.device(dev):
-                    job = codec.decode_host_layerwise([e.blob for e in entries], dst, dst_tok0, chunk_tokens, layers_per_launch)
-                jobs_out.append((codec, job))
-                return len(entries)
-            with torch.cuda.device(dev):
-                job = codec.decode([e.blob for e in entries], dst, dst_tok0, chunk_tokens)
-            codec.finish_decode(job)  # this decode's event, then its own status word
+                    codec.finish_decode(job)  # this decode's event, then its own status word
             return len(entries)
         cur = torch.cuda.current_stream(dev)
         stage = None

@@ -44,6 +44,15 @@ class CacheGenDeserializer(Deserializer):
         self.value_bins = self.cachegen_config.value_bins()
         self._lock = threading.Lock()
 
+    def make_key_bins(self, config: CacheGenConfig) -> torch.Tensor:
+        """Bins per key layer as the reference holds them: a float32 tensor (cachegen_decoder.py:121-126; on the host
+        here -- the decoder reads the bins from the blob, this mirror only serves callers that ask for the tensor)."""
+        return torch.tensor(config.key_bins(), dtype=torch.float32)
+
+    def make_value_bins(self, config: CacheGenConfig) -> torch.Tensor:
+        """... and per value layer (cachegen_decoder.py:128-132)."""
+        return torch.tensor(config.value_bins(), dtype=torch.float32)
+
     @_lmcache_nvtx_annotate
     def from_bytes(self, bs) -> torch.Tensor:
         h = native.blob_info(bs)  # validates magic / geometry / length on the host

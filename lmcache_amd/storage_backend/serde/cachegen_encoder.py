@@ -36,6 +36,15 @@ class CacheGenSerializer(Serializer):
         self._lock = threading.Lock()
         self._staging = PinnedArena(slab_bytes=64 << 20)
 
+    def make_key_bins(self, config: CacheGenConfig) -> torch.Tensor:
+        """Bins per key layer as the reference holds them: a float32 tensor (cachegen_encoder.py:339-344; on the host
+        here -- the kernels take the bins as launch arguments, not as a device tensor)."""
+        return torch.tensor(config.key_bins(), dtype=torch.float32)
+
+    def make_value_bins(self, config: CacheGenConfig) -> torch.Tensor:
+        """... and per value layer (cachegen_encoder.py:346-350)."""
+        return torch.tensor(config.value_bins(), dtype=torch.float32)
+
     @_lmcache_nvtx_annotate
     def to_bytes(self, tensor: torch.Tensor) -> bytes:
         """[L,2,T,H,D] ("vllm") or [L,2,H,T,D] ("huggingface"), bf16/fp16, any device -> bytes."""

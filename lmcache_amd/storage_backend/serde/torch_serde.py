@@ -10,6 +10,9 @@ from lmcache_amd.storage_backend.serde.serde import Deserializer, Serializer
 
 
 class TorchSerializer(Serializer):
+    def __init__(self):
+        super().__init__()
+
     def to_bytes(self, t: torch.Tensor) -> bytes:
         buf = io.BytesIO()
         torch.save(t.detach().cpu().clone(), buf)
@@ -17,5 +20,11 @@ class TorchSerializer(Serializer):
 
 
 class TorchDeserializer(Deserializer):
-    def from_bytes(self, b) -> torch.Tensor:
+    def __init__(self):
+        super().__init__()
+
+    def from_bytes_normal(self, b: bytes) -> torch.Tensor:
         return torch.load(io.BytesIO(bytes(b)), weights_only=True)
+
+    def from_bytes(self, b: bytes) -> torch.Tensor:
+        return self.from_bytes_normal(b)

@@ -243,6 +243,67 @@ def gen_engine():
     print("engine_semantics.json", [(q["name"], q["ret_tokens"]) for q in out[0]["queries"]])
 
 
+def _sig(fn):
+    """[name, kind, default repr or None] of every parameter of a callable."""
+    import inspect
+    out = []
+    for p in inspect.signature(fn).parameters.values():
+        out.append([p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)])
+    return out
+
+
+def gen_api():
+    """The reference's plugin surface for the hot path as data: the signatures a drop-in must
+    offer name for name, default for default.  tests/test_dropin_api.py holds lmcache_amd against it (on the GPU box,
+    where /root/reference does not exist, the fixture is all there is)."""
+    import dataclasses
+    import importlib
+    import inspect
+    api = {"functions": {}, "classes": {}, "dataclasses": {}}
+    for mod, name in (("lmcache.storage_backend", "CreateStorageBackend"),
+                      ("lmcache.storage_backend.serde", "CreateSerde"),
+                      ("lmcache.storage_backend.connector", "CreateConnector")):
+        api["functions"][f"{mod}.{name}"] = _sig(getattr(importlib.import_module(mod), name))
+    for mod, name in (("lmcache.cache_engine", "LMCacheEngine"), ("lmcache.cache_engine", "LMCacheEngineBuilder"),
+                      ("lmcache.storage_backend.abstract_backend", "LMCBackendInterface"),
+                      ("lmcache.storage_backend.local_backend", "LMCLocalBackend"),
+                      ("lmcache.storage_backend.remote_backend", "LMCRemoteBackend"),
+                      ("lmcache.storage_backend.remote_backend", "LMCPipelinedRemoteBackend"),
+                      ("lmcache.storage_backend.hybrid_backend", "LMCHybridBackend"),
+                      ("lmcache.storage_backend.serde.serde", "Serializer"),
+                      ("lmcache.storage_backend.serde.serde", "Deserializer"),
+                      ("lmcache.storage_backend.serde.cachegen_encoder", "CacheGenSerializer"),
+                      ("lmcache.storage_backend.serde.cachegen_decoder", "CacheGenDeserializer"),
+                      ("lmcache.storage_backend.serde.torch_serde", "TorchSerializer"),
+                      ("lmcache.storage_backend.serde.torch_serde", "TorchDeserializer"),
+                      ("lmcache.storage_backend.connector.base_connector", "RemoteConnector"),
+                      ("lmcache.utils", "CacheEngineKey")):
+        cls = getattr(importlib.import_module(mod), name)
+        methods = {}
+        for mname, member in inspect.getmembers(cls):
+            if mname.startswith("_") and mname != "__init__":
+                continue
+            if inspect.isfunction(member) or inspect.ismethod(member):
+                if mname == "__init__" and member is object.__init__:
+                    continue
+                raw = inspect.getattr_static(cls, mname)
+                kind = "static" if isinstance(raw, staticmethod) else "class" if isinstance(raw, classmethod) else "method"
+                methods[mname] = {"kind": kind, "params": _sig(member)}
+        api["classes"][f"{mod}.{name}"] = {"methods": methods, "bases": [b.__name__ for b in cls.__mro__[1:-1]]}
+    for mod, name in (("lmcache.config", "LMCacheEngineConfig"), ("lmcache.config", "LMCacheEngineMetadata"),
+                      ("lmcache.utils", "CacheEngineKey")):
+        cls = getattr(importlib.import_module(mod), name)
+        if not dataclasses.is_dataclass(cls):
+            continue
+        api["dataclasses"][f"{mod}.{name}"] = {
+            "fields": [[f.name, None if f.default is dataclasses.MISSING else repr(f.default)] for f in dataclasses.fields(cls)],
+            "constructors": {n: _sig(getattr(cls, n)) for n in ("from_defaults", "from_legacy", "from_file") if hasattr(cls, n)}}
+    with open(os.path.join(OUT, "reference_api.json"), "w") as f:
+        json.dump(api, f, indent=1, sort_keys=True)
+    print("reference_api.json", len(api["functions"]), "functions,", len(api["classes"]), "classes,",
+          len(api["dataclasses"]), "dataclasses")
+
+
 if __name__ == "__main__":
     _install_stubs()
     os.makedirs(OUT, exist_ok=True)
@@ -252,3 +313,4 @@ if __name__ == "__main__":
     gen_cdf()
     gen_layout()
     gen_engine()
+    gen_api()

@@ -272,6 +272,47 @@ def test_suffix_mask_and_mixed_prefixes():
         engine.close()
 
 
+def test_retrieve_across_packs_reads_them_in_place():
+    """The pinned CacheGen tier stores every put_kv_range as one pack, and store() skips chunks that exist: a second,
+    longer prompt behind a stored prefix adds a SECOND pack, and its retrieve spans both.  The retrieve is one
+    lmc_load_pack per run of consecutive chunks of a pack -- nothing is reassembled on the host, no pinned memory is
+    allocated by retrieving (the mixed case fell back to a host-side extract per chunk and leaked its
+    pinned copy) -- and a single get() reads its chunk from the pack as well.  Deterministic decode: two retrieves of
+    the same tokens are bit-equal, and the shared prefix is bit-equal to what the first store alone returns."""
+    fmt, cs = "vllm", 256
+    engine = LMCacheEngine(make_cfg("cachegen-host", cs), dumb_metadata(fmt))
+    try:
+        a = generate_tokens(3 * cs, "cuda")
+        kv_a = generate_kv_cache(3 * cs, fmt, "cuda")
+        engine.store(a, kv_a)
+        first, m = engine.retrieve(a)
+        assert int(m.sum()) == 3 * cs
+        b = torch.cat([a, generate_tokens(2 * cs + 40, "cuda")])  # 3 stored chunks + 2 full + a ragged one
+        kv_b = concatenate_kv_caches([kv_a, generate_kv_cache(2 * cs + 40, fmt, "cuda")], fmt)
+        engine.store(b, kv_b)
+        arena = engine.engine_.host_arena
+        before = arena.total_allocated
+        got, m = engine.retrieve(b)
+        assert int(m.sum()) == len(b)
+        again, _ = engine.retrieve(b)
+        mask = torch.ones(len(b), dtype=torch.bool, device="cuda")
+        mask[:2 * cs + 17] = False  # the run inside the first pack begins at its third chunk, trimmed
+        tail, tm = engine.retrieve(b, mask)
+        assert int(tm.sum()) == len(b) - (2 * cs + 17)
+        for (k, v), (k2, v2), (kf, vf), (kt, vt) in zip(got, again, first, tail):
+            assert torch.equal(k, k2) and torch.equal(v, v2)
+            assert torch.equal(k[:3 * cs], kf) and torch.equal(v[:3 * cs], vf)
+            assert torch.equal(k[2 * cs + 17:], kt) and torch.equal(v[2 * cs + 17:], vt)
+        # every chunk on its own: get() decodes it from its pack
+        keys = [engine._make_key(h, fmt) for h in engine._prefix_hash(engine._chunk_tokens(b))]
+        for i, key in enumerate(keys[:5]):
+            chunk = engine.engine_.get(key)
+            assert chunk is not None and torch.equal(chunk[0, 0], got[0][0][i * cs:(i + 1) * cs])
+        assert arena.total_allocated == before, "retrieving allocated pinned memory"
+    finally:
+        engine.close()
+
+
 @pytest.mark.parametrize("backend", ["cpu", "cachegen-host"])
 def test_store_nonblocking_and_skip_existing(backend):
     """blocking=False hands the offload to the worker thread (local_backend.py:72-80,122-125);

@@ -81,6 +81,68 @@ def test_restart_retires_the_records_of_the_old_arena():
         conn.unlink()
 
 
+def test_failed_and_abandoned_writes_do_not_wedge_a_key():
+    """a key whose first writer fails between reserving its slot and publishing it, or dies there, must
+    not stay "being written" for ever.  (1) a copy that raises retires the pending record: the same key can be set at
+    once; (2) a pending record whose writer is no longer alive (or is older than the timeout) is taken over; (3) setting a
+    published key again with the same number of bytes -- keys are content hashes -- takes no new extent; (4) retired slots
+    are reused by later insertions."""
+    import struct
+    from lmcache_amd.storage_backend.connector import xgmi_connector as xc
+    os.environ["LMC_XGMI_ARENA_MB"] = "2"
+    conn = xc.XgmiConnector(_name("pend"), 1, device="cpu", nslots=64)
+    try:
+        used = lambda: struct.unpack_from("<Q", conn._dir, xc._USED_OFF)[0]
+        # (1) the copy fails
+        class Boom(RuntimeError):
+            pass
+        real = conn._arena
+        def broken(owner, gen):
+            raise Boom("no peer access")
+        conn._arena = broken
+        with pytest.raises(Boom):
+            conn.set("k1", b"x" * 100)
+        conn._arena = real
+        assert not conn.exists("k1")
+        conn.set("k1", b"y" * 100)
+        assert conn.get("k1") == b"y" * 100
+        # (2) a writer that died while its record was pending: stamp of a pid that does not exist
+        with conn._locked():
+            res = conn._reserve("k2", 50)
+            assert res is not None
+            off = conn._rec_off(res[2])
+            state, owner, offset, size, cap, klen, gen = xc._REC.unpack_from(conn._dir, off)
+            assert state == xc._PENDING
+            xc._REC.pack_into(conn._dir, off, state, owner, offset, (0x3fffff << 32) | (size & 0xffffffff), cap, klen, gen)
+            assert conn._reserve("k2", 50) is not None      # dead writer: taken over
+        with conn._locked():                                 # a live writer (this process, just now) is respected
+            assert conn._reserve("k2", 50) is None
+        assert not conn.exists("k2") and "k2" not in conn.list()
+        with conn._locked():                                 # ... until it has held the key for too long
+            off = conn._rec_off(conn._find("k2")[1])
+            f = list(xc._REC.unpack_from(conn._dir, off))
+            f[3] = (os.getpid() << 32) | ((int(__import__("time").time()) - 10 * xc._PENDING_TIMEOUT_S) & 0xffffffff)
+            xc._REC.pack_into(conn._dir, off, *f)
+        conn.set("k2", b"z" * 50)
+        assert conn.get("k2") == b"z" * 50
+        # (3) the same bytes again: nothing is allocated
+        before = used()
+        conn.set("k2", b"z" * 50)
+        assert used() == before and conn.get("k2") == b"z" * 50
+        conn.set("k2", b"w" * 51)                            # another size: a fresh extent, the record flips to it
+        assert used() > before and conn.get("k2") == b"w" * 51
+        # (4) a retired slot is taken by the next key that probes over it
+        slot_k1 = conn._find("k1")[1]
+        with conn._locked():
+            struct.pack_into("<I", conn._dir, conn._rec_off(slot_k1), xc._DEAD)
+        assert not conn.exists("k1")
+        conn.set("k1", b"again")
+        assert conn._find("k1")[1] == slot_k1 and conn.get("k1") == b"again"
+    finally:
+        conn.close()
+        conn.unlink()
+
+
 def test_no_pickle_in_the_connectors():
     """Peers exchange fixed-layout binary records (directory, arena exports, SPMD exchange): nothing in the connector
     package unpickles bytes another process wrote."""
