@@ -21,13 +21,20 @@
 // The look-back granules carry the launch's epoch (flag << 62 | epoch << 32 | value): a granule of another
 // launch reads as "not published", so nothing has to zero them between jobs.
 //
-// Geometry: 256 < C <= 1024 channels per plane (G = 5..16 group streams, the 64-lane quantise tasks); other
-// shapes take the two-kernel path (lmc_api.hip).
+// Work item = a run of whole planes of one chunk (FusedArgs::pl planes, ipc items per chunk), sized so that an item
+// is about half a megabyte of raw KV whatever the plane width:
+//   C <= 128   (GL = 16)  8 planes per item, <= 16 streams; a wave quantises four row octs at a time, 16 lanes each
+//   C <= 256   (GL = 32)  4 planes per item, <= 16 streams; two row octs at a time
+//   C <= 1024  (GL = 64)  1 plane, <= 16 streams (NITER = 1 or 2 channel runs per lane)
+//   C <= 4096  (SPLIT = 2 / 4)  1 plane, <= 64 streams: 2 / 4 waves share a row oct (quantize_oct_fused), a wave codes
+//              4 / 8 streams and parks their counts in a global stash between its two passes
+// Every 256-token chunk of every geometry lmc_encode_chunks accepts comes through here (C = 128 is the Llama-3-70B
+// TP = 8 rank, C = 4096 BASELINE configs[0]); a ragged last chunk takes the two-kernel path.
 #pragma once
 #include "k_encode_counts.h"
 #include "k_quantize.h"
 
-#define FUSED_MAX_G 16
+#define FUSED_MAX_NS 64  // streams per work item
 #ifndef FUSED_WAVES
 #define FUSED_WAVES 8  // waves per workgroup: 4 workgroups per CU
 #endif
@@ -54,7 +61,29 @@ struct FusedArgs {
   // workgroup per CU at a time.
   u32 stagger_ticks, stagger_limit;
   u32* cu_rank;  // [4096] zero at launch: the workgroup with the launch's last ticket clears it again on its way out
+  int pl, ipc;   // planes per work item, items per chunk = ceil(P / pl)
+  u32* stash;    // SPLIT geometries: FUSED_STASH_DWORDS per stream of the job, where a stream's counts wait for pass 2
 };
+#define FUSED_STASH_DWORDS (9 * 64)  // pk[8] of every lane, then one row: lane k < 8 holds wor[k], lane 8 the head size
+
+// A stream's CountsState to / from its stash slot (coalesced rows of 256 bytes; written and read by the same wave).
+__device__ __forceinline__ void counts_state_store(const CountsState& cs, u32* slot, int lane) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) slot[k * 64 + lane] = cs.pk[k];
+  u32 row = cs.head;
+#pragma unroll
+  for (int k = 0; k < 8; k++) row = lane == k ? cs.wor[k] : row;
+  slot[8 * 64 + lane] = row;
+}
+__device__ __forceinline__ void counts_state_load(CountsState& cs, const u32* slot, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own stores have left it
+#pragma unroll
+  for (int k = 0; k < 8; k++) cs.pk[k] = slot[k * 64 + lane];
+  const u32 row = slot[8 * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < 8; k++) cs.wor[k] = (u32)__builtin_amdgcn_readlane((int)row, k);
+  cs.head = (u32)__builtin_amdgcn_readlane((int)row, 8);
+}
 
 __device__ __forceinline__ void aggE_store(unsigned long long* p, unsigned long long flag, u32 epoch, u32 v) {
   __hip_atomic_store(p, (flag << 62) | ((unsigned long long)epoch << 32) | (unsigned long long)v, __ATOMIC_RELAXED,
@@ -96,18 +125,23 @@ __device__ __forceinline__ u32 lookback_exclusive_epoch(unsigned long long* agg,
 // quant_special on zero / inf / NaN rows), two rows in flight, one row quad of accumulators at a time: a byte
 // plane stores each quad as soon as it is complete; a nibble plane parks the first quad's 8 * NITER dwords in
 // the wave's idle LDS slice and merges them with the second (byte k = token k | token 4 + k << 4).
-// FULL: every lane of every iteration holds channels of the plane (C == NITER * 512: Llama / Mistral GQA shapes), so
-// no per-lane validity is tested and no register is zero-filled for absent channels.
-template <int NITER, int DT, bool NIB, bool FULL = false>
+// FULL: every lane of every iteration holds channels of the plane (C == SPLIT * NITER * 512: Llama / Mistral GQA
+// shapes), so no per-lane validity is tested and no register is zero-filled for absent channels.
+// SPLIT > 1 (planes of more than 1024 channels): SPLIT waves share the oct, wave `slice` holds channels
+// [slice, slice + 1) * NITER * 512 of every row, and the row maxima of a row pair meet in LDS: xm[2][2][SPLIT], the
+// halves used alternately -- the pair after next overwrites a half only behind the barrier at which every wave has
+// read it -- so ONE workgroup barrier per row pair, executed by every wave of the workgroup (the octs are dealt out
+// evenly: lmc_api.hip only launches whole 256-token chunks).
+template <int NITER, int DT, bool NIB, bool FULL = false, int SPLIT = 1>
 __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16* pbase, int tok0, int Tc, int t_first,
                                                    bool q1valid, int C, float maxf, u32* sym_out, u16* scale_out,
-                                                   uint4* park, int lane) {
+                                                   uint4* park, int lane, int slice = 0, u32* xm = nullptr) {
   long long coff[NITER];
   int c0[NITER];
   bool cval[NITER];
 #pragma unroll
   for (int it = 0; it < NITER; it++) {
-    c0[it] = (it * 64 + lane) * 8;
+    c0[it] = ((slice * NITER + it) * 64 + lane) * 8;
     cval[it] = FULL || c0[it] < C;
     const int h = c0[it] / src.D, d = c0[it] - h * src.D;
     coff[it] = (long long)h * src.stride_head + d;
@@ -145,7 +179,23 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
         mrow[r] = max(m & 0xffffu, m >> 16);
       }
       wave_max2_u32(mrow[0], mrow[1]);  // wave-uniform from here on
-      if (lane == 0) {
+      if constexpr (SPLIT > 1) {
+        u32* const half = xm + ((hq * 2 + (r0 >> 1)) & 1) * 2 * SPLIT;
+        if (lane == 0) {
+          half[slice] = mrow[0];
+          half[SPLIT + slice] = mrow[1];
+        }
+        __syncthreads();
+        u32 m0 = 0, m1 = 0;
+#pragma unroll
+        for (int k = 0; k < SPLIT; k++) {
+          m0 = max(m0, half[k]);
+          m1 = max(m1, half[SPLIT + k]);
+        }
+        mrow[0] = (u32)__builtin_amdgcn_readfirstlane((int)m0);
+        mrow[1] = (u32)__builtin_amdgcn_readfirstlane((int)m1);
+      }
+      if (lane == 0 && slice == 0) {
 #pragma unroll
         for (int r = 0; r < 2; r++)
           if (tv[r]) scale_out[4 * hq + r0 + r] = (u16)mrow[r];
@@ -221,21 +271,26 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
   }
 }
 
-template <int NITER, int DT, int NW>
+template <int GL, int NITER, int SPLIT, int DT, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_fused(FusedArgs fa) {
-  static_assert(FUSED_MAX_G <= 2 * NW, "a wave takes at most two streams");
+  static_assert(GL == 64 || (NITER == 1 && SPLIT == 1), "narrow planes: one channel run per lane");
+  static_assert(SPLIT == 1 || (GL == 64 && NITER == 2 && NW % SPLIT == 0), "wide planes: SPLIT waves x 1024 channels");
+  constexpr bool STASH = SPLIT > 1;  // more than two streams per wave: their counts wait in global memory
   const EncodeArgs& a = fa.e;
   __shared__ __attribute__((aligned(16))) u32 lds_all[NW * (ENC_RING_DWORDS + CNT_TAB_DWORDS)];  // the staging rings, then the tables
   __shared__ __attribute__((aligned(16))) u32 rtab_lds[RTAB_LDS_DWORDS];  // reciprocals of the counts model's frequencies, bound table
-  __shared__ u32 st_alloc[FUSED_MAX_G];  // allocation of the plane-chunk's group streams
+  __shared__ u32 st_alloc[FUSED_MAX_NS];  // allocation of the item's group streams
+  __shared__ u32 xmax[SPLIT > 1 ? (NW / SPLIT) * 4 * SPLIT : 1];  // wide planes: the row maxima of the waves that share an oct
   __shared__ u32 wg_excl;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // consecutive work items are the same plane of consecutive chunks (see k_cdf_encode): a plane-chunk's predecessors
+  // consecutive work items are the same planes of consecutive chunks (see k_cdf_encode): an item's predecessors
   // in the look-back were taken at least nchunks workgroups earlier.  The item comes from a ticket, not from
   // blockIdx (EncodeArgs::ticket): a predecessor's workgroup has started, whatever order the hardware dispatches in.
   const u32 item = (u32)__builtin_amdgcn_readfirstlane((int)draw_ticket(a.ticket, a.ticket_base));
-  const int chunk = (int)(item % (unsigned)a.nchunks), p = (int)(item / (unsigned)a.nchunks);
+  const int chunk = (int)(item % (unsigned)a.nchunks), it = (int)(item / (unsigned)a.nchunks);
+  const int p0 = it * fa.pl, np = min(fa.pl, a.P - p0);  // the item's planes
+  const int NS = np * a.G;                               // ... and streams: j -> plane p0 + j / G, group j % G
   const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
   constexpr int Tc = (int)LMC_COUNTS_T;  // lmc_api.hip hands this kernel full 256-token chunks only
   u32* const hist = lds_all + NW * ENC_RING_DWORDS + wave * CNT_TAB_DWORDS;  // this wave's table slice ...
@@ -255,63 +310,97 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const u32 t0 = (u32)__builtin_amdgcn_s_memrealtime();
     while ((u32)__builtin_amdgcn_s_memrealtime() - t0 < hold) __builtin_amdgcn_s_sleep(32);
   }
-  // ---- phase A: quantise the plane-chunk ----------------------------------------------------------------
+  // ---- phase A: quantise the item's planes ------------------------------------------------------------------
   {
-    const int bins = (int)a.bins.b[p];
-    const float maxf = (float)(bins / 2 - 1);
-    const bool nib = lmc_sym_nibbles(bins);
-    const bool full = a.C == NITER * 512;  // no absent channels: the variant without per-lane validity
-    u32* const sym_pc = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.sym_stride;
-    u16* const scl = reinterpret_cast<u16*>(fa.scale_base + (long long)chunk * fa.scale_stride) + (long long)p * Tc;
-    constexpr int TO = (Tc + 7) >> 3;
-    const u16* const pbase = lmc_plane_base(fa.src, p);
+    constexpr int TO = (Tc + 7) >> 3;  // row octs of a plane-chunk
     uint4* const park = reinterpret_cast<uint4*>(hist);  // the wave's table slice is idle until pass 1
+    u8* const scl0 = fa.scale_base + (long long)chunk * fa.scale_stride;
     // Waves that fetch run at raised priority: their (few) instructions go first, so the loads are out early and
     // return under the other workgroups' coding.
     __builtin_amdgcn_s_setprio(LMC_FUSED_PRIO_A);
+    if constexpr (GL < 64) {
+      // narrow planes: a wave takes RPW row octs of one plane at a time, GL lanes each (quantize_task, k_quantize.h)
+      constexpr int RPW = 64 / GL, OG = TO / RPW;  // octs per wave pass, oct groups per plane
+      const int sub = lane / GL, sl = lane % GL;
 #pragma unroll 1
-    for (int oct = wave; oct < TO; oct += NW) {
-      const bool q1valid = 2 * oct + 1 < a.TQ;
-      if (full) {  // wave-uniform
-        if (nib)
-          quantize_oct_fused<NITER, DT, true, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                                    sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
+      for (int task = wave; task < np * OG; task += NW) {
+        const int p = p0 + task / OG, oct = (task % OG) * RPW + sub;
+        const int bins = (int)a.bins.b[p];
+        const float maxf = (float)(bins / 2 - 1);
+        const bool nib = lmc_sym_nibbles(bins);
+        u32* const sym_out = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.sym_stride + (long long)oct * (nib ? 1 : 2) * a.C;
+        u16* const scale_out = reinterpret_cast<u16*>(scl0) + (long long)p * Tc + oct * 8;
+        const bool q1valid = 2 * oct + 1 < a.TQ;
+        if (nib) quantize_task<GL, 1, DT, true, true, 4, 2>(fa.src, p, tok0, Tc, oct * 8, true, q1valid, a.C, maxf, sym_out, nullptr, scale_out, sl);
+        else quantize_task<GL, 1, DT, true, false, 4, 2>(fa.src, p, tok0, Tc, oct * 8, true, q1valid, a.C, maxf, sym_out, nullptr, scale_out, sl);
+      }
+    } else {
+      const int p = p0;
+      const int bins = (int)a.bins.b[p];
+      const float maxf = (float)(bins / 2 - 1);
+      const bool nib = lmc_sym_nibbles(bins);
+      const bool full = a.C == SPLIT * NITER * 512;  // no absent channels: the variant without per-lane validity
+      u32* const sym_pc = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.sym_stride;
+      u16* const scl = reinterpret_cast<u16*>(scl0) + (long long)p * Tc;
+      const u16* const pbase = lmc_plane_base(fa.src, p);
+      const int slice = wave % SPLIT;
+      u32* const xm = xmax + (wave / SPLIT) * 4 * SPLIT;
+#pragma unroll 1
+      for (int oct = wave / SPLIT; oct < TO; oct += NW / SPLIT) {
+        const bool q1valid = 2 * oct + 1 < a.TQ;
+        if (full) {  // wave-uniform
+          if (nib)
+            quantize_oct_fused<NITER, DT, true, true, SPLIT>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                             sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane, slice, xm);
+          else
+            quantize_oct_fused<NITER, DT, false, true, SPLIT>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                              sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane, slice, xm);
+        } else if (nib)
+          quantize_oct_fused<NITER, DT, true, false, SPLIT>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                            sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane, slice, xm);
         else
-          quantize_oct_fused<NITER, DT, false, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                                     sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
-      } else if (nib)
-        quantize_oct_fused<NITER, DT, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                            sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
-      else
-        quantize_oct_fused<NITER, DT, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                             sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
+          quantize_oct_fused<NITER, DT, false, false, SPLIT>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                             sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane, slice, xm);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
   }
-  __syncthreads();  // symbols and scales of the plane-chunk are visible to the workgroup
+  __syncthreads();  // symbols and scales of the item are visible to the workgroup
 
   // ---- pass 1: the counts of this wave's group streams, and from them the streams' allocations ----------------
-  CountsState cs0, cs1;  // of stream `wave`, and of stream `wave + NW`
-  auto pass1 = [&](int g, CountsState& cs) {
-    if (g < a.G) {  // wave-uniform
-      const CountsStream s = counts_stream_of(a, chunk, p, g, lane);
+  // stream j of the item = group j % G of plane p0 + j / G
+  auto stream_of = [&](int j) -> CountsStream {
+    const int pj = (int)((u32)j / (u32)a.G);
+    return counts_stream_of(a, chunk, p0 + pj, j - pj * a.G, lane);
+  };
+  u32* const stash0 = STASH ? fa.stash + (((long long)chunk * a.P + p0) * a.G) * FUSED_STASH_DWORDS : nullptr;
+  CountsState cs0, cs1;  // !STASH: of stream `wave`, and of stream `wave + NW`
+  auto pass1 = [&](int j, CountsState& cs) {
+    if (j < NS) {  // wave-uniform
+      const CountsStream s = stream_of(j);
       const u32 alloc = counts_hist_stream(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
-      if (lane == 0) st_alloc[g] = alloc;
+      if (lane == 0) st_alloc[j] = alloc;
+      if constexpr (STASH) counts_state_store(cs, stash0 + (long long)j * FUSED_STASH_DWORDS, lane);
     }
   };
-  pass1(wave, cs0);
-  pass1(wave + NW, cs1);
+  if constexpr (STASH) {
+#pragma unroll 1
+    for (int j = wave; j < NS; j += NW) pass1(j, cs0);
+  } else {
+    pass1(wave, cs0);
+    pass1(wave + NW, cs1);
+  }
   __syncthreads();
 
-  // ---- placement: one look-back per plane-chunk, BEFORE the streams are coded --------------------------------
+  // ---- placement: one look-back per item, BEFORE the streams are coded ------------------------------------------
   u32 wg_total = 0;
-  for (int g = 0; g < a.G; g++) wg_total += st_alloc[g];
+  for (int j = 0; j < NS; j++) wg_total += st_alloc[j];
   if (wave == 0) {
-    unsigned long long* agg = a.agg + (long long)chunk * a.P;
-    if (lane == 0 && p > 0) aggE_store(agg + p, AGG_A, fa.epoch, wg_total);
-    const u32 e = lookback_exclusive_epoch(agg, p, fa.epoch, lane, a.status);
+    unsigned long long* agg = a.agg + (long long)chunk * fa.ipc;
+    if (lane == 0 && it > 0) aggE_store(agg + it, AGG_A, fa.epoch, wg_total);
+    const u32 e = lookback_exclusive_epoch(agg, it, fa.epoch, lane, a.status);
     if (lane == 0) {
-      aggE_store(agg + p, AGG_P, fa.epoch, e + wg_total);
+      aggE_store(agg + it, AGG_P, fa.epoch, e + wg_total);
       wg_excl = e;
     }
   }
@@ -320,19 +409,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // ---- pass 2: every stream is coded at its final place -----------------------------------------------------------
   const BlobOff bo = lmc_blob_off((u32)a.P, (u32)Tc, (u32)a.G);
   u8* const blob = a.blobs + (long long)chunk * a.blob_stride;
-  auto pass2 = [&](int g, const CountsState& cs) {
-    if (g < a.G) {
+  auto pass2 = [&](int j, const CountsState& cs) {
+    if (j < NS) {
       u32 beg = wg_excl;
-      for (int j = 0; j < g; j++) beg += st_alloc[j];
-      const u32 alloc = st_alloc[g];
-      const CountsStream s = counts_stream_of(a, chunk, p, g, lane);
+      for (int k = 0; k < j; k++) beg += st_alloc[k];
+      const u32 alloc = st_alloc[j];
+      const CountsStream s = stream_of(j);
       u8* const out = blob + bo.streams + beg;
       counts_open_stream(s, cs, out, hist, lane);
       const u32 exact = cs.head + counts_code_stream<true>(a, s, hist, ring, rtab_lds, lane, reinterpret_cast<u16*>(out + cs.head));
       const u32 padded = (exact + 15u) & ~15u;
       if (alloc > padded) zero_fill16(out + padded, alloc - padded, lane);
       if (lane == 0) {
-        u32* d = reinterpret_cast<u32*>(blob + bo.gdir) + 2 * (p * a.G + g);
+        u32* d = reinterpret_cast<u32*>(blob + bo.gdir) + 2 * (s.p * a.G + s.g);
         d[0] = beg;
         d[1] = beg + exact;
         if (exact > alloc) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);  // the bound is a theorem: never
@@ -340,14 +429,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       wave_lds_fence();  // the next stream reuses this wave's LDS slices
     }
   };
-  pass2(wave, cs0);
-  pass2(wave + NW, cs1);
-  // The chunk's last plane knows the chunk's size: header, static sections, size word.
-  if (p == a.P - 1 && wave == NW - 1) {
+  if constexpr (STASH) {
+#pragma unroll 1
+    for (int j = wave; j < NS; j += NW) {
+      counts_state_load(cs0, stash0 + (long long)j * FUSED_STASH_DWORDS, lane);
+      pass2(j, cs0);
+    }
+  } else {
+    pass2(wave, cs0);
+    pass2(wave + NW, cs1);
+  }
+  // The chunk's last item knows the chunk's size: header, static sections, size word.
+  if (p0 + np == a.P && wave == NW - 1) {
     write_blob_static(blob, bo, a, (u32)Tc, wg_excl + wg_total, lane);
     if (lane == 0) a.sizes[chunk] = bo.streams + wg_excl + wg_total;
   }
-  if (fa.stagger_ticks && item == (u32)(a.nchunks * a.P) - 1u) {  // every first-generation rank was drawn long ago
+  if (fa.stagger_ticks && item == (u32)(a.nchunks * fa.ipc) - 1u) {  // every first-generation rank was drawn long ago
     for (u32 i = threadIdx.x; i < 4096u; i += 64u * NW) fa.cu_rank[i] = 0u;
   }
 }

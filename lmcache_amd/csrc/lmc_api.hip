@@ -36,6 +36,7 @@ struct lmc_ctx {
   // encode workspace
   u32* sym4 = nullptr;  size_t sym4_bytes = 0;
   u8* scratch = nullptr; size_t scratch_bytes = 0;
+  u32* stash = nullptr; size_t stash_bytes = 0;     // fused encode of wide planes: the streams' counts between the two passes
   unsigned long long* agg = nullptr; size_t agg_bytes = 0;  // look-back granules of the in-kernel compaction
   hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
   bool ws_used = false;
@@ -113,6 +114,7 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   if (c->ws_used) (void)hipEventSynchronize(c->ws_free);
   if (c->sym4) (void)hipFree(c->sym4);
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->stash) (void)hipFree(c->stash);
   if (c->agg) (void)hipFree(c->agg);
   if (c->ticket) (void)hipFree(c->ticket);
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
@@ -248,19 +250,33 @@ static int ws_grow(void** p, size_t* have, size_t need) {
   return LMC_OK;
 }
 
+// The fused encode for a plane width (k_fused.h: lanes per quantise task, channel runs per lane, waves per row).
+template <int DT>
+static void launch_fused(int C, dim3 grid, dim3 block, hipStream_t s, const FusedArgs& fa) {
+  if (C <= 128) hipLaunchKernelGGL((k_encode_fused<16, 1, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
+  else if (C <= 256) hipLaunchKernelGGL((k_encode_fused<32, 1, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
+  else if (C <= 512) hipLaunchKernelGGL((k_encode_fused<64, 1, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
+  else if (C <= 1024) hipLaunchKernelGGL((k_encode_fused<64, 2, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
+  else if (C <= 2048) hipLaunchKernelGGL((k_encode_fused<64, 2, 2, DT, FUSED_WAVES>), grid, block, 0, s, fa);
+  else hipLaunchKernelGGL((k_encode_fused<64, 2, 4, DT, FUSED_WAVES>), grid, block, 0, s, fa);
+}
+
 // caller holds ctx->mu.  The symbol workspace and the look-back granules of `max_chunks` chunks; the stream scratch
 // too when `scratch` (the two-kernel path codes into scratch slots; the fused kernel codes straight into the blobs).
-static int reserve_locked(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_chunks, bool scratch) {
+static int reserve_locked(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_chunks, bool scratch, bool stash = false) {
   const size_t P = 2 * (size_t)L, C = (size_t)H * D, G = (C + 63) / 64, TQ = ((size_t)chunk_tokens + 3) / 4;
   const size_t need_sym = (size_t)max_chunks * P * TQ * C * 4;
   const size_t need_scr = scratch ? (size_t)max_chunks * P * G * lmc_group_cap_bytes((uint32_t)chunk_tokens) : 0;
+  const size_t need_stash = stash ? (size_t)max_chunks * P * G * FUSED_STASH_DWORDS * 4 : 0;
   const size_t need_agg = (size_t)max_chunks * P * G * 8;
-  if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && need_agg <= c->agg_bytes) return LMC_OK;
+  if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && need_agg <= c->agg_bytes && need_stash <= c->stash_bytes)
+    return LMC_OK;
   // growing frees memory that queued kernels may still use: wait for them (this call only)
   if (c->ws_used) HIP_TRY(hipEventSynchronize(c->ws_free));
   int rc;
   if ((rc = ws_grow((void**)&c->sym4, &c->sym4_bytes, need_sym))) return rc;
   if ((rc = ws_grow((void**)&c->scratch, &c->scratch_bytes, need_scr))) return rc;
+  if ((rc = ws_grow((void**)&c->stash, &c->stash_bytes, need_stash))) return rc;
   const size_t agg_before = c->agg_bytes;
   if ((rc = ws_grow((void**)&c->agg, &c->agg_bytes, need_agg))) return rc;
   // fresh granules must not look like a published value of some epoch (k_fused.h)
@@ -331,16 +347,18 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   hipStream_t s = (hipStream_t)stream;
 
   std::lock_guard<std::mutex> lk(c->mu);
-  // k_fused.h codes 256-token chunks (the counts model) of 256 < C <= 1024 channels (64-lane quantise tasks, G <= 16)
+  // k_fused.h codes the 256-token chunks (the counts model) of every plane width: a work item is a run of whole planes
+  // of one chunk -- 8 planes of <= 128 channels, 4 of <= 256, else one
   const int nfull = (tok_end - tok_begin) / chunk_tokens;  // chunks of exactly chunk_tokens tokens; a ragged one may follow
-  const bool fused_fits = C > 256 && C <= 1024 && chunk_tokens == (int)LMC_COUNTS_T && nfull > 0;
-  // AUTO: the fused kernel pays once its (chunk, plane) workgroups outnumber the slots of the chip (4 per CU):
-  // measured on MI355X with 64 planes, 4 / 8 / 12 / 16 / 32 / 64 chunks: fused / two-kernel time = 1.27 / 1.16 /
-  // 1.05 / 1.00 / 0.91 / 0.90 (tools/probes/encode_ab.hip)
+  const bool fused_fits = chunk_tokens == (int)LMC_COUNTS_T && nfull > 0;
+  const int pl = C <= 128 ? 8 : C <= 256 ? 4 : 1, ipc = (P + pl - 1) / pl;
+  // AUTO: the fused kernel pays once its workgroups fill the slots of the chip (4 per CU): measured on MI355X with
+  // 64 planes of 1024 channels, 4 / 8 / 12 / 16 / 32 / 64 chunks: fused / two-kernel time = 1.27 / 1.16 / 1.05 / 1.00 /
+  // 0.91 / 0.90 (tools/probes/encode_ab.hip)
   const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
-                                    (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * P > 4ll * c->num_cus));
+                                    (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * ipc >= 4ll * c->num_cus));
   const bool two_kernel_part = !fused || nfull < nchunks;  // chunks that code into scratch slots
-  int rc = reserve_locked(c, L, H, D, chunk_tokens, nchunks, two_kernel_part);
+  int rc = reserve_locked(c, L, H, D, chunk_tokens, nchunks, two_kernel_part, fused && C > 1024);
   if (rc) return rc;
   if (c->ws_used) HIP_TRY(hipStreamWaitEvent(s, c->ws_free, 0));
   // A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next (k_offload, k_pack_scan,
@@ -426,23 +444,19 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     c->epoch = (c->epoch + 1u) & 0x3fffffffu;
     if (!c->epoch) c->epoch = 1u;
     fa.epoch = c->epoch;
-    const dim3 grid((unsigned)((long long)nfull * P)), block(64 * FUSED_WAVES);
+    fa.pl = pl; fa.ipc = ipc; fa.stash = c->stash;
+    const dim3 grid((unsigned)((long long)nfull * ipc)), block(64 * FUSED_WAVES);
     fa.e.ticket_base = c->tickets_drawn;
     if ((rc = prof_mark(c, s))) return rc;
-    if (c->stagger_us > 0 && (long long)nfull * P >= 8ll * c->num_cus) {
+    if (c->stagger_us > 0 && (long long)nfull * ipc >= 8ll * c->num_cus) {
       if (!c->cu_rank) {  // zeroed once; every launch leaves it zero
         HIP_TRY(hipMalloc((void**)&c->cu_rank, 4096 * sizeof(u32)));
         HIP_TRY(hipMemsetAsync(c->cu_rank, 0, 4096 * sizeof(u32), s));
       }
       fa.stagger_ticks = (u32)c->stagger_us * 100u; fa.stagger_limit = 4u * (u32)c->num_cus; fa.cu_rank = c->cu_rank;
     }
-    if (src->dtype == LMC_DTYPE_BF16) {
-      if (C <= 512) hipLaunchKernelGGL((k_encode_fused<1, LMC_DTYPE_BF16, FUSED_WAVES>), grid, block, 0, s, fa);
-      else hipLaunchKernelGGL((k_encode_fused<2, LMC_DTYPE_BF16, FUSED_WAVES>), grid, block, 0, s, fa);
-    } else {
-      if (C <= 512) hipLaunchKernelGGL((k_encode_fused<1, LMC_DTYPE_FP16, FUSED_WAVES>), grid, block, 0, s, fa);
-      else hipLaunchKernelGGL((k_encode_fused<2, LMC_DTYPE_FP16, FUSED_WAVES>), grid, block, 0, s, fa);
-    }
+    if (src->dtype == LMC_DTYPE_BF16) launch_fused<LMC_DTYPE_BF16>(C, grid, block, s, fa);
+    else launch_fused<LMC_DTYPE_FP16>(C, grid, block, s, fa);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) { g_last_hip = (int)le; tickets_reset(); return LMC_ERR_HIP; }
     c->tickets_drawn += grid.x;

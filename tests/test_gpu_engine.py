@@ -280,7 +280,7 @@ def test_retrieve_across_packs_reads_them_in_place():
     pinned copy) -- and a single get() reads its chunk from the pack as well.  Deterministic decode: two retrieves of
     the same tokens are bit-equal, and the shared prefix is bit-equal to what the first store alone returns."""
     fmt, cs = "vllm", 256
-    engine = LMCacheEngine(make_cfg("cachegen-host", cs), dumb_metadata(fmt))
+    engine = LMCacheEngine(make_cfg("cachegen-host", cs), dumb_metadata(fmt, MODEL))
     try:
         a = generate_tokens(3 * cs, "cuda")
         kv_a = generate_kv_cache(3 * cs, fmt, "cuda")

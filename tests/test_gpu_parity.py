@@ -635,6 +635,16 @@ FUSED_SHAPES = [
     (1, 256, 256, 5, 72, torch.bfloat16, "randn"),    # C = 360: partial last group (idle lanes in the coder)
     (3, 768, 256, 4, 128, torch.float16, "randn"),    # C = 512: one channel run per lane
     (2, 256, 256, 3, 128, torch.bfloat16, "randn"),   # C = 384
+    # narrow planes: several planes per work item, 16 / 32 lanes per quantise task
+    (10, 512, 256, 1, 128, torch.bfloat16, "randn"),  # C = 128 (Llama-3-70B TP=8 rank): 20 planes = items of 8, 8 and 4 planes
+    (3, 256, 256, 1, 64, torch.float16, "outlier"),   # C = 64: one group stream per plane, 6 planes in one item
+    (5, 512, 256, 2, 128, torch.bfloat16, "rand"),    # C = 256: items of 4, 4 and 2 planes
+    (2, 256, 256, 1, 200, torch.bfloat16, "randn"),   # C = 200: the 32-lane task with a partial last group
+    # wide planes: 2 / 4 waves per row oct, 4 / 8 streams per wave through the stash
+    (1, 512, 256, 32, 128, torch.float16, "rand"),    # C = 4096 (BASELINE configs[0])
+    (2, 256, 256, 16, 128, torch.bfloat16, "randn"),  # C = 2048
+    (1, 256, 256, 25, 128, torch.bfloat16, "outlier"),# C = 3200: partial channel runs in the last wave of a row
+    (1, 256, 256, 9, 136, torch.bfloat16, "randn"),   # C = 1224: SPLIT = 2 with an almost empty second slice
     (2, 236, 236, 8, 128, torch.float16, "outlier"),  # tests/test_serde.py:87-107 chunk length: not a fused geometry
     (1, 300, 300, 8, 128, torch.bfloat16, "randn"),   # T > 256 in one chunk (two-byte counts): not a fused geometry
     (2, 9, 4, 3, 128, torch.bfloat16, "randn"),       # chunks shorter than a row oct: not a fused geometry
@@ -736,11 +746,44 @@ def test_fused_encode_gathers_paged_blocks(nat, ctx, oracle, layout):
         assert blob == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)), f"chunk {i}"
 
 
-def test_fused_setting_falls_back_outside_its_geometry(nat, ctx, oracle):
-    """C = 128 and C = 4096 are outside the fused kernel's range: the setting is a preference, the job still runs."""
+def test_fused_setting_is_a_preference_for_other_chunk_lengths(nat, ctx, oracle):
+    """The fused kernel codes 256-token chunks; with any other chunk length the setting is a preference and the job takes
+    k_quantize + k_cdf_encode (C = 128 and C = 4096 here: geometries the fused kernel does take at 256 tokens)."""
     for (L, T, H, D) in ((2, 20, 1, 128), (1, 12, 32, 128)):
         kv = make_kv(L, T, H, D, torch.bfloat16, "randn", seed=H)
         bins = default_bins(L)
         blobs, _, _ = encode_with_path(nat, ctx, "fused", nat.KVLayout.from_chunk(kv.to(DEV), "vllm"), 0, T, T, bins)
         b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
         assert blobs[0] == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+
+
+def test_fused_encode_of_the_70b_tp8_rank_shape_at_32k(nat, ctx, oracle):
+    """BASELINE configs[3]: Llama-3-70B, TP = 8 -- a rank holds 80 layers x 1 KV head x 128 = planes of 128 channels --
+    32 768 tokens = 128 chunks.  The whole job through lmc_encode_chunks' default path (AUTO picks the fused kernel:
+    20 work items of 8 planes per chunk x 128 chunks), decoded again and held against the quantisation bound, and three
+    chunks byte for byte against the oracle."""
+    L, T, H, D, cs = 80, 32768, 1, 128, 256
+    bins = [32] * 10 + [16] * 70 + [32] * 2 + [16] * 78
+    kv = make_kv(L, T, H, D, torch.bfloat16, "randn", seed=3).to(DEV)
+    lay = nat.KVLayout.from_chunk(kv, "vllm")
+    n = T // cs
+    stride = nat.r16(nat.blob_bound(L, cs, H, D))
+    blob_dev = torch.empty(n * stride, dtype=torch.uint8, device=DEV)
+    sizes = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ctx.encode_chunks(lay, 0, T, cs, bins, blob_dev.data_ptr(), stride, sizes.data_ptr())
+    out = torch.zeros_like(kv)
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, n, nat.KVLayout.from_chunk(out, "vllm"), 0, cs)
+    torch.cuda.synchronize()
+    ctx.raise_on_status("70B rank shape")
+    szs = sizes.cpu().tolist()
+    assert all(0 < s <= stride for s in szs)
+    for i in (0, 57, n - 1):
+        chunk = kv[:, :, i * cs:(i + 1) * cs].cpu()
+        b, code = oracle.torch_to_bits(chunk.reshape(L, 2, cs, H * D))
+        ref = oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+        assert blob_dev[i * stride:i * stride + szs[i]].cpu().numpy().tobytes() == ref, i
+        assert np.array_equal(bits_np(out[:, :, i * cs:(i + 1) * cs]).reshape(L, 2, cs, H * D), oracle.decode_blob(ref, oracle.BF16))
+    # size-independent property over the whole job: |decode(encode(x)) - x| within the quantisation bound
+    mx = kv.float().abs().amax(dim=(3, 4), keepdim=True)
+    M = torch.tensor([b // 2 - 1 for b in bins], dtype=torch.float32, device=DEV).reshape(2, L).T.reshape(L, 2, 1, 1, 1)
+    assert ((out.float() - kv.float()).abs() <= mx / (2 * M) + mx * 2.0 ** -7).all()
