@@ -16,6 +16,9 @@
 //             (v5 wrote every stream three times and read it twice: 1 GB of fabric traffic per 16 k context).
 // Several workgroups share a CU (4.6 KiB of LDS per wave + 2.5 KiB of reciprocals and bound table, <= 64 VGPRs: 8
 // waves per SIMD) and are in different phases at any time, so the loads of one hide under the coding of the others.
+// (Round 3 held a CU's first workgroups back by rank x 50 us so that its four slots would not run their phases in
+// lock-step; with the look-back between the two passes the slots drift apart by themselves and the same hold-back
+// costs 2 - 9 %: 0.925-0.933 ms without, 0.942-0.961 with, alternating rounds on one box.  Removed.)
 // Blobs are byte-identical to the two-kernel path (same device functions; tests/test_gpu_parity.py runs both).
 //
 // The look-back granules carry the launch's epoch (flag << 62 | epoch << 32 | value): a granule of another
@@ -51,16 +54,6 @@ struct FusedArgs {
   u8* scale_base;
   long long scale_stride;
   u32 epoch;  // 1 .. 2^30 - 1
-  // Staggered start (lmc_api.hip: 50 us, LMC_FUSED_STAGGER_US): every workgroup of a launch takes the same time, so
-  // the four workgroups a CU holds tend to run their phases in lock-step for the whole launch -- all fetch (HBM busy,
-  // VALU idle), then all code (VALU busy, HBM idle).  A first-generation workgroup (ticket < stagger_limit) draws its
-  // rank among the workgroups of ITS CU (hardware id -> cu_rank[]) and holds its fetch back by rank x stagger_ticks
-  // (s_memrealtime ticks, 10 ns): the CU's slots then run about a quarter period apart.  Measured over alternating
-  // processes on one box: 1.046-1.12 ms without, 1.010-1.059 with 50 us (-3 % on average).  Keyed on the ticket
-  // instead of the CU (rank = ticket / CUs) it does nothing: tickets follow dispatch order, which is not one
-  // workgroup per CU at a time.
-  u32 stagger_ticks, stagger_limit;
-  u32* cu_rank;  // [4096] zero at launch: the workgroup with the launch's last ticket clears it again on its way out
   int pl, ipc;   // planes per work item, items per chunk = ceil(P / pl)
   u32* stash;    // SPLIT geometries: FUSED_STASH_DWORDS per stream of the job, where a stream's counts wait for pass 2
 };
@@ -297,19 +290,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   u16* const ring = reinterpret_cast<u16*>(lds_all + wave * ENC_RING_DWORDS);  // ... and staging ring
 
   rtab_to_lds(rtab_lds);  // visible to the coder waves behind the barrier that ends phase A
-  if (fa.stagger_ticks && item < fa.stagger_limit) {
-    __shared__ u32 cu_slot;
-    if (threadIdx.x == 0) {
-      const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);  // HW_ID, XCC_ID
-      const u32 key = ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);  // XCC | SE, SH, CU
-      cu_slot = atomicAdd(&fa.cu_rank[key], 1u);
-    }
-    __syncthreads();
-    // wave-uniform, in SGPRs: the wait loop is scalar code (32-bit tick arithmetic: a hold is < 2^32 x 10 ns)
-    const u32 hold = (u32)__builtin_amdgcn_readfirstlane((int)(min(cu_slot, 3u) * fa.stagger_ticks));
-    const u32 t0 = (u32)__builtin_amdgcn_s_memrealtime();
-    while ((u32)__builtin_amdgcn_s_memrealtime() - t0 < hold) __builtin_amdgcn_s_sleep(32);
-  }
   // ---- phase A: quantise the item's planes ------------------------------------------------------------------
   {
     constexpr int TO = (Tc + 7) >> 3;  // row octs of a plane-chunk
@@ -443,8 +423,5 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   if (p0 + np == a.P && wave == NW - 1) {
     write_blob_static(blob, bo, a, (u32)Tc, wg_excl + wg_total, lane);
     if (lane == 0) a.sizes[chunk] = bo.streams + wg_excl + wg_total;
-  }
-  if (fa.stagger_ticks && item == (u32)(a.nchunks * fa.ipc) - 1u) {  // every first-generation rank was drawn long ago
-    for (u32 i = threadIdx.x; i < 4096u; i += 64u * NW) fa.cu_rank[i] = 0u;
   }
 }

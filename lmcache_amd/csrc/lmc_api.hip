@@ -42,8 +42,6 @@ struct lmc_ctx {
   bool ws_used = false;
   int num_cus = 256;
   int enc_path = LMC_ENCODE_PATH_AUTO;  // lmc_ctx_set_encode_path
-  int stagger_us = 50;                  // fused encode: staggered start of a CU's first workgroups (k_fused.h), microseconds; LMC_FUSED_STAGGER_US=0: off
-  u32* cu_rank = nullptr;
   u32 epoch = 0;                        // of the last fused launch (tags its look-back granules)
   unsigned long long* pack_table = nullptr;  // device copy of a pack's offset table while it is written (lmc_store_pack)
   size_t pack_table_bytes = 0;
@@ -103,7 +101,6 @@ int lmc_ctx_create(int device, lmc_ctx** out) {
   memset(c->status_h, 0, 64);
   e = hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming);
   if (e != hipSuccess) { g_last_hip = (int)e; (void)hipHostFree(c->status_h); delete c; return LMC_ERR_HIP; }
-  if (const char* e = getenv("LMC_FUSED_STAGGER_US")) c->stagger_us = atoi(e);
   *out = c;
   return LMC_OK;
 }
@@ -122,7 +119,6 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   if (c->store_arena) (void)hipFree(c->store_arena);
   if (c->load_slots) (void)hipFree(c->load_slots);
   if (c->pack_table) (void)hipFree(c->pack_table);
-  if (c->cu_rank) (void)hipFree(c->cu_rank);
   if (c->store_free) (void)hipEventDestroy(c->store_free);
   if (c->load_free) (void)hipEventDestroy(c->load_free);
   for (int i = 0; i < 64; i++) if (c->evpool[i]) (void)hipEventDestroy(c->evpool[i]);
@@ -351,12 +347,20 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   // of one chunk -- 8 planes of <= 128 channels, 4 of <= 256, else one
   const int nfull = (tok_end - tok_begin) / chunk_tokens;  // chunks of exactly chunk_tokens tokens; a ragged one may follow
   const bool fused_fits = chunk_tokens == (int)LMC_COUNTS_T && nfull > 0;
-  const int pl = C <= 128 ? 8 : C <= 256 ? 4 : 1, ipc = (P + pl - 1) / pl;
+  // planes per work item: narrow planes are grouped until an item has about eight streams -- one per wave (C = 128,
+  // 80 layers, 128 chunks, measured: 4 planes = 8 streams per item 0.65 ms, 8 planes 0.68, 2 planes 0.80)
+  int pl = C <= 256 ? (8 / G > 1 ? 8 / G : 1) : 1;
+  if (const char* e = getenv("LMC_FUSED_PL")) { const int v = atoi(e); if (v >= 1 && v * G <= 16 && C <= 256) pl = v; }  // A/B switch (tools/probes)
+  const int ipc = (P + pl - 1) / pl;
   // AUTO: the fused kernel pays once its workgroups fill the slots of the chip (4 per CU): measured on MI355X with
   // 64 planes of 1024 channels, 4 / 8 / 12 / 16 / 32 / 64 chunks: fused / two-kernel time = 1.27 / 1.16 / 1.05 / 1.00 /
   // 0.91 / 0.90 (tools/probes/encode_ab.hip)
+  // Planes of more than 1024 channels (one item = 2 MB of raw KV, 64 streams): at one generation of workgroups nothing
+  // overlaps and the fused kernel loses (C = 4096, 16 chunks: 1.54 vs 1.25-1.31 ms), at four generations it is 2-5 %
+  // ahead (64 chunks: 4.42-4.53 vs 4.62-4.66 ms) -- AUTO takes it from four generations on.
+  const long long auto_min = (C > 1024 ? 16ll : 4ll) * c->num_cus;
   const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
-                                    (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * ipc >= 4ll * c->num_cus));
+                                    (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * ipc >= auto_min));
   const bool two_kernel_part = !fused || nfull < nchunks;  // chunks that code into scratch slots
   int rc = reserve_locked(c, L, H, D, chunk_tokens, nchunks, two_kernel_part, fused && C > 1024);
   if (rc) return rc;
@@ -448,13 +452,6 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     const dim3 grid((unsigned)((long long)nfull * ipc)), block(64 * FUSED_WAVES);
     fa.e.ticket_base = c->tickets_drawn;
     if ((rc = prof_mark(c, s))) return rc;
-    if (c->stagger_us > 0 && (long long)nfull * ipc >= 8ll * c->num_cus) {
-      if (!c->cu_rank) {  // zeroed once; every launch leaves it zero
-        HIP_TRY(hipMalloc((void**)&c->cu_rank, 4096 * sizeof(u32)));
-        HIP_TRY(hipMemsetAsync(c->cu_rank, 0, 4096 * sizeof(u32), s));
-      }
-      fa.stagger_ticks = (u32)c->stagger_us * 100u; fa.stagger_limit = 4u * (u32)c->num_cus; fa.cu_rank = c->cu_rank;
-    }
     if (src->dtype == LMC_DTYPE_BF16) launch_fused<LMC_DTYPE_BF16>(C, grid, block, s, fa);
     else launch_fused<LMC_DTYPE_FP16>(C, grid, block, s, fa);
     const hipError_t le = hipGetLastError();
