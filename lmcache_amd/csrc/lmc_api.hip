@@ -33,13 +33,24 @@ static thread_local int g_last_hip = 0;
 struct lmc_ctx {
   int device;
   std::mutex mu;
-  // encode workspace
-  u32* sym4 = nullptr;  size_t sym4_bytes = 0;
-  u8* scratch = nullptr; size_t scratch_bytes = 0;
-  u32* stash = nullptr; size_t stash_bytes = 0;     // fused encode of wide planes: the streams' counts between the two passes
-  unsigned long long* agg = nullptr; size_t agg_bytes = 0;  // look-back granules of the in-kernel compaction
-  hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
-  bool ws_used = false;
+  // Encode workspaces.  An encode job owns a workspace from its first kernel to its last; the job that takes it next
+  // waits (on its own stream) for the event behind that last kernel.  TWO of them, so that a worker thread's
+  // non-blocking put and the engine thread's put (the reference's model: local_backend.py:41-45, 72-80) run side by side
+  // on their two streams instead of one behind the other: a job takes the slot its stream used last, else an idle one
+  // (the second is allocated when the first is found busy by another stream for the first time), else the first.
+  struct Workspace {
+    u32* sym4 = nullptr;  size_t sym4_bytes = 0;       // symbols between the quantise stage and the coder
+    u8* scratch = nullptr; size_t scratch_bytes = 0;   // two-kernel path: the streams before they are placed
+    u32* stash = nullptr; size_t stash_bytes = 0;      // fused encode of wide planes: the streams' counts between the two passes
+    unsigned long long* agg = nullptr; size_t agg_bytes = 0;  // look-back granules of the in-kernel compaction
+    hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
+    bool ws_used = false;
+    hipStream_t last_stream = nullptr;
+    u32* ticket = nullptr;     // device work-ticket counter of the coder launches (k_encode.h: EncodeArgs::ticket) ...
+    u32 tickets_drawn = 0;     // ... and how many tickets the launches so far have drawn (mod 2^32): per workspace, since
+                               // launches that share a counter must be ordered
+  };
+  Workspace ws[2];
   int num_cus = 256;
   int enc_path = LMC_ENCODE_PATH_AUTO;  // lmc_ctx_set_encode_path
   u32 epoch = 0;                        // of the last fused launch (tags its look-back granules)
@@ -52,8 +63,6 @@ struct lmc_ctx {
   hipEvent_t store_free = nullptr, load_free = nullptr;  // the arena / the slots may be reused behind these
   bool store_used = false, load_used = false;
   hipEvent_t evpool[64] = {}; int evnext = 0;         // fork / join events of the two legs (round robin)
-  u32* ticket = nullptr;                // device work-ticket counter of the coder launches (k_encode.h: EncodeArgs::ticket)
-  u32 tickets_drawn = 0;                // ... and how many tickets the launches so far have drawn (mod 2^32)
   u32* status_h = nullptr;  // pinned, device-accessible
   // optional per-kernel timing (lmc_ctx_profile)
   bool profile = false;
@@ -99,8 +108,10 @@ int lmc_ctx_create(int device, lmc_ctx** out) {
   hipError_t e = hipHostMalloc((void**)&c->status_h, 64, hipHostMallocMapped | hipHostMallocPortable);
   if (e != hipSuccess) { g_last_hip = (int)e; delete c; return LMC_ERR_HIP; }
   memset(c->status_h, 0, 64);
-  e = hipEventCreateWithFlags(&c->ws_free, hipEventDisableTiming);
-  if (e != hipSuccess) { g_last_hip = (int)e; (void)hipHostFree(c->status_h); delete c; return LMC_ERR_HIP; }
+  for (int k = 0; k < 2; k++) {
+    e = hipEventCreateWithFlags(&c->ws[k].ws_free, hipEventDisableTiming);
+    if (e != hipSuccess) { g_last_hip = (int)e; (void)hipHostFree(c->status_h); delete c; return LMC_ERR_HIP; }
+  }
   *out = c;
   return LMC_OK;
 }
@@ -108,12 +119,15 @@ int lmc_ctx_create(int device, lmc_ctx** out) {
 int lmc_ctx_destroy(lmc_ctx* c) {
   if (!c) return LMC_OK;
   (void)hipSetDevice(c->device);
-  if (c->ws_used) (void)hipEventSynchronize(c->ws_free);
-  if (c->sym4) (void)hipFree(c->sym4);
-  if (c->scratch) (void)hipFree(c->scratch);
-  if (c->stash) (void)hipFree(c->stash);
-  if (c->agg) (void)hipFree(c->agg);
-  if (c->ticket) (void)hipFree(c->ticket);
+  for (lmc_ctx::Workspace& w : c->ws) {
+    if (w.ws_used) (void)hipEventSynchronize(w.ws_free);
+    if (w.sym4) (void)hipFree(w.sym4);
+    if (w.scratch) (void)hipFree(w.scratch);
+    if (w.stash) (void)hipFree(w.stash);
+    if (w.agg) (void)hipFree(w.agg);
+    if (w.ticket) (void)hipFree(w.ticket);
+    if (w.ws_free) (void)hipEventDestroy(w.ws_free);
+  }
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->copy_stream2) { (void)hipStreamSynchronize(c->copy_stream2); (void)hipStreamDestroy(c->copy_stream2); }
   if (c->store_arena) (void)hipFree(c->store_arena);
@@ -122,7 +136,6 @@ int lmc_ctx_destroy(lmc_ctx* c) {
   if (c->store_free) (void)hipEventDestroy(c->store_free);
   if (c->load_free) (void)hipEventDestroy(c->load_free);
   for (int i = 0; i < 64; i++) if (c->evpool[i]) (void)hipEventDestroy(c->evpool[i]);
-  if (c->ws_free) (void)hipEventDestroy(c->ws_free);
   for (int i = 0; i < 8; i++) if (c->pev[i]) (void)hipEventDestroy(c->pev[i]);
   if (c->status_h) (void)hipHostFree(c->status_h);
   delete c;
@@ -259,7 +272,7 @@ static void launch_fused(int C, dim3 grid, dim3 block, hipStream_t s, const Fuse
 
 // caller holds ctx->mu.  The symbol workspace and the look-back granules of `max_chunks` chunks; the stream scratch
 // too when `scratch` (the two-kernel path codes into scratch slots; the fused kernel codes straight into the blobs).
-static int reserve_locked(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_chunks, bool scratch, bool stash = false) {
+static int reserve_locked(lmc_ctx::Workspace* c, int L, int H, int D, int chunk_tokens, int max_chunks, bool scratch, bool stash = false) {
   const size_t P = 2 * (size_t)L, C = (size_t)H * D, G = (C + 63) / 64, TQ = ((size_t)chunk_tokens + 3) / 4;
   const size_t need_sym = (size_t)max_chunks * P * TQ * C * 4;
   const size_t need_scr = scratch ? (size_t)max_chunks * P * G * lmc_group_cap_bytes((uint32_t)chunk_tokens) : 0;
@@ -286,7 +299,7 @@ int lmc_ctx_reserve(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_c
   if (!c || L < 1 || H < 1 || D < 8 || chunk_tokens < 1 || max_chunks < 1) return LMC_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   std::lock_guard<std::mutex> lk(c->mu);
-  return reserve_locked(c, L, H, D, chunk_tokens, max_chunks, true);
+  return reserve_locked(&c->ws[0], L, H, D, chunk_tokens, max_chunks, true);
 }
 
 int lmc_quantize(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t ntok, const int32_t* bins_h,
@@ -362,9 +375,22 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
                                     (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * ipc >= auto_min));
   const bool two_kernel_part = !fused || nfull < nchunks;  // chunks that code into scratch slots
-  int rc = reserve_locked(c, L, H, D, chunk_tokens, nchunks, two_kernel_part, fused && C > 1024);
+  // which workspace: the one this stream used last (stream order alone keeps the jobs apart), else an idle one, else --
+  // both busy with other streams' jobs -- the first, behind its job
+  lmc_ctx::Workspace* w = nullptr;
+  for (lmc_ctx::Workspace& k : c->ws)
+    if (!w && k.ws_used && k.last_stream == s) w = &k;
+  for (lmc_ctx::Workspace& k : c->ws) {
+    if (w) break;
+    if (!k.ws_used) { w = &k; break; }
+    const hipError_t q = hipEventQuery(k.ws_free);
+    if (q == hipSuccess) w = &k;
+    else (void)hipGetLastError();  // hipErrorNotReady
+  }
+  if (!w) w = &c->ws[0];
+  int rc = reserve_locked(w, L, H, D, chunk_tokens, nchunks, two_kernel_part, fused && C > 1024);
   if (rc) return rc;
-  if (c->ws_used) HIP_TRY(hipStreamWaitEvent(s, c->ws_free, 0));
+  if (w->ws_used) HIP_TRY(hipStreamWaitEvent(s, w->ws_free, 0));
   // A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next (k_offload, k_pack_scan,
   // the host): no stale word of an earlier job may stand in for it.
   HIP_TRY(hipMemsetAsync(sizes, 0, sizeof(uint32_t) * (size_t)nchunks, s));
@@ -377,39 +403,39 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
 
   EncodeArgs ea;
   memset(&ea, 0, sizeof ea);
-  ea.sym4 = c->sym4;
+  ea.sym4 = w->sym4;
   ea.tok_begin = tok_begin; ea.tok_end = tok_end; ea.chunk_tokens = chunk_tokens; ea.nchunks = nchunks;
   ea.P = P; ea.C = C; ea.G = G; ea.TQ = TQ;
   ea.sym_stride = (long long)TQ * C;
   ea.blobs = (u8*)blobs; ea.blob_stride = (long long)blob_stride;
-  ea.scratch = c->scratch; ea.cap = cap;
+  ea.scratch = w->scratch; ea.cap = cap;
   ea.status = job_status ? job_status : c->status_h;
   ea.bins = bins;
-  ea.agg = c->agg; ea.sizes = sizes;
+  ea.agg = w->agg; ea.sizes = sizes;
   ea.L = L; ea.H = H; ea.D = D; ea.dtype = src->dtype;
   u8* const scale_base = (u8*)blobs + hl.off_scales;  // off_scales does not depend on T
 
-  if (!c->ticket) {
-    HIP_TRY(hipMalloc((void**)&c->ticket, 64));
-    HIP_TRY(hipMemsetAsync(c->ticket, 0, 64, s));  // ordered in front of the first launch that draws from it
-    c->tickets_drawn = 0;
+  if (!w->ticket) {
+    HIP_TRY(hipMalloc((void**)&w->ticket, 64));
+    HIP_TRY(hipMemsetAsync(w->ticket, 0, 64, s));  // ordered in front of the first launch that draws from it
+    w->tickets_drawn = 0;
   }
-  ea.ticket = c->ticket;
+  ea.ticket = w->ticket;
   c->pn = 0;
   // A launch that draws tickets and fails leaves the host's count and the device counter apart: both start over.
   auto tickets_reset = [&]() {
-    (void)hipMemsetAsync(c->ticket, 0, 64, s);
-    c->tickets_drawn = 0;
+    (void)hipMemsetAsync(w->ticket, 0, 64, s);
+    w->tickets_drawn = 0;
   };
   // the chunks [c0, c0 + n) of the job with the two kernels: k_quantize, then k_cdf_encode (CDF or counts table +
   // coder + in-kernel compaction of the streams into the blobs).  Measured alternatives that lost: HISTORY.md.
   auto two_kernels = [&](int c0, int n) -> int {
     EncodeArgs e2 = ea;
     e2.tok_begin = tok_begin + c0 * chunk_tokens; e2.nchunks = n;
-    e2.sym4 = c->sym4 + (size_t)c0 * P * (size_t)ea.sym_stride;
+    e2.sym4 = w->sym4 + (size_t)c0 * P * (size_t)ea.sym_stride;
     e2.blobs = (u8*)blobs + (size_t)c0 * blob_stride;
-    e2.scratch = c->scratch + (size_t)c0 * PG * cap;
-    e2.agg = c->agg + (size_t)c0 * PG;
+    e2.scratch = w->scratch + (size_t)c0 * PG * cap;
+    e2.agg = w->agg + (size_t)c0 * PG;
     e2.sizes = sizes + c0;
     QuantArgs qa;
     memset(&qa, 0, sizeof qa);
@@ -429,12 +455,12 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     const bool counts_only = chunk_tokens == (int)LMC_COUNTS_T && e2.tok_begin + n * chunk_tokens <= tok_end && PG % 8 == 0;
     const int nw = counts_only ? 8 : ENC_WAVES;
     const unsigned nwg = (unsigned)((ngroups + nw - 1) / nw);
-    e2.ticket_base = c->tickets_drawn;
+    e2.ticket_base = w->tickets_drawn;
     if (counts_only) hipLaunchKernelGGL((k_cdf_encode<true, true, 8, true>), dim3(nwg), dim3(64 * 8), 0, s, e2);
     else hipLaunchKernelGGL((k_cdf_encode<true, true>), dim3(nwg), dim3(64 * ENC_WAVES), 0, s, e2);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) { g_last_hip = (int)le; tickets_reset(); return LMC_ERR_HIP; }
-    c->tickets_drawn += nwg;  // only a launch that went out has drawn
+    w->tickets_drawn += nwg;  // only a launch that went out has drawn
     return prof_mark(c, s);
   };
   if (fused) {
@@ -448,15 +474,15 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     c->epoch = (c->epoch + 1u) & 0x3fffffffu;
     if (!c->epoch) c->epoch = 1u;
     fa.epoch = c->epoch;
-    fa.pl = pl; fa.ipc = ipc; fa.stash = c->stash;
+    fa.pl = pl; fa.ipc = ipc; fa.stash = w->stash;
     const dim3 grid((unsigned)((long long)nfull * ipc)), block(64 * FUSED_WAVES);
-    fa.e.ticket_base = c->tickets_drawn;
+    fa.e.ticket_base = w->tickets_drawn;
     if ((rc = prof_mark(c, s))) return rc;
     if (src->dtype == LMC_DTYPE_BF16) launch_fused<LMC_DTYPE_BF16>(C, grid, block, s, fa);
     else launch_fused<LMC_DTYPE_FP16>(C, grid, block, s, fa);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) { g_last_hip = (int)le; tickets_reset(); return LMC_ERR_HIP; }
-    c->tickets_drawn += grid.x;
+    w->tickets_drawn += grid.x;
     if ((rc = prof_mark(c, s))) return rc;
     if (nfull < nchunks && (rc = two_kernels(nfull, nchunks - nfull))) return rc;  // the ragged last chunk
   } else if (nfull > 0 && nfull < nchunks && chunk_tokens == (int)LMC_COUNTS_T) {
@@ -466,8 +492,9 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     if ((rc = two_kernels(0, nchunks))) return rc;
   }
 
-  HIP_TRY(hipEventRecord(c->ws_free, s));
-  c->ws_used = true;
+  HIP_TRY(hipEventRecord(w->ws_free, s));
+  w->ws_used = true;
+  w->last_stream = s;
   return LMC_OK;
 }
 

@@ -355,6 +355,44 @@ def test_llama70b_tp8_rank_shape(nat, ctx, oracle):
     assert np.array_equal(bits_np(outt[79][1][:cs]).reshape(cs, H * D), want0[79, 1])
 
 
+def test_encodes_on_two_streams_do_not_wait_for_each_other(nat, ctx, oracle):
+    """lmc_ctx holds two encode workspaces: a job on stream B must not queue behind a job on stream A (the reference's
+    model is a worker thread putting while the engine thread puts, local_backend.py:41-45, 72-80).  Stream A is kept busy
+    by a spin kernel with an encode queued BEHIND it; the encode on stream B has to finish long before A's spin ends --
+    with one workspace it would wait for A's job, i.e. for the spin.  Bytes of both jobs against the oracle."""
+    L, T, H, D = 2, 256, 8, 128
+    bins = default_bins(L)
+    kva, kvb = make_kv(L, T, H, D, torch.bfloat16, "randn", 5), make_kv(L, T, H, D, torch.bfloat16, "rand", 6)
+    da, db = kva.to(DEV), kvb.to(DEV)
+    stride = nat.r16(nat.blob_bound(L, T, H, D))
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    ba, bb = torch.zeros(stride, dtype=torch.uint8, device=DEV), torch.zeros(stride, dtype=torch.uint8, device=DEV)
+    za, zb = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    # warm both workspaces (allocation of the second one synchronises nothing, but keep it out of the timing)
+    ctx.encode_chunks(nat.KVLayout.from_chunk(da, "vllm"), 0, T, T, bins, ba.data_ptr(), stride, za.data_ptr(), stream=sa.cuda_stream)
+    ctx.encode_chunks(nat.KVLayout.from_chunk(db, "vllm"), 0, T, T, bins, bb.data_ptr(), stride, zb.data_ptr(), stream=sb.cuda_stream)
+    torch.cuda.synchronize()
+    spin_cycles = 400_000_000  # torch.cuda._sleep counts shader clocks: ~0.2 s
+    a_done, b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = torch.cuda.Event(enable_timing=True)
+    t0.record(sa)
+    with torch.cuda.stream(sa):
+        torch.cuda._sleep(spin_cycles)
+    ctx.encode_chunks(nat.KVLayout.from_chunk(da, "vllm"), 0, T, T, bins, ba.data_ptr(), stride, za.data_ptr(), stream=sa.cuda_stream)
+    a_done.record(sa)
+    b0.record(sb)
+    ctx.encode_chunks(nat.KVLayout.from_chunk(db, "vllm"), 0, T, T, bins, bb.data_ptr(), stride, zb.data_ptr(), stream=sb.cuda_stream)
+    b1.record(sb)
+    torch.cuda.synchronize()
+    ctx.raise_on_status("two streams")
+    a_ms, b_ms = t0.elapsed_time(a_done), b0.elapsed_time(b1)
+    assert a_ms > 20.0, f"the spin did not hold stream A ({a_ms:.1f} ms)"
+    assert b_ms < a_ms / 4, f"the encode on stream B took {b_ms:.1f} ms while stream A was held for {a_ms:.1f} ms"
+    for kv, blob, sz in ((kva, ba, za), (kvb, bb, zb)):
+        b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
+        assert blob[:int(sz.item())].cpu().numpy().tobytes() == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+
+
 def test_concurrent_calls_share_one_context(nat, ctx, oracle):
     """Re-entrancy (SURVEY.md 8b threading): two host threads, each on its own stream, encode and decode
     different KV through the SAME context; the workspace is ordered by events, results must not mix."""
