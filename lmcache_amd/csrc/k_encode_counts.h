@@ -496,7 +496,54 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
     if (lane == 0 && (t.exact > alloc || t.exact + 16 > a.cap)) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);
   };
   if constexpr (COUNTS_ONLY) {
-    counts_stream();
+    // Launches of 256-token chunks only (lmc_api.hip: P * G is a multiple of NW): like the fused kernel, the streams are
+    // placed BETWEEN their two passes -- histogram, allocation, one look-back per workgroup, then the coder writes
+    // straight into the blob.  No scratch slot, no copy.
+    const int n = a.P * a.G;
+    const u32 p_i = pg_i / (u32)a.G;
+    const CountsStream s = counts_stream_of(a, (int)chunk_i, (int)p_i, (int)(pg_i - p_i * (u32)a.G), lane);
+    CountsState cs;
+    alloc = counts_hist_stream(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
+    __shared__ u32 wg_alloc[NW];
+    __shared__ u32 wg_excl;
+    if (lane == 0) wg_alloc[wave] = alloc;
+    __syncthreads();
+    u32 before = 0, wg_total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      before += w < wave ? wg_alloc[w] : 0u;
+      wg_total += wg_alloc[w];
+    }
+    if (wave == 0) {
+      unsigned long long* agg = a.agg + (long long)chunk_i * n;
+      const int wgi = (int)pg_i / NW;
+      if (lane == 0 && wgi > 0) agg_store(agg + wgi, AGG_A, wg_total);
+      const u32 e = lookback_exclusive(agg, wgi, lane, a.status);
+      if (lane == 0) {
+        agg_store(agg + wgi, AGG_P, e + wg_total);
+        wg_excl = e;
+      }
+    }
+    __syncthreads();
+    const u32 beg = wg_excl + before;
+    const BlobOff bo = lmc_blob_off((u32)a.P, LMC_COUNTS_T, (u32)a.G);
+    u8* const blob = a.blobs + (long long)chunk_i * a.blob_stride;
+    u8* const out = blob + bo.streams + beg;
+    counts_open_stream(s, cs, out, hist, lane);
+    const u32 exact = cs.head + counts_code_stream<true>(a, s, hist, wring, rtab_lds, lane, reinterpret_cast<u16*>(out + cs.head));
+    const u32 padded = (exact + 15u) & ~15u;
+    if (alloc > padded) zero_fill16(out + padded, alloc - padded, lane);
+    if (lane == 0) {
+      u32* d = reinterpret_cast<u32*>(blob + bo.gdir) + 2 * pg_i;
+      d[0] = beg;
+      d[1] = beg + exact;
+      if (exact > alloc) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);  // the bound is a theorem: never
+    }
+    if ((int)pg_i == n - 1) {  // the chunk's last stream knows the chunk's size: header, static sections, size word
+      write_blob_static(blob, bo, a, LMC_COUNTS_T, wg_excl + wg_total, lane);
+      if (lane == 0) a.sizes[chunk_i] = bo.streams + wg_excl + wg_total;
+    }
+    return;
   } else if constexpr (ENCODE && QUADSYM) {
     // 256-token chunks are coded on their symbol counts (LMC_MODEL_COUNTS), every other length on the 16-bit CDF
     const int chunk_of = (int)chunk_i;

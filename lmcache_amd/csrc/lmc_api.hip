@@ -270,12 +270,13 @@ static void launch_fused(int C, dim3 grid, dim3 block, hipStream_t s, const Fuse
   else hipLaunchKernelGGL((k_encode_fused<64, 2, 4, DT, FUSED_WAVES>), grid, block, 0, s, fa);
 }
 
-// caller holds ctx->mu.  The symbol workspace and the look-back granules of `max_chunks` chunks; the stream scratch
-// too when `scratch` (the two-kernel path codes into scratch slots; the fused kernel codes straight into the blobs).
-static int reserve_locked(lmc_ctx::Workspace* c, int L, int H, int D, int chunk_tokens, int max_chunks, bool scratch, bool stash = false) {
+// caller holds ctx->mu.  The symbol workspace and the look-back granules of `max_chunks` chunks, stream scratch for
+// `scratch_chunks` of them (only the general coder launch -- chunk lengths other than 256, a ragged last chunk -- codes
+// into scratch slots; the fused kernel and the counts-only coder launch code straight into the blobs).
+static int reserve_locked(lmc_ctx::Workspace* c, int L, int H, int D, int chunk_tokens, int max_chunks, int scratch_chunks, bool stash = false) {
   const size_t P = 2 * (size_t)L, C = (size_t)H * D, G = (C + 63) / 64, TQ = ((size_t)chunk_tokens + 3) / 4;
   const size_t need_sym = (size_t)max_chunks * P * TQ * C * 4;
-  const size_t need_scr = scratch ? (size_t)max_chunks * P * G * lmc_group_cap_bytes((uint32_t)chunk_tokens) : 0;
+  const size_t need_scr = (size_t)scratch_chunks * P * G * lmc_group_cap_bytes((uint32_t)chunk_tokens);
   const size_t need_stash = stash ? (size_t)max_chunks * P * G * FUSED_STASH_DWORDS * 4 : 0;
   const size_t need_agg = (size_t)max_chunks * P * G * 8;
   if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && need_agg <= c->agg_bytes && need_stash <= c->stash_bytes)
@@ -299,7 +300,7 @@ int lmc_ctx_reserve(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_c
   if (!c || L < 1 || H < 1 || D < 8 || chunk_tokens < 1 || max_chunks < 1) return LMC_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   std::lock_guard<std::mutex> lk(c->mu);
-  return reserve_locked(&c->ws[0], L, H, D, chunk_tokens, max_chunks, true);
+  return reserve_locked(&c->ws[0], L, H, D, chunk_tokens, max_chunks, max_chunks);
 }
 
 int lmc_quantize(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t ntok, const int32_t* bins_h,
@@ -374,7 +375,10 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   const long long auto_min = (C > 1024 ? 16ll : 4ll) * c->num_cus;
   const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
                                     (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * ipc >= auto_min));
-  const bool two_kernel_part = !fused || nfull < nchunks;  // chunks that code into scratch slots
+  // chunks that go through the general coder launch (scratch slots): every chunk of a job whose chunks are not 256 tokens
+  // long or whose streams do not fill 8-wave workgroups, else only a ragged last one
+  const bool general_only = chunk_tokens != (int)LMC_COUNTS_T || ((long long)P * G) % 8 != 0;
+  const int scratch_chunks = general_only ? (fused ? nchunks - nfull : nchunks) : nchunks - nfull;
   // which workspace: the one this stream used last (stream order alone keeps the jobs apart), else an idle one, else --
   // both busy with other streams' jobs -- the first, behind its job
   lmc_ctx::Workspace* w = nullptr;
@@ -388,7 +392,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     else (void)hipGetLastError();  // hipErrorNotReady
   }
   if (!w) w = &c->ws[0];
-  int rc = reserve_locked(w, L, H, D, chunk_tokens, nchunks, two_kernel_part, fused && C > 1024);
+  int rc = reserve_locked(w, L, H, D, chunk_tokens, nchunks, scratch_chunks, fused && C > 1024);
   if (rc) return rc;
   if (w->ws_used) HIP_TRY(hipStreamWaitEvent(s, w->ws_free, 0));
   // A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next (k_offload, k_pack_scan,
@@ -434,7 +438,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     e2.tok_begin = tok_begin + c0 * chunk_tokens; e2.nchunks = n;
     e2.sym4 = w->sym4 + (size_t)c0 * P * (size_t)ea.sym_stride;
     e2.blobs = (u8*)blobs + (size_t)c0 * blob_stride;
-    e2.scratch = w->scratch + (size_t)c0 * PG * cap;
+    e2.scratch = w->scratch;  // (at most one launch of a job codes into scratch: its slots are counted from its first chunk)
     e2.agg = w->agg + (size_t)c0 * PG;
     e2.sizes = sizes + c0;
     QuantArgs qa;

@@ -7,22 +7,29 @@ the VALU roof -- so those numbers are the committed profile's, never hand-copied
 sq.db     --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES
 fetch.db  --pmc FETCH_SIZE GRBM_GUI_ACTIVE
 write.db  --pmc WRITE_SIZE
-(separate passes, as MI355X_MICROARCH.md prescribes).  Only full-context dispatches (>= 4 M work-items) count.
-FETCH_SIZE is doubled for k_quantize (16 B / lane streaming loads: the guide's gfx950 correction), taken as is for
-k_cdf_encode (4 B / lane symbol loads and its own L2-hot scratch re-read).  k_encode_fused (the default launch at
-the bench's size) mixes both kinds: its raw-KV loads are the quantiser's (16 B / lane, tallied at half), the rest is
-the coder's -- and its FETCH_SIZE is indeed k_quantize's + k_cdf_encode's to 3 % (the symbols do NOT come back from
-L2: 128 plane-chunks in flight per XCD are 16-32 MB against 4 MB of L2) -- so the half the counter misses is added
-once: FETCH_SIZE(k_encode_fused) + FETCH_SIZE(k_quantize) when the database holds both (the A/B probe), x 1.55
-otherwise.  The totals (`traffic_bytes_per_step`, `valu_insts_per_step`) are those of the DEFAULT launch path:
-k_encode_fused when it ran, else k_quantize + k_cdf_encode.
+(separate passes, as MI355X_MICROARCH.md prescribes).  Only full-context dispatches (>= 2 M work-items) count.
+The byte counters are corrected with MEASURED factors: profiles/r04_counter_calibration.json (tools/probes/
+counter_calibration under the same two PMC passes: 1 GiB moved by each of the kernels' access patterns) -- FETCH_SIZE
+reports half of every read pattern the kernels use (16 B and 4 B per lane, temporal or not, global_load_lds alike),
+WRITE_SIZE is exact.  (Rounds 1-3 doubled FETCH_SIZE for the 16 B / lane loads only and took the 4 B / lane symbol
+loads as reported: their `traffic` was low by the symbols' re-reads.)  The totals (`traffic_bytes_per_step`,
+`valu_insts_per_step`) are those of the DEFAULT launch path: k_encode_fused when it ran, else k_quantize + k_cdf_encode.
 """
 import json
 import sqlite3
 import sys
 
+import os
+
 MIN_GRID = 2_000_000  # k_encode_fused: 4096 workgroups x 512
-KERNELS = {"k_encode_fused": 1.55, "k_quantize": 2.0, "k_cdf_encode": 1.0}  # kernel name prefix -> FETCH_SIZE factor
+CAL = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r04_counter_calibration.json")))["factors"]
+# kernel name prefix -> (FETCH_SIZE factor, WRITE_SIZE factor) from the calibrated patterns the kernel uses
+KERNELS = {"k_encode_fused": (max(CAL["rd16_nt"], CAL["rd4"], CAL["rd4_nt"]), CAL["wr4_nt"]),
+           "k_quantize": (CAL["rd16"], CAL["wr16"]),
+           "k_cdf_encode": (max(CAL["rd4"], CAL["rd_lds16"]), CAL["wr16_nt"]),
+           "k_decode": (CAL["rd4_nt"], CAL["wr2_buf"])}
+assert min(CAL[k] for k in ("rd16_nt", "rd4", "rd4_nt", "rd16", "rd_lds16")) > 0.97 * max(CAL[k] for k in ("rd16_nt", "rd4", "rd4_nt", "rd16", "rd_lds16")), \
+    "the read patterns no longer share one FETCH_SIZE factor: split the kernels' reads by pattern"
 
 
 def counters(path):
@@ -40,10 +47,11 @@ def counters(path):
 def main(argv):
     tag, sq, fe, wr = argv[1:5]
     csq, cfe, cwr = counters(sq), counters(fe), counters(wr)
-    res = {"source": [f"profiles/{tag}_pmc.md", f"profiles/{tag}_bench_kernel_stats.md"], "kernels": {}}
+    res = {"source": [f"profiles/{tag}_pmc.md", f"profiles/{tag}_bench_kernel_stats.md", "profiles/r04_counter_calibration.md"],
+           "kernels": {}}
     traffic = valu = 0.0
     dominant, dom_us = None, 0.0
-    for k, factor in KERNELS.items():
+    for k, (factor, wfactor) in KERNELS.items():
         if k not in csq or k not in cfe or k not in cwr:
             continue
         fetch_kib = cfe[k]["FETCH_SIZE"][0]
@@ -53,12 +61,12 @@ def main(argv):
         insts = csq[k]["SQ_INSTS_VALU"][0]
         active, sq_ns, _ = csq[k]["SQ_ACTIVE_INST_VALU"]
         busy = active * 4.0 / (1024.0 * sq_ns * clock_ghz)
-        hbm = (fetch_kib * factor + write_kib) * 1024.0
-        if k == "k_encode_fused" and "k_quantize" in cfe:
-            hbm = (fetch_kib + cfe["k_quantize"]["FETCH_SIZE"][0] + write_kib) * 1024.0
-        res["kernels"][k] = {"avg_us_profiled": round(sq_ns / 1e3, 1), "hbm_bytes": int(hbm), "valu_insts": int(insts),
+        hbm = (fetch_kib * factor + write_kib * wfactor) * 1024.0
+        res["kernels"][k] = {"avg_us_profiled": round(sq_ns / 1e3, 1), "hbm_bytes": int(hbm),
+                             "fetch_bytes": int(fetch_kib * factor * 1024.0), "write_bytes": int(write_kib * wfactor * 1024.0),
+                             "valu_insts": int(insts),
                              "valu_busy": round(busy, 3), "clock_GHz": round(clock_ghz, 3)}
-        default_path = k == "k_encode_fused" or "k_encode_fused" not in csq
+        default_path = k == "k_encode_fused" or (k != "k_decode" and "k_encode_fused" not in csq)
         if default_path:
             traffic += hbm
             valu += insts
