@@ -35,6 +35,7 @@ struct QuantArgs {
   long long scale_stride;
   unsigned long long* agg;  // the coder's look-back granules, zeroed here (saves a memset dispatch), or NULL
   long long agg_n;
+  u32* sizes;               // ... and the job's size words [nchunks] (0 = "this chunk's encode did not finish"), or NULL
 };
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256) void k_quantize(QuantArgs a) {
   if (QUAD && a.agg) {  // the launch has at least 256 threads per plane-chunk, a plane-chunk at most 64 granules
     const long long i = (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
     if (i < a.agg_n) a.agg[i] = 0ull;
+    if (a.sizes && i < a.nchunks) a.sizes[i] = 0u;
   }
   const int TO = (a.TQ + 1) >> 1;
   int oct = SPLIT > 1 ? ((int)blockIdx.x * 4 + wave) / SPLIT : ((int)blockIdx.x * 4 + wave) * RPW + sub;

@@ -395,9 +395,10 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   int rc = reserve_locked(w, L, H, D, chunk_tokens, nchunks, scratch_chunks, fused && C > 1024);
   if (rc) return rc;
   if (w->ws_used) HIP_TRY(hipStreamWaitEvent(s, w->ws_free, 0));
-  // A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next (k_offload, k_pack_scan,
-  // the host): no stale word of an earlier job may stand in for it.
-  HIP_TRY(hipMemsetAsync(sizes, 0, sizeof(uint32_t) * (size_t)nchunks, s));
+  // (A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next -- k_offload,
+  // k_pack_scan, the host --: the kernels clear the job's words themselves, k_quantize / the first item of a chunk in
+  // k_encode_fused, so that no stale word of an earlier job stands in for a size and no memset dispatch sits in front
+  // of every job.)
 
   const int TQ = (chunk_tokens + 3) / 4;
   const u32 cap = lmc_group_cap_bytes((uint32_t)chunk_tokens);  // scratch slot stride (and capacity)
@@ -450,6 +451,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     qa.scale_base = scale_base + (size_t)c0 * blob_stride;
     qa.scale_stride = (long long)blob_stride;
     qa.agg = e2.agg; qa.agg_n = (long long)n * PG;  // zeroed by the quantiser: one dispatch less per job
+    qa.sizes = e2.sizes;
     int r;
     if ((r = prof_mark(c, s))) return r;
     if ((r = launch_quant<true>(qa, s))) return r;
