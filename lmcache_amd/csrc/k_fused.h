@@ -290,10 +290,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   u16* const ring = reinterpret_cast<u16*>(lds_all + wave * ENC_RING_DWORDS);  // ... and staging ring
 
   rtab_to_lds(rtab_lds);  // visible to the coder waves behind the barrier that ends phase A
-  // A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next (k_offload, k_pack_scan,
-  // the host): the chunk's FIRST item clears the word of whatever job used it before, its last item (which cannot
-  // finish before every item in front of it has published its allocation) writes the size.
-  if (it == 0 && threadIdx.x == 0) a.sizes[chunk] = 0u;
   // ---- phase A: quantise the item's planes ------------------------------------------------------------------
   {
     constexpr int TO = (Tc + 7) >> 3;  // row octs of a plane-chunk
