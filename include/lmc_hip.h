@@ -205,7 +205,7 @@ int lmc_decode_chunks(lmc_ctx* ctx, const void* blobs, uint64_t blob_stride, int
  * The same decode for a RANGE OF LAYERS of blobs that lie anywhere in device memory: the launch handles the K and V
  * planes of layers [layer_begin, layer_begin + layer_count) of every chunk.  A retrieve cut into one launch per
  * layer range (an event after each) hands layer 0's KV to the model after 1/L of the decode instead of all of it
- * -- the streams of a plane are independent and the blob's directory (gend) gives random access to them.  Stands
+ * -- the streams of a plane are independent and the blob's stream directory ({beg, end} per stream) gives random access to them.  Stands
  * where the reference decodes and concatenates the whole context before the first layer can run
  * (cache_engine.py:339-381; the connector writes layer by layer afterwards, LLM_Engine.rst:101-122).
  *   blob_ptrs       device array [nchunks] of device pointers, blob i at blob_ptrs[i] (16-byte aligned)

@@ -122,11 +122,11 @@ struct PendingTile {
   const u16* out;
 };
 
-// In-kernel compaction: where does a finished stream go?  Single-pass prefix sum over the padded lengths of
-// the chunk's P*G groups (decoupled look-back): lengths are published as soon as streams are coded, a wave
-// looks back over its predecessors' granules until it meets an inclusive prefix, publishes its own inclusive
-// prefix, and the streams move from their scratch slots to their final places (the cumsum + gather of
-// collect_bytes, cachegen_encoder.py:230-238).  Predecessors have lower stream ids: they were taken by
+// In-kernel compaction: where does a stream go?  Single-pass prefix sum over the ALLOCATIONS of the chunk's P*G
+// streams (decoupled look-back; lmc_format.h v6: a counts-model stream's allocation is a bound known before it is
+// coded, a CDF16 stream's its exact length): allocations are published as soon as they are known, a wave looks back
+// over its predecessors' granules until it meets an inclusive prefix and publishes its own inclusive prefix (the
+// cumsum + gather of collect_bytes, cachegen_encoder.py:230-238).  Predecessors have lower stream ids: they were taken by
 // workgroups dispatched no later than ours, in an earlier or the same round, and never wait on us.
 // Exclusive prefix of granule `idx` over the granule array `agg` (decoupled look-back, one wave): walks back 64
 // granules at a time until it meets an inclusive prefix; waits while a granule it needs is unpublished.
@@ -158,9 +158,7 @@ __device__ __forceinline__ u32 lookback_exclusive(unsigned long long* agg, int i
   return excl;
 }
 
-// Move a finished stream from its scratch slot to offset `excl` of the chunk's streams section, record its
-// end in the directory; the chunk's last group also writes header, bins, rowpre, pads and the size word.
-// STATIC = false: the caller writes the chunk's static sections itself (k_fused.h).
+// (The general coder launch only: the fused kernel and the counts-only launch code straight into the blob.)
 // A finished stream from its scratch slot to its place in the blob, n16 16-byte pieces by one wave.  `dst[i] = src[i]`
 // compiles to "load, wait, store" per KiB (the pointers may alias): 9 dependent memory round trips for a typical
 // 8.6 KiB stream with the wave's slot held throughout.  Holding a batch in VGPRs instead costs the whole kernel its

@@ -142,10 +142,9 @@ template <int NS>
 __device__ __forceinline__ void counts_model_of(const u32 (&pk)[8], bool active, u32 (&cnt)[NS]) {
   u32 sum = 0;
 #pragma unroll
-  for (int i = 0; i < NS; i++) {
-    cnt[i] = (pk[i >> 2] >> (8 * (i & 3))) & 0xffu;
-    sum += cnt[i];
-  }
+  for (int k = 0; k < NS / 4; k++) sum = __builtin_amdgcn_sad_u8(pk[k], 0u, sum);  // four counts per instruction
+#pragma unroll
+  for (int i = 0; i < NS; i++) cnt[i] = (pk[i >> 2] >> (8 * (i & 3))) & 0xffu;
   const u32 deficit = LMC_COUNTS_T - sum;  // 0, or 1 for a constant channel (256 for a lane without a channel)
   const bool first = cnt[0] == 255u;
   cnt[0] += first ? 0u : deficit;
@@ -246,15 +245,21 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
   wave_lds_fence();  // the counters are dead: every lane holds its counts
   head_or_counts<8>(cs.pk, cs.wor);
   cs.head = head_bytes_of<8, 8>(cs.wor, s.R);
-  // the bound: S over the lane's model counts
+  // the bound: S over the lane's MODEL counts = its stored counts, plus the count of 1 a constant channel's model
+  // gives a second symbol (stored 255 alone: the sum is a unit short)
   const u32 bits_addr = (u32)(size_t)(lds_u16p) reinterpret_cast<const u16*>(bits);
   u32 S = 0;
   auto bound = [&](auto ns_tag) {
     constexpr int NS = decltype(ns_tag)::value;
-    u32 cnt[NS];
-    counts_model_of<NS>(cs.pk, s.active, cnt);
+    u32 sum = 0;
 #pragma unroll
-    for (int i = 0; i < NS; i++) S += (u32) * (lds_u16p)(size_t)(bits_addr + 2u * cnt[i]);
+    for (int k = 0; k < NS / 4; k++) sum = __builtin_amdgcn_sad_u8(cs.pk[k], 0u, sum);
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      const u32 c = (cs.pk[i >> 2] >> (8 * (i & 3))) & 0xffu;
+      S += (u32) * (lds_u16p)(size_t)(bits_addr + 2u * c);
+    }
+    S += sum == LMC_COUNTS_T - 1u ? (u32) * (lds_u16p)(size_t)(bits_addr + 2u) : 0u;
   };
   if (s.nib) bound(IntTag<16>{});
   else bound(IntTag<32>{});

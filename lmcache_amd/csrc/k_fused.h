@@ -13,7 +13,7 @@
 //             the plane-chunk knows its final place BEFORE it is coded;
 //   pass 2    head, table, interleaved rANS (counts_open_stream, counts_code_stream) -- the symbols come back from L2,
 //             the words leave in 256-byte pieces for the blob itself.  No stream scratch, no second placement pass
-//             (v5 wrote every stream three times and read it twice: 1 GB of fabric traffic per 16 k context).
+//             (format v5 wrote every stream twice and read it once in between: 1.5 GB of fabric traffic per 16 k context).
 // Several workgroups share a CU (4.6 KiB of LDS per wave + 2.5 KiB of reciprocals and bound table, <= 64 VGPRs: 8
 // waves per SIMD) and are in different phases at any time, so the loads of one hide under the coding of the others.
 // (Round 3 held a CU's first workgroups back by rank x 50 us so that its four slots would not run their phases in

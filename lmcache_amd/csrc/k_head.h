@@ -42,13 +42,15 @@ __device__ __forceinline__ u32 bit_width_u32(u32 v) { return v ? 32u - (u32)__bu
 // field_width() reads a symbol's width.
 template <int NREG>
 __device__ __forceinline__ void head_or_counts(const u32 (&pk)[NREG], u32 (&wor)[NREG]) {
-  static_assert(NREG % 2 == 0, "pairs");
+  static_assert(NREG % 4 == 0, "four registers per reduction");
 #pragma unroll
-  for (int k = 0; k < NREG; k += 2) {
-    u32 a = pk[k], b = pk[k + 1];
-    wave_or2_u32(a, b);
+  for (int k = 0; k < NREG; k += 4) {
+    u32 a = pk[k], b = pk[k + 1], c = pk[k + 2], d = pk[k + 3];
+    wave_or4_u32(a, b, c, d);
     wor[k] = a;
     wor[k + 1] = b;
+    wor[k + 2] = c;
+    wor[k + 3] = d;
   }
 }
 template <int FB, int NREG>

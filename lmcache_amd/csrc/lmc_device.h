@@ -240,10 +240,63 @@ __device__ __forceinline__ void wave_or2_u32(u32& a, u32& b) {
   b = sb;
 }
 
+// ... for FOUR values at once, as a reduce-scatter: two half-swaps fold the four registers into one whose row r
+// (16 lanes) holds value r OR-ed over the four rows -- v_permlane32_swap_b32 x, y exchanges lanes 32..63 of x with lanes
+// 0..31 of y, so x | y afterwards is "a over the lane pair (l, l + 32)" in the lower half and "c ..." in the upper;
+// v_permlane16_swap_b32 does the same with odd and even rows -- then the four DPP steps inside the rows, and one
+// v_readlane per value.  14 VALU instructions where four separate ladders take 56.
+__device__ __forceinline__ void wave_or4_u32(u32& a, u32& b, u32& c, u32& d) {
+  u32 sa, sb, sc, sd;
+  asm("s_nop 1\n\t"
+      "v_permlane32_swap_b32 %[a], %[c]\n\t"
+      "v_permlane32_swap_b32 %[b], %[d]\n\t"
+      "s_nop 1\n\t"
+      "v_or_b32_e32 %[a], %[a], %[c]\n\t"
+      "v_or_b32_e32 %[b], %[b], %[d]\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %[a], %[b]\n\t"
+      "s_nop 1\n\t"
+      "v_or_b32_e32 %[a], %[a], %[b]\n\t"
+      "s_nop 1\n\t"
+      "v_or_b32_dpp %[a], %[a], %[a] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_or_b32_dpp %[a], %[a], %[a] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_or_b32_dpp %[a], %[a], %[a] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_or_b32_dpp %[a], %[a], %[a] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_readlane_b32 %[sa], %[a], 0\n\t"
+      "v_readlane_b32 %[sb], %[a], 16\n\t"
+      "v_readlane_b32 %[sc], %[a], 32\n\t"
+      "v_readlane_b32 %[sd], %[a], 48\n\t"
+      "s_nop 4"
+      : [a] "+v"(a), [b] "+v"(b), [c] "+v"(c), [d] "+v"(d), [sa] "=s"(sa), [sb] "=s"(sb), [sc] "=s"(sc), [sd] "=s"(sd));
+  a = sa; b = sb; c = sc; d = sd;
+}
+
+// sum over the 64 lanes on the same DPP ladder (every lane of a quad holds the quad's sum, a half-row mirror adds the
+// other quad of the half, ...; row_bcast adds the rows below into rows 1 and 3, then into 2 and 3): lane 63 holds the
+// total.  Wave-uniform result.
 __device__ __forceinline__ u32 wave_sum_u32(u32 v) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) v += (u32)__shfl_xor((int)v, off);
-  return v;
+  u32 sv;
+  asm("s_nop 1\n\t"
+      "v_add_u32_dpp %[v], %[v], %[v] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %[v], %[v], %[v] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %[v], %[v], %[v] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %[v], %[v], %[v] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %[v], %[v], %[v] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %[v], %[v], %[v] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_readlane_b32 %[sv], %[v], 63\n\t"
+      "s_nop 4"
+      : [v] "+v"(v), [sv] "=s"(sv));
+  return sv;
 }
 
 // Checksum of a plane's T scales (lmc_format.h: scsum), by one wave.
