@@ -223,25 +223,23 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
   }
   // the lane's stored counts: min(count, 255), four to a register; a lane without a channel (it saw symbol 0 only)
   // stores nothing
+  // (min and byte insert are ONE instruction: v_min_u32_sdwa writes byte i % 4 of the register and keeps the others)
 #pragma unroll
   for (int k = 0; k < 8; k++) cs.pk[k] = 0u;
-  if (s.nib) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const u32 c = tabmem[i * 64 + lane];
-      cs.pk[i >> 2] |= (c - (c >> 8)) << (8 * (i & 3));
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 32; i++) {
-      const u32 c = (u32)tab16[i * 64 + lane];
-      cs.pk[i >> 2] |= (c - (c >> 8)) << (8 * (i & 3));
-    }
-  }
-  if (!s.active) {
-#pragma unroll
-    for (int k = 0; k < 8; k++) cs.pk[k] = 0u;
-  }
+  const u32 cap = s.active ? 255u : 0u;
+  auto put = [&](auto itag, u32 c) {
+    constexpr int i = decltype(itag)::value;
+    if constexpr ((i & 3) == 0)
+      asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(cs.pk[i >> 2]) : "v"(c), "v"(cap));
+    else if constexpr ((i & 3) == 1)
+      asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(cs.pk[i >> 2]) : "v"(c), "v"(cap));
+    else if constexpr ((i & 3) == 2)
+      asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(cs.pk[i >> 2]) : "v"(c), "v"(cap));
+    else
+      asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(cs.pk[i >> 2]) : "v"(c), "v"(cap));
+  };
+  if (s.nib) static_for<16>([&](auto itag) { put(itag, tabmem[decltype(itag)::value * 64 + lane]); });
+  else static_for<32>([&](auto itag) { put(itag, (u32)tab16[decltype(itag)::value * 64 + lane]); });
   wave_lds_fence();  // the counters are dead: every lane holds its counts
   head_or_counts<8>(cs.pk, cs.wor);
   cs.head = head_bytes_of<8, 8>(cs.wor, s.R);

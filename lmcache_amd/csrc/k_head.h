@@ -83,13 +83,15 @@ __device__ __forceinline__ u32 head_write(u8* out_v, const u32 (&pk)[NREG], cons
   static_for<NSYM>([&](auto itag) {  // (a compile-time loop: pk and wor stay in registers)
     constexpr int i = decltype(itag)::value;
     const u32 w = (u32)i < R ? field_width<FB, NREG>(wor, i) : 0u;  // uniform
-    wv = writelane_const<i>((int)w, wv);
-    u32 t = ((pk[i / PER] >> (FB * (i % PER))) & ((1u << FB) - 1u)) << ((32u - w) & 31u);  // the field's top bit at bit 31
+    if (w != 0u) {  // (uniform; a symbol that does not occur in the group costs nothing: widths starts at 0)
+      wv = writelane_const<i>((int)w, wv);
+      u32 t = ((pk[i / PER] >> (FB * (i % PER))) & ((1u << FB) - 1u)) << (32u - w);  // the field's top bit at bit 31
 #pragma unroll 1
-    for (u32 b = 0; b < w; b++) {
-      plane_step(t, j & 63u, lo, hi);
-      j++;
-      if ((j & 63u) == 0u) planes[j - 64u + (u32)lane] = u32x2_t{(u32)lo, (u32)hi};
+      for (u32 b = 0; b < w; b++) {
+        plane_step(t, j & 63u, lo, hi);
+        j++;
+        if ((j & 63u) == 0u) planes[j - 64u + (u32)lane] = u32x2_t{(u32)lo, (u32)hi};
+      }
     }
   });
   if ((u32)lane < (j & 63u)) planes[(j & ~63u) + (u32)lane] = u32x2_t{(u32)lo, (u32)hi};
