@@ -298,6 +298,12 @@ int lmc_load_chunks(lmc_ctx* ctx, const void* const* host_blob_ptrs_h, const uin
  *   bytes; lmc_pack_bound is the worst case, a Llama-3-8B context needs about a quarter of it) without any host wait.
  *   sizes_h: pinned uint32 [nchunks], the blob sizes (0 = that chunk's encode failed).  Valid once `stream` has completed:
  *   the pack header's total_bytes (0 and LMC_STATUS_HOST_ARENA_FULL if the pack did not fit or a chunk failed).
+ *   WHERE pack_h points decides who pays: mapped pinned HOST memory makes the call complete by itself (no host wait at
+ *   all), but its copy kernel then posts PCIe writes from 64 workgroups for ~10 ms per 16 k context, and a bandwidth-bound
+ *   kernel running beside it (a decode step) was measured 4.3x slower for that time -- the form for an otherwise idle
+ *   GPU.  DEVICE memory (pack_h and sizes_h both device-accessible) builds the pack in HBM in ~0.3 ms; the caller reads
+ *   total_bytes from the 256-byte header and moves the pack with DMA copies, which leave concurrent kernels alone
+ *   (1.03x): what lmcache_amd's engine does (CacheGenDeviceCodec.store_pack).
  * lmc_pack_info: check a pack's header and offset table (host only), return the header.
  * lmc_pack_extract: chunk `chunk` of a pack as the blob lmc_encode_chunks wrote, byte for byte (host only: the
  *   one-chunk path of the backend, and how the tests pin a pack to the oracle).
