@@ -290,6 +290,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   u16* const ring = reinterpret_cast<u16*>(lds_all + wave * ENC_RING_DWORDS);  // ... and staging ring
 
   rtab_to_lds(rtab_lds);  // visible to the coder waves behind the barrier that ends phase A
+  // A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next (k_offload, k_pack_scan,
+  // the host).  The workgroup that will write the chunk's size clears the word of whatever job used it before -- the
+  // SAME workgroup, so that both stores pass through one XCD's L2 in program order (clearing from the chunk's first
+  // item was tried: the two workgroups may sit on different XCDs, whose L2s write back in either order, and a test
+  // caught a size of 0).  No memset dispatch in front of every job.
+  if (p0 + np == a.P && threadIdx.x == 64 * (NW - 1)) a.sizes[chunk] = 0u;
   // ---- phase A: quantise the item's planes ------------------------------------------------------------------
   {
     constexpr int TO = (Tc + 7) >> 3;  // row octs of a plane-chunk

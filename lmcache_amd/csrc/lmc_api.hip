@@ -395,12 +395,9 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   int rc = reserve_locked(w, L, H, D, chunk_tokens, nchunks, scratch_chunks, fused && C > 1024);
   if (rc) return rc;
   if (w->ws_used) HIP_TRY(hipStreamWaitEvent(s, w->ws_free, 0));
-  // A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next (k_offload, k_pack_scan,
-  // the host): no stale word of an earlier job may stand in for a size.  The two-kernel path clears its words in
-  // k_quantize; the fused kernel cannot clear its own (the clearing workgroup and the one that writes the size may sit on
-  // different XCDs, whose L2s write the two stores back in either order -- tried, and test_fused_encode_... caught a
-  // size of 0), so its words are cleared by a memset in front of it.
-  if (fused) HIP_TRY(hipMemsetAsync(sizes, 0, sizeof(uint32_t) * (size_t)nfull, s));
+  // (A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next: the kernels clear the
+  // job's words themselves -- k_quantize on the two-kernel path, in the fused kernel the workgroup that later writes the
+  // size -- so that no stale word of an earlier job stands in for a size and no memset dispatch sits in front of a job.)
 
   const int TQ = (chunk_tokens + 3) / 4;
   const u32 cap = lmc_group_cap_bytes((uint32_t)chunk_tokens);  // scratch slot stride (and capacity)
