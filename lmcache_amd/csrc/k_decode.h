@@ -166,10 +166,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
     if (counts_model) {
       // LMC_MODEL_COUNTS: freq = 2 * count, start = 2 * (symbols below), total 2^9.
       if (nsym <= 16u) {
-        // quarters of packed entries start << 23 | &lut[symbol] << 10 | freq (start is even and the LUTs lie in the
-        // first KiB of LDS: 9 + 10 + 10 bits; the token loop gets the symbol's LUT address out of the entry it
-        // found with one v_bfe instead of tracking it through the search);
-        // symbols behind the last one that occurs would start at 2^9: all ones, above every search key
+        // quarters of packed entries: start in bits 23 .. 31 (start is even), and in the 23 bits below
+        //     0x7ffffe - (3 - i % 4) << 20 - &lut[symbol] << 10 - freq
+        // (the LUTs lie in the first KiB of LDS: 2 + 10 + 10 bits).  A search key is slot << 23 | 0x7ffffe, so
+        // key - entry, for an entry that is <= key, is (slot - start) << 23 | (3 - i % 4) << 20 | &lut << 10 | freq
+        // without a borrow -- and UNSIGNED, the smallest of the four differences of a quarter belongs to the largest
+        // entry <= key (an entry above the key wraps to more than the key): the token loop takes start, freq and
+        // the LUT address out of one v_min3 / v_min, no selection among the entries.  (Entries of symbols that do
+        // not occur share their successor's start: i % 4 makes the later one the larger.)
+        // Symbols behind the last one that occurs would start at 2^9: all ones, above every search key.
         u32* tab32 = reinterpret_cast<u32*>(cdfT);
         const u32 lut0 = (u32)(size_t)(const __attribute__((address_space(3))) float*)lut;
         if (lut0 + DEC_LUT_BYTES > 1024u) __builtin_trap();  // lds_all is the kernel's only LDS object: offset 0
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
 #pragma unroll
         for (int i = 0; i < 16; i++) {
           const u32 ci = (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-          u32 ent = acc >= 256u ? 0xffffffffu : ((acc << 24) | ((lut0 + 4u * (u32)i) << 10) | (ci << 1));
+          u32 ent = acc >= 256u ? 0xffffffffu : ((acc << 24) | (0x7ffffeu - (((3u - ((u32)i & 3u)) << 20) | ((lut0 + 4u * (u32)i) << 10) | (ci << 1))));
           if (!active) ent = ((u32)i << 24) | 2u;  // idle lanes: any strictly increasing column keeps the search in range
           tab32[(i >> 2) * 256 + lane * 4 + (i & 3)] = ent;
           acc += ci;
@@ -393,27 +398,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
             : [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [full] "s"(full_exec), [lv] "v"(Lv)
             : "vcc");
       } else {
-        // the same selection without the address bookkeeping: the entry found carries its symbol's LUT address
-        // (bits 10..19) next to its freq (bits 0..9); d = slot - start = (key - entry) >> 23 (the key's low 23 bits
-        // are >= any entry's: no borrow), x = freq * (x >> 9) + d
-        u32 f;
-        asm("v_cmpx_le_u32_e32 vcc, %[e2], %[sl]\n\t"
-            "v_mov_b32_e32 %[e0], %[e2]\n\t"
-            "v_mov_b32_e32 %[e1], %[e3]\n\t"
-            "s_mov_b64 exec, %[full]\n\t"
-            "v_cmpx_le_u32_e32 vcc, %[e1], %[sl]\n\t"
-            "v_mov_b32_e32 %[e0], %[e1]\n\t"
-            "s_mov_b64 exec, %[full]\n\t"
-            "v_sub_u32_e32 %[d], %[sl], %[e0]\n\t"
-            "v_and_b32_e32 %[f], 0x3ff, %[e0]\n\t"
+        // no selection: d = the smallest of key - entry over the quarter (see the table above) = slot - start (bits
+        // 23 ..), the symbol's LUT address (bits 10 .. 19) and freq (bits 0 .. 9) of the entry found; x = freq * (x >> 9)
+        // + (slot - start)
+        u32 f, d0, d1, d2;
+        asm("v_sub_u32_e32 %[d0], %[sl], %[e0]\n\t"
+            "v_sub_u32_e32 %[d1], %[sl], %[e1]\n\t"
+            "v_sub_u32_e32 %[d2], %[sl], %[e2]\n\t"
+            "v_sub_u32_e32 %[d], %[sl], %[e3]\n\t"
+            "v_min3_u32 %[d0], %[d0], %[d1], %[d2]\n\t"
             "v_lshrrev_b32_e32 %[x], 9, %[x]\n\t"
+            "v_min_u32_e32 %[d], %[d], %[d0]\n\t"
+            "v_and_b32_e32 %[f], 0x3ff, %[d]\n\t"
+            "v_bfe_u32 %[r], %[d], 10, 10\n\t"
             "v_lshrrev_b32_e32 %[d], 23, %[d]\n\t"
-            "v_bfe_u32 %[r], %[e0], 10, 10\n\t"
             "v_mad_u32_u24 %[x], %[x], %[f], %[d]\n\t"
             "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
-            : [e0] "+v"(e0), [e1] "+v"(e1), [r] "=&v"(r), [x] "+v"(x), [d] "=&v"(d), [f] "=&v"(f), [m] "=&s"(mask)
-            : [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [full] "s"(full_exec), [lv] "v"(Lv)
-            : "vcc");
+            : [r] "=&v"(r), [x] "+v"(x), [d] "=&v"(d), [f] "=&v"(f), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [m] "=&s"(mask)
+            : [e0] "v"(e4.x), [e1] "v"(e4.y), [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [lv] "v"(Lv));
       }
       if (!SYMOUT) lv = *(lds_f32p)(size_t)r;  // issued here: back by the time the word pop below has its word
       return decode_pop(mask), r;
