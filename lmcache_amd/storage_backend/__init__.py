@@ -4,7 +4,8 @@
   remote only                -> LMCRemoteBackend (serde + connector), LMCPipelinedRemoteBackend if pipelined_backend
   local "cpu" / "cuda"       -> LMCLocalBackend  (HBM, pinned raw, or pinned CacheGen via local_serde)
   local + remote             -> LMCHybridBackend (write-through / read-through over the two above)
-  local path (disk)          -> outside the hot path (file I/O: SURVEY.md section 2 #3)
+  local path (disk)          -> LMCLocalDiskBackend (raw safetensors files as the reference writes them, or the flat
+                                CacheGen blob via local_serde)
 """
 from lmcache_amd.config import LMCacheEngineConfig, LMCacheEngineMetadata
 from lmcache_amd.logging import init_logger
@@ -24,11 +25,12 @@ def CreateStorageBackend(config: LMCacheEngineConfig, metadata: LMCacheEngineMet
         if local in ("cpu", "cuda"):
             from lmcache_amd.storage_backend.local_backend import LMCLocalBackend
             return LMCLocalBackend(config, metadata)
-        raise ValueError(f"local disk backend ({local!r}) is file I/O outside lmcache_amd's scope; "
-                         f"use the reference's LMCLocalDiskBackend")
+        from lmcache_amd.storage_backend.local_backend import LMCLocalDiskBackend
+        logger.info(f"Initializing local-only (disk) backend at {local}")
+        return LMCLocalDiskBackend(config, metadata)
     if local is not None and remote is not None:
-        if local not in ("cpu", "cuda"):
-            raise ValueError(f"local disk tier ({local!r}) is file I/O outside lmcache_amd's scope")
+        if local not in ("cpu", "cuda"):  # the reference's hybrid backend only ever builds an LMCLocalBackend (hybrid_backend.py:29)
+            raise ValueError(f"hybrid backend: the local tier is 'cpu' or 'cuda', not a path ({local!r})")
         from lmcache_amd.storage_backend.hybrid_backend import LMCHybridBackend
         return LMCHybridBackend(config, metadata)
     raise ValueError(f"Invalid configuration: {config}")

@@ -252,6 +252,35 @@ def _sig(fn):
     return out
 
 
+def gen_disk():
+    """A chunk file written by the reference's LMCLocalDiskBackend (local_backend.py:163-310): the file name it gives
+    the key and the safetensors payload.  lmcache_amd's disk tier in its raw mode reads this file and writes the same."""
+    import shutil
+    import tempfile
+    from lmcache.config import LMCacheEngineConfig
+    from lmcache.storage_backend.local_backend import LMCLocalDiskBackend
+    from lmcache.utils import CacheEngineKey
+
+    d = tempfile.mkdtemp() + "/"
+    torch.cuda.Stream = lambda *a, **k: None  # the put worker makes one at start (local_backend.py:234); no GPU here
+    be = LMCLocalDiskBackend(LMCacheEngineConfig.from_legacy(chunk_size=16, backend="file://" + d))
+    g = torch.Generator().manual_seed(5)
+    t = torch.rand([3, 2, 16, 2, 8], generator=g).to(torch.bfloat16)
+    key = CacheEngineKey("vllm", "test_model", 1, 0, "ab" * 32)
+    be.put(key, t, blocking=True)
+    be.close()
+    names = os.listdir(d)
+    assert len(names) == 1
+    os.makedirs(os.path.join(OUT, "disk"), exist_ok=True)
+    shutil.copy(os.path.join(d, names[0]), os.path.join(OUT, "disk", names[0]))
+    os.chmod(os.path.join(OUT, "disk", names[0]), 0o644)
+    with open(os.path.join(OUT, "disk", "disk.json"), "w") as f:
+        json.dump({"file": names[0], "key": key.to_string(), "shape": list(t.shape), "seed": 5,
+                   "bits": bits(t).reshape(-1).tolist()}, f)
+    shutil.rmtree(d)
+    print("disk", names[0], os.path.getsize(os.path.join(OUT, "disk", names[0])), "bytes")
+
+
 def gen_api():
     """The reference's plugin surface for the hot path as data: the signatures a drop-in must
     offer name for name, default for default.  tests/test_dropin_api.py holds lmcache_amd against it (on the GPU box,
@@ -267,6 +296,7 @@ def gen_api():
     for mod, name in (("lmcache.cache_engine", "LMCacheEngine"), ("lmcache.cache_engine", "LMCacheEngineBuilder"),
                       ("lmcache.storage_backend.abstract_backend", "LMCBackendInterface"),
                       ("lmcache.storage_backend.local_backend", "LMCLocalBackend"),
+                      ("lmcache.storage_backend.local_backend", "LMCLocalDiskBackend"),
                       ("lmcache.storage_backend.remote_backend", "LMCRemoteBackend"),
                       ("lmcache.storage_backend.remote_backend", "LMCPipelinedRemoteBackend"),
                       ("lmcache.storage_backend.hybrid_backend", "LMCHybridBackend"),
@@ -313,4 +343,5 @@ if __name__ == "__main__":
     gen_cdf()
     gen_layout()
     gen_engine()
+    gen_disk()
     gen_api()

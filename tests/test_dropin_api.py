@@ -24,6 +24,7 @@ ADDITIONS = {
     "lmcache.config.LMCacheEngineConfig.from_legacy": ["local_serde"],
     # the local tier can hold ENCODED chunks (local_serde: cachegen), for which it needs the model's bins and format
     "lmcache.storage_backend.local_backend.LMCLocalBackend.__init__": ["metadata"],
+    "lmcache.storage_backend.local_backend.LMCLocalDiskBackend.__init__": ["metadata"],
 }
 
 # public-looking names of the reference that are private machinery of ITS implementation, with what stands in their

@@ -10,7 +10,7 @@ not copied: the flows are re-written here, the assertions are theirs):
                                      decoder (shape, non-zero mean), a chunk shorter than chunk_size
   tests/test_cache_engine.py:88-297  retrieve on the destination device, store -> retrieve equality, prefix retrieve,
                                      mixed retrieve, skip_existing, the builder
-for the backends in scope (SURVEY.md section 8: "cuda", "cpu"; disk / redis / lm:// stay with the reference)."""
+for the backends in scope (SURVEY.md section 8: "cuda", "cpu", a disk path; redis / lm:// stay with the reference)."""
 import importlib
 import pkgutil
 import sys

@@ -866,3 +866,61 @@ def test_baseline_config3_rank_shape_full_size(oracle):
             assert torch.equal(have, want)
     finally:
         engine.close()
+
+
+@pytest.mark.parametrize("fmt", ["vllm", "huggingface"])
+def test_disk_tier_stores_the_flat_blob_and_decodes_from_the_file(fmt, tmp_path, oracle):
+    """LMCLocalDiskBackend with local_serde="cachegen": the file of a chunk is the v6 blob the serializer would return
+    (bit-exact vs the oracle elsewhere), a retrieve through the engine is the oracle's decode(encode(x)), a damaged file
+    is a miss."""
+    import os
+    from lmcache_amd.storage_backend.local_backend import LMCLocalDiskBackend
+    d = str(tmp_path) + "/"
+    cfg = LMCacheEngineConfig.from_legacy(chunk_size=256, backend="file://" + d)
+    cfg.local_serde = "cachegen"
+    meta = dumb_metadata(fmt, MODEL)
+    engine = LMCacheEngine(cfg, meta)
+    assert isinstance(engine.engine_, LMCLocalDiskBackend)
+    torch.manual_seed(3)
+    ntok = 600  # two full chunks and a short one
+    tokens = generate_tokens(ntok, "cuda")
+    kv = generate_kv_cache(ntok, fmt, "cuda", num_layers=4)
+    try:
+        engine.store(tokens, kv)
+        files = sorted(os.listdir(d))
+        assert len(files) == 3 and all(n.endswith(".lmc") for n in files)
+        # the file of the first chunk == CacheGenSerializer.to_bytes of that chunk
+        tdim = 0 if fmt == "vllm" else 1
+        first = to_blob(tuple((k.narrow(tdim, 0, 256), v.narrow(tdim, 0, 256)) for k, v in kv))
+        want = CacheGenSerializer(cfg, meta).to_bytes(first)
+        sizes = {len(open(d + n, "rb").read()) for n in files}
+        assert len(want) in sizes
+        assert any(open(d + n, "rb").read() == want for n in files)
+        ret, mask = engine.retrieve(tokens)
+        assert mask.all() and len(ret) == 4
+        out_dtype = torch.bfloat16 if fmt == "vllm" else torch.float16
+        for c0 in range(0, ntok, 256):
+            n = min(256, ntok - c0)
+            piece = tuple((k.narrow(tdim, c0, n), v.narrow(tdim, c0, n)) for k, v in kv)
+            dec = oracle_roundtrip(oracle, piece, fmt, MODEL, out_dtype)
+            for layer in range(4):
+                for j in range(2):
+                    got = ret[layer][j].narrow(tdim, c0, n).cpu()
+                    assert got.dtype == out_dtype
+                    assert torch.equal(got.view(torch.int16), dec[layer, j].contiguous().view(torch.int16))
+        # a damaged file: the decode flags it, the chunk is a miss (never garbage, never an exception)
+        victim = d + files[0]
+        raw = bytearray(open(victim, "rb").read())
+        raw[len(raw) // 2] ^= 0x5a
+        raw[200] ^= 0xff
+        open(victim, "wb").write(bytes(raw))
+        ret2, mask2 = engine.retrieve(tokens)
+        assert not mask2.all()
+        # queued puts
+        tokens2 = generate_tokens(300, "cuda")
+        engine.store(tokens2, generate_kv_cache(300, fmt, "cuda", num_layers=4), blocking=False)
+        engine.engine_.close()
+        _, mask3 = engine.retrieve(tokens2)
+        assert mask3.all()
+    finally:
+        engine.close()

@@ -372,3 +372,47 @@ def test_pack_cap_covers_the_least_compressible_input():
         assert len(pack) <= cap, (T, len(pack), cap)
         if T % cs == 0:  # (a ragged last chunk is sized like a full one)
             assert cap < 1.35 * len(pack), "the bound should stay close to the least compressible case"
+
+
+def test_disk_backend_reads_and_writes_the_reference_files(golden_dir, tmp_path):
+    """LMCLocalDiskBackend, raw mode (lmcache/storage_backend/local_backend.py:163-310): the file a chunk is stored in
+    -- name and safetensors payload -- is the reference's.  tests/golden/disk holds a file the reference itself wrote
+    (oracle/gen_golden.py: gen_disk)."""
+    import shutil
+    from safetensors import safe_open
+    from lmcache_amd.storage_backend import CreateStorageBackend
+    from lmcache_amd.storage_backend.local_backend import LMCLocalDiskBackend
+    rec = json.load(open(os.path.join(golden_dir, "disk", "disk.json")))
+    want = torch.from_numpy(np.array(rec["bits"], np.uint16).view(np.int16)).view(torch.bfloat16).reshape(rec["shape"])
+    d = str(tmp_path) + "/"
+    cfg = LMCacheEngineConfig.from_legacy(chunk_size=16, backend="file://" + d)
+    be = CreateStorageBackend(cfg, LMCacheEngineMetadata("test_model", 1, 0, "vllm", "half"))
+    assert isinstance(be, LMCLocalDiskBackend)
+    be.dst_device = "cpu"  # "cuda" is hard-coded, as in the reference (:203)
+    key = CacheEngineKey.from_string(rec["key"])
+    try:
+        assert not be.contains(key) and be.get(key) is None  # a miss is None, never an exception
+        # our file == the reference's file, byte for byte
+        be.put(key, want, blocking=True)
+        assert be.contains(key)
+        assert os.listdir(d) == [rec["file"]]
+        assert open(d + rec["file"], "rb").read() == open(os.path.join(golden_dir, "disk", rec["file"]), "rb").read()
+        assert torch.equal(be.get(key), want)
+        # the reference's file is read
+        shutil.copy(os.path.join(golden_dir, "disk", rec["file"]), d + rec["file"])
+        got = be.get(key)
+        assert got.dtype == torch.bfloat16 and torch.equal(got, want)
+        # the queued put (:254-275): visible once the worker has written the file
+        key2 = CacheEngineKey("vllm", "test_model", 1, 0, "cd" * 32)
+        be.put(key2, want * 2, blocking=False)
+        be.close()
+        assert be.contains(key2) and torch.equal(be.get(key2), want * 2)
+        with safe_open(be._key_to_path(key2), framework="pt", device="cpu") as f:
+            assert list(f.keys()) == ["kv_chunk"]
+        assert not [n for n in os.listdir(d) if n.endswith(".tmp")]
+    finally:
+        be.close()
+    # the reference's hybrid backend has no disk tier (hybrid_backend.py:29)
+    with pytest.raises(ValueError):
+        CreateStorageBackend(LMCacheEngineConfig(16, d, "mem://x:1", "torch", False, False),
+                             LMCacheEngineMetadata("test_model", 1, 0, "vllm", "half"))
