@@ -370,9 +370,10 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   // 64 planes of 1024 channels, 4 / 8 / 12 / 16 / 32 / 64 chunks: fused / two-kernel time = 1.27 / 1.16 / 1.05 / 1.00 /
   // 0.91 / 0.90 (tools/probes/encode_ab.hip)
   // Planes of more than 1024 channels (one item = 2 MB of raw KV, 64 streams): at one generation of workgroups nothing
-  // overlaps and the fused kernel loses (C = 4096, 16 chunks: 1.54 vs 1.25-1.31 ms), at four generations it is 2-5 %
-  // ahead (64 chunks: 4.42-4.53 vs 4.62-4.66 ms) -- AUTO takes it from four generations on.
-  const long long auto_min = (C > 1024 ? 16ll : 4ll) * c->num_cus;
+  // overlaps and the fused kernel loses (C = 4096, 16 chunks: 1.43-1.55 vs 1.12-1.14 ms), at four generations the two
+  // are level (C = 2048 / 4096, 16 k tokens: 2.198 vs 2.204 / 4.41-4.60 vs 4.34-4.41 ms), at eight it is ahead (C = 2048,
+  // 32 k tokens: 3.94 vs 4.32 ms; tools/probes/wide_plane_paths.py) -- AUTO takes it from eight generations on.
+  const long long auto_min = (C > 1024 ? 32ll : 4ll) * c->num_cus;
   const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
                                     (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * ipc >= auto_min));
   // chunks that go through the general coder launch (scratch slots): every chunk of a job whose chunks are not 256 tokens

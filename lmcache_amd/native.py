@@ -481,7 +481,7 @@ class Context:
 
     def set_encode_path(self, path: str) -> None:
         """Which kernels encode_chunks launches: "auto" (default), "two_kernels" (k_quantize + k_cdf_encode) or
-        "fused" (k_encode_fused; 256 < C <= 1024 only).  Blobs are byte-identical either way (include/lmc_hip.h)."""
+        "fused" (k_encode_fused: whole 256-token chunks of any plane width).  Blobs are byte-identical either way (include/lmc_hip.h)."""
         check(lib().lmc_ctx_set_encode_path(self.handle, ENCODE_PATHS[path]), "lmc_ctx_set_encode_path")
 
     def profile(self, enable: bool) -> None:
