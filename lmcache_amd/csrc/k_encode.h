@@ -343,7 +343,8 @@ __device__ __forceinline__ void encode_group_stream(const EncodeArgs& a, long lo
 #pragma unroll
     for (int i = 0; i < 16; i++) pk[i] = active ? hreg[i] : 0u;
     head_or_counts<16>(pk, wor);
-    head = head_write<16, 16>(reinterpret_cast<u8*>(out), pk, wor, (u32)a.bins.b[p] - 1u, lane);
+    head = head_write<16, 16>(reinterpret_cast<u8*>(out), pk, wor, (u32)a.bins.b[p] - 1u, reinterpret_cast<u32*>(tab), lane);
+    wave_lds_fence();  // the words parked in `tab` are dead
     out += head >> 1;
   }
 

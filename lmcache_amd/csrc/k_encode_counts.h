@@ -269,7 +269,7 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
 // The stream opens: its head to `out` (16-byte aligned: the stream's place in the blob, or a scratch slot), the coder's
 // table to the wave's slice (whose previous contents are dead).  The words go to out + cs.head.
 __device__ __forceinline__ void counts_open_stream(const CountsStream& s, const CountsState& cs, u8* out, u32* tabmem, int lane) {
-  (void)head_write<8, 8>(out, cs.pk, cs.wor, s.R, lane);
+  (void)head_write<8, 8>(out, cs.pk, cs.wor, s.R, tabmem, lane);  // (the slice is idle: the table comes next)
   wave_lds_fence();
   if (s.nib) {
     u32 cnt[16];

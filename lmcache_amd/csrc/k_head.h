@@ -9,6 +9,7 @@
 // on scalar trip counts.
 #pragma once
 #include "lmc_device.h"
+#include "k_bits.h"
 
 // v_writelane_b32: lane `sel` of `old` <- the wave-uniform `val`.  Data and lane select are both scalar operands and
 // gfx9 reads one SGPR per VALU instruction, so a select that is not a constant travels in M0 (saved and restored: the
@@ -70,34 +71,59 @@ __device__ __forceinline__ u32 head_bytes_of(const u32 (&wor)[NREG], u32 R) {
 }
 
 // Write the head to `out` (16-byte aligned, wave-uniform); returns its size.  pk: this lane's stored counts (0 for a
-// lane without a channel), wor: their OR over the lanes (head_or_counts).
+// lane without a channel), wor: their OR over the lanes (head_or_counts).  `stage`: 512 bytes of this wave's LDS per 64
+// planes (8 * W bytes; the wave's idle table slice).
+// A lane strings its counts together, most significant bit first, 64 bits at a time -- a ROW of the 64 x 64 bit matrix
+// whose COLUMNS are the planes -- and parks each finished word in its own LDS slot (a compile-time loop over the
+// symbols: pk and wor stay in registers; two or three instructions per symbol); then, per 64 planes, one transpose64
+// (k_bits.h) turns rows into planes and one coalesced 8-byte store per lane writes them.  (A ballot and two
+// v_writelane per plane, the first form of this function, cost three instructions per PLANE.)
 template <int FB, int NREG>
-__device__ __forceinline__ u32 head_write(u8* out_v, const u32 (&pk)[NREG], const u32 (&wor)[NREG], u32 R, int lane) {
+__device__ __forceinline__ u32 head_write(u8* out_v, const u32 (&pk)[NREG], const u32 (&wor)[NREG], u32 R, u32* stage, int lane) {
   constexpr int PER = 32 / FB, NSYM = NREG * PER;
+  typedef __attribute__((address_space(3))) u32x2_t* lds_u64w;
   u8* const out = reinterpret_cast<u8*>(uniform_ptr64(out_v));
   const u32 R8 = (R + 7u) & ~7u;
   LMC_GLOBAL u32x2_t* const planes = (LMC_GLOBAL u32x2_t*)(out + R8);
-  int wv = 0;          // lane i: widths[i]
-  int lo = 0, hi = 0;  // lane l: plane jbase + l
-  u32 j = 0;           // planes made so far (wave-uniform)
-  static_for<NSYM>([&](auto itag) {  // (a compile-time loop: pk and wor stay in registers)
+  const lds_u64w slot = (lds_u64w)reinterpret_cast<u32x2_t*>(stage) + lane;  // word b of this lane: slot[64 b]
+  int wv = 0;    // lane i: widths[i]
+  u64 acc = 0;   // the lane's row of the current block: nb bits, right-aligned
+  u32 nb = 0;    // (wave-uniform, like every width)
+  u32 nblk = 0;  // finished words
+  static_for<NSYM>([&](auto itag) {
     constexpr int i = decltype(itag)::value;
     const u32 w = (u32)i < R ? field_width<FB, NREG>(wor, i) : 0u;  // uniform
     if (w != 0u) {  // (uniform; a symbol that does not occur in the group costs nothing: widths starts at 0)
       wv = writelane_const<i>((int)w, wv);
-      u32 t = ((pk[i / PER] >> (FB * (i % PER))) & ((1u << FB) - 1u)) << (32u - w);  // the field's top bit at bit 31
-#pragma unroll 1
-      for (u32 b = 0; b < w; b++) {
-        plane_step(t, j & 63u, lo, hi);
-        j++;
-        if ((j & 63u) == 0u) planes[j - 64u + (u32)lane] = u32x2_t{(u32)lo, (u32)hi};
+      const u32 c = (pk[i / PER] >> (FB * (i % PER))) & ((1u << FB) - 1u);  // < 2^w
+      if (nb + w < 64u) {
+        acc = (acc << w) | c;
+        nb += w;
+      } else {  // the word is complete with the top 64 - nb bits of the field
+        const u32 t = 64u - nb, rest = w - t;
+        const u64 full = (acc << t) | (u64)(c >> rest);
+        slot[64u * nblk] = u32x2_t{(u32)full, (u32)(full >> 32)};
+        nblk++;
+        acc = (u64)(c & ((1u << rest) - 1u));
+        nb = rest;
       }
     }
   });
-  if ((u32)lane < (j & 63u)) planes[(j & ~63u) + (u32)lane] = u32x2_t{(u32)lo, (u32)hi};
+  const u32 W = 64u * nblk + nb;
+  if (nb != 0u) {  // the last, partial word, left-aligned: plane p of the block is bit 63 - p whatever the fill
+    const u64 full = acc << (64u - nb);
+    slot[64u * nblk] = u32x2_t{(u32)full, (u32)(full >> 32)};
+  }
+  for (u32 b = 0; 64u * b < W; b++) {
+    const u32x2_t v = slot[64u * b];
+    u32 lo = v.x, hi = v.y;
+    transpose64(lo, hi, lane);  // lane k: column k = plane 63 - k of the block
+    const u32 p = 64u * b + 63u - (u32)lane;
+    if (p < W) planes[p] = u32x2_t{lo, hi};
+  }
   if ((u32)lane < R8) ((LMC_GLOBAL u8*)out)[lane] = (u8)wv;  // widths[R .. R8) = 0: wv starts at 0
-  const u32 raw = R8 + 8u * j;
-  if ((raw & 8u) && lane == 0) planes[j] = u32x2_t{0u, 0u};  // zeros to 16 bytes
+  const u32 raw = R8 + 8u * W;
+  if ((raw & 8u) && lane == 0) planes[W] = u32x2_t{0u, 0u};  // zeros to 16 bytes
   return (raw + 15u) & ~15u;
 }
 
