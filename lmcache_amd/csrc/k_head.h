@@ -4,37 +4,20 @@
 //
 //   widths u8[R8] | planes u64[W] | zeros to 16 B        R8 = R rounded up to 8, W = sum of the widths
 //
-// A plane is one bit of one symbol's stored count across the 64 lanes -- what a wave64 produces with one ballot and
-// takes apart again by testing bit `lane`; widths[i] is wave-uniform (an OR over the lanes), so every loop below runs
-// on scalar trip counts.
+// A plane is one bit of one symbol's stored count across the 64 lanes: a COLUMN of the 64 x 64 bit matrix whose rows
+// are the lanes' counts strung together -- 64 planes at a time are made from, and turned back into, the lanes' rows by
+// one transpose64 (k_bits.h); widths[i] is wave-uniform (an OR over the lanes), so every loop below runs on scalar
+// trip counts and every field sits at a wave-uniform bit position.
 #pragma once
 #include "lmc_device.h"
 #include "k_bits.h"
 
-// v_writelane_b32: lane `sel` of `old` <- the wave-uniform `val`.  Data and lane select are both scalar operands and
-// gfx9 reads one SGPR per VALU instruction, so a select that is not a constant travels in M0 (saved and restored: the
-// compiler keeps its own values there, e.g. the LDS base of global_load_lds).
+// v_writelane_b32: lane SEL of `old` <- the wave-uniform `val`.
 template <int SEL>
 __device__ __forceinline__ int writelane_const(int val, int old) {
   asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(__builtin_amdgcn_readfirstlane(val)), "n"(SEL));
   return old;
 }
-// One bit plane: vcc = the top bits of t over the lanes (the carry of t + t, which also moves the next bit up), and
-// lane `sel` of {lo, hi} <- vcc.
-__device__ __forceinline__ void plane_step(u32& t, u32 sel, int& lo, int& hi) {
-  u32 keep;
-  asm volatile("s_mov_b32 %[k], m0\n\t"
-               "s_mov_b32 m0, %[sel]\n\t"
-               "v_add_co_u32_e32 %[t], vcc, %[t], %[t]\n\t"
-               "s_nop 0\n\t"
-               "v_writelane_b32 %[lo], vcc_lo, m0\n\t"
-               "v_writelane_b32 %[hi], vcc_hi, m0\n\t"
-               "s_mov_b32 m0, %[k]"
-               : [t] "+v"(t), [lo] "+v"(lo), [hi] "+v"(hi), [k] "=&s"(keep)
-               : [sel] "s"(__builtin_amdgcn_readfirstlane((int)sel))
-               : "vcc");
-}
-
 // Significant bits of the wave-uniform value v (0 for 0).
 __device__ __forceinline__ u32 bit_width_u32(u32 v) { return v ? 32u - (u32)__builtin_clz(v) : 0u; }
 
@@ -128,11 +111,15 @@ __device__ __forceinline__ u32 head_write(u8* out_v, const u32 (&pk)[NREG], cons
 }
 
 // Read a head back: `head` (wave-uniform, 16-byte aligned) -> this lane's stored counts cv[0 .. NSYM), NSYM = 32 or 16
-// (symbols >= R read 0).  `stage` = at least 2 KiB of this wave's LDS (the planes pass through it); `limit` = bytes the
-// head may take.  Returns the head's size, 0 if it is malformed (a width above 16, a head longer than `limit`).
+// (symbols >= R read 0).  `stage` = 512 bytes of this wave's LDS per 64 planes (at most 16 * NSYM planes: 4 KiB for
+// NSYM = 32); `limit` = bytes the head may take.  Returns the head's size, 0 if it is malformed (a width above 16, a
+// head longer than `limit`).
+// head_write backwards: per 64 planes, lane k loads plane 63 - k of the block (one coalesced 8-byte load), transpose64
+// turns the planes into the lanes' rows, each lane parks its row in its own LDS slot; then a compile-time loop over
+// the symbols cuts the counts out of the rows at wave-uniform bit positions (a 64-bit shift and a mask per symbol).
 template <int NSYM>
 __device__ __forceinline__ u32 head_read(const u8* head_v, u32 limit, u32 R, u32* stage, u32 (&cv)[NSYM], int lane) {
-  typedef __attribute__((address_space(3))) u32* lds_u32w;
+  typedef __attribute__((address_space(3))) u32x2_t* lds_u64w;
   const u8* const head = reinterpret_cast<const u8*>(uniform_ptr64(head_v));
   const u32 R8 = (R + 7u) & ~7u;
   const u32 wv = ((u32)lane < R8 && R8 <= limit) ? (u32)((const LMC_GLOBAL u8*)head)[lane] : 0u;
@@ -151,28 +138,40 @@ __device__ __forceinline__ u32 head_read(const u8* head_v, u32 limit, u32 R, u32
     for (int i = 0; i < NSYM; i++) cv[i] = 0u;
     return 0u;
   }
-  // planes -> LDS (one coalesced 8-byte load per lane and batch of 64), then every lane picks its bit of plane j from
-  // dword 2 j + lane / 32
   const LMC_GLOBAL u32x2_t* const planes = (const LMC_GLOBAL u32x2_t*)(head + R8);
+  const lds_u64w slot = (lds_u64w)reinterpret_cast<u32x2_t*>(stage) + lane;  // row b of this lane: slot[64 b]
   wave_lds_fence();
-  for (u32 j0 = 0; j0 < W; j0 += 64u) {
-    if (j0 + (u32)lane < W) {
-      const u32x2_t v = planes[j0 + (u32)lane];
-      stage[2u * (j0 + (u32)lane)] = v.x;
-      stage[2u * (j0 + (u32)lane) + 1u] = v.y;
-    }
+  for (u32 b = 0; 64u * b < W; b++) {
+    const u32 p = 64u * b + 63u - (u32)lane;
+    u32x2_t v = {0u, 0u};
+    if (p < W) v = planes[p];
+    u32 lo = v.x, hi = v.y;
+    transpose64(lo, hi, lane);  // lane l: its bits of planes 64 b .. 64 b + 63, the first plane on top
+    slot[64u * b] = u32x2_t{lo, hi};
   }
-  wave_lds_fence();
-  const u32 my = (u32)(size_t)(lds_u32w)stage + 4u * ((u32)lane >> 5);
-  const u32 sh = (u32)lane & 31u;
-  u32 j = 0;
+  u64 cur = 0;   // the row being cut up
+  u32 pos = 64;  // bits of it already used (wave-uniform)
+  u32 blk = 0;   // rows fetched
+  auto next_row = [&]() {
+    const u32x2_t v = slot[64u * blk];
+    blk++;
+    return ((u64)v.y << 32) | (u64)v.x;
+  };
   static_for<NSYM>([&](auto itag) {
     constexpr int i = decltype(itag)::value;
+    const u32 wi = w[i];
     u32 c = 0;
-#pragma unroll 1
-    for (u32 b = 0; b < w[i]; b++, j++) {
-      const u32 dw = *(lds_u32w)(size_t)(my + 8u * j);
-      c = (c << 1) | ((dw >> sh) & 1u);
+    if (wi != 0u) {  // (uniform)
+      if (pos + wi <= 64u) {
+        c = (u32)(cur >> (64u - pos - wi)) & ((1u << wi) - 1u);
+        pos += wi;
+      } else {  // the field runs over into the next row (or starts one)
+        const u32 t = 64u - pos, rest = wi - t;  // t < 16 bits left here
+        const u32 top = (u32)cur & ((1u << t) - 1u);
+        cur = next_row();
+        c = (top << rest) | (u32)(cur >> (64u - rest));
+        pos = rest;
+      }
     }
     cv[i] = c;
   });
