@@ -143,9 +143,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
 #pragma unroll
     for (int i = 0; i < 16; i++) hreg[i] = cv[2 * i] | (cv[2 * i + 1] << 16);
     if (bytes1) {  // the counts of a channel sum to T
-      u32 sum = 0;
+      u32 both = 0;  // the two halves add up side by side: no count is above 255 here, so neither sum passes 16 bits
 #pragma unroll
-      for (int i = 0; i < 16; i++) sum += (hreg[i] & 0xffffu) + (hreg[i] >> 16);
+      for (int i = 0; i < 16; i++) both += hreg[i];
+      const u32 sum = (both & 0xffffu) + (both >> 16);
       const u32 deficit = active ? T - sum : 0u;  // 0 or 1 in a well-formed blob
       if (__ballot(deficit != 0u)) {
         if (counts_model) {
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   }
   // ---- dequantisation LUT; the per-token scales are fetched 64 tokens at a time inside the loop ----
   const u16* scl = reinterpret_cast<const u16*>(blob + bo.scales) + (long long)p * T;
-  if (!SYMOUT) {  // the scales are the one section whose damage the coder cannot see: check their checksum
+  if (!SYMOUT && g == 0) {  // the scales are the one section whose damage the coder cannot see: the plane's first wave
+                            // checks their checksum (every launch decodes all the groups of the planes it takes)
     const u32 want = (u32)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const u32*>(blob + bo.scsum)[p]);
     if (scale_checksum(scl, T, lane) != want) {
       if (lane == 0) atomicOr(a.status, LMC_ST_BAD_SCALES);
