@@ -176,6 +176,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
         // the LUT address out of one v_min3 / v_min, no selection among the entries.  (Entries of symbols that do
         // not occur share their successor's start: i % 4 makes the later one the larger.)
         // Symbols behind the last one that occurs would start at 2^9: all ones, above every search key.
+        // (A lane without a channel stored zeros: all its entries start at 0, whichever the search finds has freq 0 and
+        // a LUT address of this wave, its state stays 0 and never renormalises -- no special column for it.)
         u32* tab32 = reinterpret_cast<u32*>(cdfT);
         const u32 lut0 = (u32)(size_t)(const __attribute__((address_space(3))) float*)lut;
         if (lut0 + DEC_LUT_BYTES > 1024u) __builtin_trap();  // lds_all is the kernel's only LDS object: offset 0
@@ -184,7 +186,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
         for (int i = 0; i < 16; i++) {
           const u32 ci = (hreg[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
           u32 ent = acc >= 256u ? 0xffffffffu : ((acc << 24) | (0x7ffffeu - (((3u - ((u32)i & 3u)) << 20) | ((lut0 + 4u * (u32)i) << 10) | (ci << 1))));
-          if (!active) ent = ((u32)i << 24) | 2u;  // idle lanes: any strictly increasing column keeps the search in range
           tab32[(i >> 2) * 256 + lane * 4 + (i & 3)] = ent;
           acc += ci;
         }
