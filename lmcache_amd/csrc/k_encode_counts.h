@@ -252,12 +252,15 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
     u32 sum = 0;
 #pragma unroll
     for (int k = 0; k < NS / 4; k++) sum = __builtin_amdgcn_sad_u8(cs.pk[k], 0u, sum);
+    // (read unconditionally: a load under a condition becomes a branch, and every 16-bit value that crosses it costs
+    // a v_and)
+    const u32 bits_of_1 = (u32) * (lds_u16p)(size_t)(bits_addr + 2u);
 #pragma unroll
     for (int i = 0; i < NS; i++) {
       const u32 c = (cs.pk[i >> 2] >> (8 * (i & 3))) & 0xffu;
       S += (u32) * (lds_u16p)(size_t)(bits_addr + 2u * c);
     }
-    S += sum == LMC_COUNTS_T - 1u ? (u32) * (lds_u16p)(size_t)(bits_addr + 2u) : 0u;
+    S += sum == LMC_COUNTS_T - 1u ? bits_of_1 : 0u;
   };
   if (s.nib) bound(IntTag<16>{});
   else bound(IntTag<32>{});
@@ -328,7 +331,7 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
         : [x] "+v"(x), [q] "=&v"(q)
         : [m] "v"(m), [shc] "v"(shc), [e] "v"(e));
   };
-  auto rans_put_byte = [&](u32 e, u32 m, u32 shc) {
+  auto rans_put_byte = [&](_Float16 e, u32 m, u32 shc) {
     u32 q, st2;
     asm("v_mul_hi_u32 %[q], %[x], %[m]\n\t"
         "v_lshrrev_b32_sdwa %[q], %[shc], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
@@ -344,11 +347,18 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
     constexpr int DPB = NIB ? 4 : 8;
     constexpr int NB = Tc / 32;
     const u32 col = NIB ? tab_addr + 4u * (u32)lane : tab_addr + 2u * (u32)lane;  // LDS address of tab[0][lane]
-    auto entry_at = [&](u32 ad) -> u32 {
-      return NIB ? *(lds_u32w)(size_t)ad : (u32) * (lds_u16w)(size_t)ad;
+    // A byte plane's 16-bit entries travel as _Float16: the blocks below only ever take them apart by SDWA byte
+    // selects, so the register's upper half does not matter -- but an integer of 16 bits that lives across the
+    // step's branches is zero-extended where it is used (one v_and per step); a half is passed as it is.
+    using ET = std::conditional_t<NIB, u32, _Float16>;
+    auto entry_at = [&](u32 ad) -> ET {
+      if constexpr (NIB) return *(lds_u32w)(size_t)ad;
+      else return __builtin_bit_cast(_Float16, *(lds_u16w)(size_t)ad);
     };
-    auto rtab_of = [&](u32 e) -> u32x2_t {  // the reciprocal of the entry's frequency
-      const u32 ra = NIB ? (e >> 20) : ((e & 0xffu) << 3);
+    auto rtab_of = [&](ET e) -> u32x2_t {  // the reciprocal of the entry's frequency
+      u32 ra;
+      if constexpr (NIB) ra = e >> 20;
+      else ra = ((u32)__builtin_bit_cast(u16, e) & 0xffu) << 3;
       return *(const __attribute__((address_space(3))) u32x2_t*)(size_t)(rtab_addr + ra);
     };
     u32 w[DPB], wn[DPB];
@@ -360,10 +370,10 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
     // reciprocal and appends the step's words -- under exec = emitting lanes: v_cmpx on the state's upper half against
     // the entry's (count << 7), mbcnt rank, ds_write_b16 into the ring, x >>= 16, exec restored -- and the loads are
     // plain loads the compiler tracks, issued right behind the block (behind the ring store in the LDS queue).
-    u32 E0 = entry_at(row_addr_cnt<NIB, 31>(w, col));
-    u32 E1 = entry_at(row_addr_cnt<NIB, 30>(w, col));
-    u32 E2 = entry_at(row_addr_cnt<NIB, 29>(w, col));
-    u32 E3 = entry_at(row_addr_cnt<NIB, 28>(w, col));
+    ET E0 = entry_at(row_addr_cnt<NIB, 31>(w, col));
+    ET E1 = entry_at(row_addr_cnt<NIB, 30>(w, col));
+    ET E2 = entry_at(row_addr_cnt<NIB, 29>(w, col));
+    ET E3 = entry_at(row_addr_cnt<NIB, 28>(w, col));
     u32x2_t R0 = rtab_of(E0);
     u32x2_t R1 = rtab_of(E1);
     for (int b = NB - 1; b >= 0; b--) {
@@ -407,7 +417,7 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
                        : "vcc", "scc", "memory");
         }
         const u32x2_t R2 = *(const __attribute__((address_space(3))) u32x2_t*)(size_t)(rtab_addr + ra);
-        const u32 E4 = entry_at(ad4);
+        const ET E4 = entry_at(ad4);
         wcur += cnt;
         flush_ring();
         if constexpr (NIB) rans_put_nib(E0, R0.x, R0.y);
