@@ -97,10 +97,23 @@ __device__ __forceinline__ u32 row_addr_sh(u32 w, u32 base) {
 }
 // ... of token I (0..31) of a 32-token block of workspace dwords (k_quantize.h formats).  Nibble planes: rows of
 // 256 B (dword entries), byte planes: rows of 128 B (u16 entries).
-template <bool NIB, int I>
+// ALIGNED: the wave's table slice starts at a multiple of 4 KiB (the 8-wave layouts: k_encode_fused, the counts-only
+// k_cdf_encode), so bits 8 .. 11 of a lane's column address are zero and the one nibble of a dword that already
+// sits there is merged in by ONE v_and_or_b32.
+template <bool NIB, int I, bool ALIGNED = false>
 __device__ __forceinline__ u32 row_addr_cnt(const u32* w, u32 base) {
-  if constexpr (NIB) return row_addr_sh<8 * (I & 3) + 4 * ((I >> 2) & 1), 4, 8>(w[I >> 3], base);
-  else return row_addr_sh<8 * (I & 3), 8, 7>(w[I >> 2], base);
+  if constexpr (NIB) {
+    constexpr int POS = 8 * (I & 3) + 4 * ((I >> 2) & 1);
+    if constexpr (ALIGNED && POS == 8) {
+      u32 r;
+      asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w[I >> 3]), "s"(0xf00u), "v"(base));
+      return r;
+    } else {
+      return row_addr_sh<POS, 4, 8>(w[I >> 3], base);
+    }
+  } else {
+    return row_addr_sh<8 * (I & 3), 8, 7>(w[I >> 2], base);
+  }
 }
 
 
@@ -179,12 +192,14 @@ __device__ __forceinline__ void counts_table_byte(const u32 (&cnt)[32], u16* tab
 // active lanes can emit -- S = sum of lmc_counts_bits over a lane's model counts (`bits` = the workgroup's LDS copy),
 // lmc_counts_lane_words(S) words per lane -- + the 64 states.  Wave g == 0 also writes the checksum of the plane's
 // scales.  The slice is free again on return.
+template <bool ALIGNED = false>
 __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const CountsStream& s, u32* tabmem, const u32* bits,
                                                   int lane, CountsState& cs) {
   typedef __attribute__((address_space(3))) u32* lds_u32w;
   typedef const __attribute__((address_space(3))) u16* lds_u16p;
   constexpr int Tc = (int)LMC_COUNTS_T;
   const u32 tab_addr = (u32)(size_t)(lds_u32w)tabmem;
+  if (ALIGNED && (tab_addr & 0xfffu)) __builtin_trap();  // (wave-uniform: the layout is static)
   u16* const tab16 = reinterpret_cast<u16*>(tabmem);
   auto pass1 = [&](auto nib_tag) {
     constexpr bool NIB = decltype(nib_tag)::value;
@@ -204,7 +219,7 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
       }
       static_for<32>([&](auto itag) {
         constexpr int i = decltype(itag)::value;
-        const u32 ad = row_addr_cnt<NIB, i>(w, col);
+        const u32 ad = row_addr_cnt<NIB, i, ALIGNED>(w, col);
         __hip_atomic_fetch_add((lds_u32w)(size_t)ad, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       });
 #pragma unroll
@@ -290,7 +305,8 @@ __device__ __forceinline__ void counts_open_stream(const CountsStream& s, const 
 // `tabmem` holds the stream's table, `ring` is the wave's staging ring (ENC_RING_DWORDS), `rtab` the workgroup's copy
 // of g_rans_rtab.  The words of a step go to the ring (256 slots + a 64-slot extension: a step never wraps); whenever
 // 128 words have gathered they leave with one coalesced 256-byte store to `out` (wave-uniform).  NT: the stores are
-// non-temporal (the stream is at its final place: nobody reads it again).
+// non-temporal (the stream is at its final place: nobody reads it again) -- the callers that code in place are the
+// 8-wave layouts, whose table slices are 4 KiB aligned (row_addr_cnt's ALIGNED).
 // Returns the exact length in bytes of words + states (the head in front of `out` not counted); the 64 states follow
 // the words, then zeros up to a multiple of 16 (`out` is 16-byte aligned).
 template <bool NT>
@@ -300,6 +316,7 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
   typedef __attribute__((address_space(3))) u16* lds_u16w;
   constexpr int Tc = (int)LMC_COUNTS_T;
   const u32 tab_addr = (u32)(size_t)(lds_u32w)tabmem;
+  if (NT && (tab_addr & 0xfffu)) __builtin_trap();  // (wave-uniform: the layout is static)
   const u32 rtab_addr = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(lds_u32w) const_cast<u32*>(rtab));
   u32 x = s.active ? LMC_COUNTS_L : 0u;  // idle lanes stay at 0 and never emit
   u32 wcur = 0;  // wave-uniform word cursor
@@ -370,10 +387,10 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
     // reciprocal and appends the step's words -- under exec = emitting lanes: v_cmpx on the state's upper half against
     // the entry's (count << 7), mbcnt rank, ds_write_b16 into the ring, x >>= 16, exec restored -- and the loads are
     // plain loads the compiler tracks, issued right behind the block (behind the ring store in the LDS queue).
-    ET E0 = entry_at(row_addr_cnt<NIB, 31>(w, col));
-    ET E1 = entry_at(row_addr_cnt<NIB, 30>(w, col));
-    ET E2 = entry_at(row_addr_cnt<NIB, 29>(w, col));
-    ET E3 = entry_at(row_addr_cnt<NIB, 28>(w, col));
+    ET E0 = entry_at(row_addr_cnt<NIB, 31, NT>(w, col));
+    ET E1 = entry_at(row_addr_cnt<NIB, 30, NT>(w, col));
+    ET E2 = entry_at(row_addr_cnt<NIB, 29, NT>(w, col));
+    ET E3 = entry_at(row_addr_cnt<NIB, 28, NT>(w, col));
     u32x2_t R0 = rtab_of(E0);
     u32x2_t R1 = rtab_of(E1);
     for (int b = NB - 1; b >= 0; b--) {
@@ -382,8 +399,8 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
       static_for<32>([&](auto itag) {
         constexpr int i = 31 - decltype(itag)::value;  // token of the block, descending
         u32 ad4;  // row address of the token four further on (past the last block: row 0, read and never used)
-        if constexpr (i >= 4) ad4 = row_addr_cnt<NIB, i - 4>(w, col);
-        else ad4 = row_addr_cnt<NIB, 28 + i>(wn, col);
+        if constexpr (i >= 4) ad4 = row_addr_cnt<NIB, i - 4, NT>(w, col);
+        else ad4 = row_addr_cnt<NIB, 28 + i, NT>(wn, col);
         const u32 wbase = ring_addr + ((wcur & (ENC_RING_WORDS - 1)) << 1);  // scalar
         u32 tt, cnt, ra;
         if constexpr (NIB) {
@@ -459,7 +476,7 @@ template <bool QUADSYM, bool ENCODE, int NW = ENC_WAVES, bool COUNTS_ONLY = fals
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 8 : 4, 8))) void k_cdf_encode(EncodeArgs a) {
   static_assert(!COUNTS_ONLY || (QUADSYM && ENCODE), "the counts coder reads the workspace and places its streams");
   constexpr int TAB_DWORDS = COUNTS_ONLY ? CNT_TAB_DWORDS : ENC_TAB_DWORDS;
-  __shared__ __attribute__((aligned(16))) u32 lds_all[NW * (ENC_RING_DWORDS + TAB_DWORDS)];  // the staging rings, then the tables
+  __shared__ __attribute__((aligned(4096))) u32 lds_all[NW * (TAB_DWORDS + ENC_RING_DWORDS)];  // the tables, then the staging rings (counts-only launch: 4 KiB slices at multiples of 4 KiB, row_addr_cnt ALIGNED)
   __shared__ __attribute__((aligned(16))) u32 rtab_lds[ENCODE ? RTAB_LDS_DWORDS : 4];     // counts model: reciprocals, bound table
   if (ENCODE && QUADSYM) {
     rtab_to_lds(rtab_lds);
@@ -469,7 +486,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
   // everything derived from the wave id is wave-uniform: keep it in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long ngroups_total = (long long)a.nchunks * a.P * a.G;
-  u32* hist = lds_all + NW * ENC_RING_DWORDS + wave * TAB_DWORDS;  // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
+  u32* hist = lds_all + wave * TAB_DWORDS;  // [32][64] u16 counters; lanes 2i, 2i+1 share a dword
 
   // Workgroup -> streams.  When the streams of a chunk fill whole workgroups, consecutive workgroups take the SAME
   // position of consecutive CHUNKS (chunk = block % nchunks): the predecessors a workgroup's placement depends on
@@ -495,7 +512,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
   const long long gid = (long long)chunk_i * npg + pg_i;
   if (gid >= ngroups_total) return;
   PendingTile t;
-  u16* const wring = reinterpret_cast<u16*>(lds_all + wave * (ENC_RING_DWORDS));
+  u16* const wring = reinterpret_cast<u16*>(lds_all + NW * TAB_DWORDS + wave * ENC_RING_DWORDS);
   u32 alloc = 0;  // the stream's allocation in the blob
   auto counts_stream = [&]() {
     const u32 p_i = pg_i / (u32)a.G;
@@ -516,7 +533,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
     const u32 p_i = pg_i / (u32)a.G;
     const CountsStream s = counts_stream_of(a, (int)chunk_i, (int)p_i, (int)(pg_i - p_i * (u32)a.G), lane);
     CountsState cs;
-    alloc = counts_hist_stream(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
+    alloc = counts_hist_stream<true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
     __shared__ u32 wg_alloc[NW];
     __shared__ u32 wg_excl;
     if (lane == 0) wg_alloc[wave] = alloc;

@@ -270,7 +270,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   static_assert(SPLIT == 1 || (GL == 64 && NITER == 2 && NW % SPLIT == 0), "wide planes: SPLIT waves x 1024 channels");
   constexpr bool STASH = SPLIT > 1;  // more than two streams per wave: their counts wait in global memory
   const EncodeArgs& a = fa.e;
-  __shared__ __attribute__((aligned(16))) u32 lds_all[NW * (ENC_RING_DWORDS + CNT_TAB_DWORDS)];  // the staging rings, then the tables
+  // (4 KiB aligned, the 4 KiB table slices first: every slice starts at a multiple of 4 KiB, which the row addressing
+  // of the counts coder uses -- row_addr_cnt ALIGNED)
+  __shared__ __attribute__((aligned(4096))) u32 lds_all[NW * (CNT_TAB_DWORDS + ENC_RING_DWORDS)];  // the tables, then the staging rings
   __shared__ __attribute__((aligned(16))) u32 rtab_lds[RTAB_LDS_DWORDS];  // reciprocals of the counts model's frequencies, bound table
   __shared__ u32 st_alloc[FUSED_MAX_NS];  // allocation of the item's group streams
   __shared__ u32 xmax[SPLIT > 1 ? (NW / SPLIT) * 4 * SPLIT : 1];  // wide planes: the row maxima of the waves that share an oct
@@ -286,8 +288,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   const int NS = np * a.G;                               // ... and streams: j -> plane p0 + j / G, group j % G
   const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
   constexpr int Tc = (int)LMC_COUNTS_T;  // lmc_api.hip hands this kernel full 256-token chunks only
-  u32* const hist = lds_all + NW * ENC_RING_DWORDS + wave * CNT_TAB_DWORDS;  // this wave's table slice ...
-  u16* const ring = reinterpret_cast<u16*>(lds_all + wave * ENC_RING_DWORDS);  // ... and staging ring
+  u32* const hist = lds_all + wave * CNT_TAB_DWORDS;  // this wave's table slice ...
+  u16* const ring = reinterpret_cast<u16*>(lds_all + NW * CNT_TAB_DWORDS + wave * ENC_RING_DWORDS);  // ... and staging ring
 
   rtab_to_lds(rtab_lds);  // visible to the coder waves behind the barrier that ends phase A
   // A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next (k_offload, k_pack_scan,
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   auto pass1 = [&](int j, CountsState& cs) {
     if (j < NS) {  // wave-uniform
       const CountsStream s = stream_of(j);
-      const u32 alloc = counts_hist_stream(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
+      const u32 alloc = counts_hist_stream<true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
       if (lane == 0) st_alloc[j] = alloc;
       if constexpr (STASH) counts_state_store(cs, stash0 + (long long)j * FUSED_STASH_DWORDS, lane);
     }
