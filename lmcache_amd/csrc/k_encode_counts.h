@@ -269,12 +269,12 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
     for (int k = 0; k < NS / 4; k++) sum = __builtin_amdgcn_sad_u8(cs.pk[k], 0u, sum);
     // (read unconditionally: a load under a condition becomes a branch, and every 16-bit value that crosses it costs
     // a v_and)
-    const u32 bits_of_1 = (u32) * (lds_u16p)(size_t)(bits_addr + 2u);
 #pragma unroll
     for (int i = 0; i < NS; i++) {
       const u32 c = (cs.pk[i >> 2] >> (8 * (i & 3))) & 0xffu;
       S += (u32) * (lds_u16p)(size_t)(bits_addr + 2u * c);
     }
+    const u32 bits_of_1 = (u32) * (lds_u16p)(size_t)(bits_addr + 2u);
     S += sum == LMC_COUNTS_T - 1u ? bits_of_1 : 0u;
   };
   if (s.nib) bound(IntTag<16>{});
