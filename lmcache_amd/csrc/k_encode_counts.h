@@ -193,7 +193,8 @@ __device__ __forceinline__ void counts_table_byte(const u32 (&cnt)[32], u16* tab
 // lmc_counts_lane_words(S) words per lane -- + the 64 states.  Wave g == 0 also writes the checksum of the plane's
 // scales.  The slice is free again on return.
 template <bool ALIGNED = false>
-__device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const CountsStream& s, u32* tabmem, const u32* bits,
+__device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const CountsStream& s, u32* tabmem,
+                                                  const u32* bits,
                                                   int lane, CountsState& cs) {
   typedef __attribute__((address_space(3))) u32* lds_u32w;
   typedef const __attribute__((address_space(3))) u16* lds_u16p;
@@ -260,6 +261,9 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
   cs.head = head_bytes_of<8, 8>(cs.wor, s.R);
   // the bound: S over the lane's MODEL counts = its stored counts, plus the count of 1 a constant channel's model
   // gives a second symbol (stored 255 alone: the sum is a unit short)
+  // (`bits` points into a __shared__ array of the kernel: a constant after inlining, so it rides in the
+  // loads' offset field and a symbol costs a shift out of its byte -- one SDWA instruction -- and an add)
+  __builtin_assume(bits != nullptr);  // (else the cast below carries a null check and is no constant)
   const u32 bits_addr = (u32)(size_t)(lds_u16p) reinterpret_cast<const u16*>(bits);
   u32 S = 0;
   auto bound = [&](auto ns_tag) {
@@ -269,11 +273,15 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
     for (int k = 0; k < NS / 4; k++) sum = __builtin_amdgcn_sad_u8(cs.pk[k], 0u, sum);
     // (read unconditionally: a load under a condition becomes a branch, and every 16-bit value that crosses it costs
     // a v_and)
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-      const u32 c = (cs.pk[i >> 2] >> (8 * (i & 3))) & 0xffu;
-      S += (u32) * (lds_u16p)(size_t)(bits_addr + 2u * c);
-    }
+    static_for<NS>([&](auto itag) {
+      constexpr int i = decltype(itag)::value;
+      u32 c2;  // 2 * count of symbol i
+      if constexpr ((i & 3) == 0) asm("v_lshlrev_b32_sdwa %0, 1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(c2) : "v"(cs.pk[i >> 2]));
+      else if constexpr ((i & 3) == 1) asm("v_lshlrev_b32_sdwa %0, 1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(c2) : "v"(cs.pk[i >> 2]));
+      else if constexpr ((i & 3) == 2) asm("v_lshlrev_b32_sdwa %0, 1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(c2) : "v"(cs.pk[i >> 2]));
+      else asm("v_lshlrev_b32_sdwa %0, 1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(c2) : "v"(cs.pk[i >> 2]));
+      S += (u32) * (lds_u16p)(size_t)(c2 + bits_addr);
+    });
     const u32 bits_of_1 = (u32) * (lds_u16p)(size_t)(bits_addr + 2u);
     S += sum == LMC_COUNTS_T - 1u ? bits_of_1 : 0u;
   };
