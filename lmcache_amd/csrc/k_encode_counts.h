@@ -147,42 +147,58 @@ struct CountsState {
   u32 head;
 };
 
+// VOP2 with an SDWA byte select on the second operand: D = OP(a, byte K of b) -- a count leaves its packed register
+// inside the instruction that uses it.
+#define LMC_SDWA_BYTE_OP(NAME, OP)                                                                                      \
+  template <int K>                                                                                                      \
+  __device__ __forceinline__ u32 NAME(u32 a, u32 b) {                                                                   \
+    u32 d;                                                                                                              \
+    if constexpr (K == 0) asm(OP " %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(a), "v"(b)); \
+    else if constexpr (K == 1) asm(OP " %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(a), "v"(b)); \
+    else if constexpr (K == 2) asm(OP " %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(a), "v"(b)); \
+    else asm(OP " %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(a), "v"(b)); \
+    return d;                                                                                                           \
+  }
+LMC_SDWA_BYTE_OP(sdwa_byte_shl, "v_lshlrev_b32_sdwa")  // byte K of b << a
+LMC_SDWA_BYTE_OP(sdwa_byte_add, "v_add_u32_sdwa")      // a + byte K of b
+LMC_SDWA_BYTE_OP(sdwa_byte_or, "v_or_b32_sdwa")        // a | byte K of b
+
 // A lane's MODEL counts (lmc_counts_model) from its stored counts: themselves, but a channel whose 256 symbols are
 // equal (stored 255, a unit missing from the sum) is coded with 255 and a count of 1 on symbol 0 (on symbol 1 if its
 // own symbol is 0); a lane without a channel is coded like a constant channel of symbol 0 (it never emits).
-// cnt[i] = count of symbol i, NS = 16 or 32.
+// Packed as the stored counts are: mp[k] = four model counts (the fix-ups touch symbols 0 and 1 only, and neither
+// carries out of its byte: a count that grows was 0).
 template <int NS>
-__device__ __forceinline__ void counts_model_of(const u32 (&pk)[8], bool active, u32 (&cnt)[NS]) {
+__device__ __forceinline__ void counts_model_pk(const u32 (&pk)[8], bool active, u32 (&mp)[NS / 4]) {
   u32 sum = 0;
 #pragma unroll
-  for (int k = 0; k < NS / 4; k++) sum = __builtin_amdgcn_sad_u8(pk[k], 0u, sum);  // four counts per instruction
-#pragma unroll
-  for (int i = 0; i < NS; i++) cnt[i] = (pk[i >> 2] >> (8 * (i & 3))) & 0xffu;
+  for (int k = 0; k < NS / 4; k++) sum = __builtin_amdgcn_sad_u8(pk[k], 0u, sum);
   const u32 deficit = LMC_COUNTS_T - sum;  // 0, or 1 for a constant channel (256 for a lane without a channel)
-  const bool first = cnt[0] == 255u;
-  cnt[0] += first ? 0u : deficit;
-  cnt[1] += first ? deficit : 0u;
-  if (!active) { cnt[0] = 255u; cnt[1] = 1u; }
+  const bool first = (pk[0] & 0xffu) == 255u;
+#pragma unroll
+  for (int k = 0; k < NS / 4; k++) mp[k] = pk[k];
+  mp[0] += first ? deficit << 8 : deficit;
+  if (!active) mp[0] = 0x01ffu;  // (its stored counts are all 0)
 }
-
 // The table of a <= 16-symbol plane from this lane's MODEL counts: entry = count << 23 | 2 * (symbols below) -- the
-// emit threshold's upper half, and the start.
-__device__ __forceinline__ void counts_table_nib(const u32 (&cnt)[16], u32* tabmem, int lane) {
+// emit threshold's upper half, and the start.  Three instructions per symbol.
+__device__ __forceinline__ void counts_table_nib_pk(const u32 (&mp)[4], u32* tabmem, int lane) {
   u32 acc = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    tabmem[i * 64 + lane] = (cnt[i] << 23) | (acc << 1);
-    acc += cnt[i];
-  }
+  static_for<16>([&](auto itag) {
+    constexpr int i = decltype(itag)::value;
+    const u32 t = sdwa_byte_shl<i & 3>(23u, mp[i >> 2]);
+    tabmem[i * 64 + lane] = (acc << 1) | t;
+    acc = sdwa_byte_add<i & 3>(acc, mp[i >> 2]);
+  });
 }
-// ... of a plane with more symbols: entry = (symbols below) << 8 | count; 255 + 1 keeps both in a byte
-__device__ __forceinline__ void counts_table_byte(const u32 (&cnt)[32], u16* tab16, int lane) {
+// ... of a plane with more symbols: entry = (symbols below) << 8 | count in 16 bits; 255 + 1 keeps both in a byte
+__device__ __forceinline__ void counts_table_byte_pk(const u32 (&mp)[8], u16* tab16, int lane) {
   u32 acc = 0;
-#pragma unroll
-  for (int i = 0; i < 32; i++) {
-    tab16[i * 64 + lane] = (u16)(((acc & 0xffu) << 8) | cnt[i]);
-    acc += cnt[i];
-  }
+  static_for<32>([&](auto itag) {
+    constexpr int i = decltype(itag)::value;
+    tab16[i * 64 + lane] = (u16)sdwa_byte_or<i & 3>(acc << 8, mp[i >> 2]);
+    acc = sdwa_byte_add<i & 3>(acc, mp[i >> 2]);
+  });
 }
 
 // ---- pass 1 --------------------------------------------------------------------------------------------------------
@@ -298,13 +314,13 @@ __device__ __forceinline__ void counts_open_stream(const CountsStream& s, const 
   (void)head_write<8, 8>(out, cs.pk, cs.wor, s.R, tabmem, lane);  // (the slice is idle: the table comes next)
   wave_lds_fence();
   if (s.nib) {
-    u32 cnt[16];
-    counts_model_of<16>(cs.pk, s.active, cnt);
-    counts_table_nib(cnt, tabmem, lane);
+    u32 mp[4];
+    counts_model_pk<16>(cs.pk, s.active, mp);
+    counts_table_nib_pk(mp, tabmem, lane);
   } else {
-    u32 cnt[32];
-    counts_model_of<32>(cs.pk, s.active, cnt);
-    counts_table_byte(cnt, reinterpret_cast<u16*>(tabmem), lane);
+    u32 mp[8];
+    counts_model_pk<32>(cs.pk, s.active, mp);
+    counts_table_byte_pk(mp, reinterpret_cast<u16*>(tabmem), lane);
   }
   wave_lds_fence();
 }
@@ -332,6 +348,8 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
   const u64 full_exec = __builtin_amdgcn_read_exec();
   u16* const out = reinterpret_cast<u16*>(uniform_ptr64(out_v));
   u32 flushed = 0;     // words already in global memory (a multiple of 128), wave-uniform
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, (int)0xfffffff0u, 0x00020000);
+  const u32 lane4 = 4u * (u32)lane;
   auto flush_ring = [&]() {
     if (wcur - flushed >= 128u) {
       wave_lds_fence();
@@ -340,9 +358,9 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
         if ((u32)lane < over) ring[lane] = ring[ENC_RING_WORDS + lane];
       }
       const u32 v = (reinterpret_cast<const u32*>(ring) + ((flushed & (ENC_RING_WORDS - 1)) >> 1))[lane];
-      LMC_GLOBAL u32* const dst = (LMC_GLOBAL u32*)out + (flushed >> 1) + lane;
-      if (NT) __builtin_nontemporal_store(v, dst);
-      else *dst = v;
+      // (uniform base in the descriptor, the lane in the vector offset, the stream position in the scalar offset: no
+      // vector instruction for the address)
+      __builtin_amdgcn_raw_buffer_store_b32((int)v, out_rsrc, (int)lane4, (int)(flushed << 1), NT ? 2 : 0);
       flushed += 128u;
     }
   };
