@@ -195,7 +195,8 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
       }
       float factor[2];
       bool special[2] = {false, false};
-      bool slow = false;
+      u32 slow = 0;  // (an integer, not a bool: a bool merged over the branch below becomes a lane mask, and testing it
+                     // costs two vector instructions in front of every block of eight elements)
       // both row maxes are wave-uniform: one scalar branch picks the short division for the pair -- and a max inside
       // its range is finite, non-zero and has a finite factor, so such a pair cannot be special: no tests at all
       const bool short_div = LMC_SHORT_ROW_DIV && row_div_in_range(mrow[0], DT) && row_div_in_range(mrow[1], DT);
@@ -211,7 +212,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
           special[r] = !(__builtin_fabsf(factor[r]) < __builtin_inff()) || !(sf < __builtin_inff());
           any_special |= special[r];
         }
-        slow = __ballot(any_special) != 0;  // wave-uniform and rare
+        slow = __ballot(any_special) != 0 ? 1u : 0u;  // wave-uniform and rare
       }
 #pragma unroll
       for (int it = 0; it < NITER; it++) {
@@ -219,7 +220,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
 #pragma unroll
         for (int r = 0; r < 2; r++) {
           const u32 w[4] = {v[r][it].x, v[r][it].y, v[r][it].z, v[r][it].w};
-          if (!slow) {
+          if (slow == 0u) {
             const f32x2_t f2 = {factor[r], factor[r]};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
