@@ -1,6 +1,6 @@
 #!/bin/bash
 # Turn the databases tools/scripts/profile_round.sh left under gpurun_out/<dir> into the committed summaries:
-#   bash tools/scripts/render_profiles.sh rprof r04_g
+#   bash tools/scripts/render_profiles.sh rprof r04_h
 set -e
 O=gpurun_out/$1; TAG=$2
 python tools/rocpd_stats.py $O/stats/bench_results.db --min-grid 2000000 > profiles/${TAG}_bench_kernel_stats.md
