@@ -46,7 +46,9 @@
 // non-temporal, the streams are stored non-temporal (counts_code_stream<true>), the coding pass reads its symbols for
 // the last time non-temporal (LMC_SYM_LAST_LOAD, k_encode_counts.h).  Round 3, same box, alternating processes:
 // 1.017-1.027 ms without, 0.968-0.975 with.
+#ifndef LMC_FUSED_PRIO_A
 #define LMC_FUSED_PRIO_A 3  // wave priority while a wave fetches / quantises (phase A): its few instructions go first
+#endif
 
 struct FusedArgs {
   KvAddr src;
