@@ -343,25 +343,34 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
   if (NT && (tab_addr & 0xfffu)) __builtin_trap();  // (wave-uniform: the layout is static)
   const u32 rtab_addr = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(lds_u32w) const_cast<u32*>(rtab));
   u32 x = s.active ? LMC_COUNTS_L : 0u;  // idle lanes stay at 0 and never emit
-  u32 wcur = 0;  // wave-uniform word cursor
   const u32 ring_addr = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(lds_u16w)ring);
   const u64 full_exec = __builtin_amdgcn_read_exec();
   u16* const out = reinterpret_cast<u16*>(uniform_ptr64(out_v));
+  // The staging buffer is LINEAR (round 5; it was a ring whose cursor was masked, shifted and re-based every token):
+  // `wb` is the LDS byte address of the next free slot, a step's words go to wb + 2 * rank and wb += 2 * count -- one
+  // scalar instruction -- and every SECOND token one compare asks whether the first 128 words are complete.  If so
+  // they leave with one coalesced 256-byte store, the < 128 words behind them move down to the buffer's start and
+  // wb steps back by 256 bytes.  Two steps add at most 128 words to fewer than 128: 256 words = 512 B of the wave's
+  // ENC_RING_DWORDS.  What this removes from every token step: s_sub / s_cmpk / a TAKEN s_cbranch (now every second
+  // step), s_lshl / s_and / s_add of the cursor -- 3.3 + 0.9 ns of the step's 24.2 in the issue-slot replica
+  // (tools/probes/issue_model.py, profiles/r05_issue_model.md).
+  u32 wb = ring_addr;
+  const u32 wlimit = ring_addr + 256u;
   u32 flushed = 0;     // words already in global memory (a multiple of 128), wave-uniform
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, (int)0xfffffff0u, 0x00020000);
   const u32 lane4 = 4u * (u32)lane;
+  u32* const ring32 = reinterpret_cast<u32*>(ring);
   auto flush_ring = [&]() {
-    if (wcur - flushed >= 128u) {
+    if (__builtin_expect(wb >= wlimit, 0)) {
       wave_lds_fence();
-      if (flushed & 128u) {  // the upper half leaves: bring the words that ran past slot 255 back to slots 0..
-        const u32 over = wcur - flushed - 128u;  // < 64
-        if ((u32)lane < over) ring[lane] = ring[ENC_RING_WORDS + lane];
-      }
-      const u32 v = (reinterpret_cast<const u32*>(ring) + ((flushed & (ENC_RING_WORDS - 1)) >> 1))[lane];
+      const u32 v = ring32[lane];
+      const u32 up = ring32[64 + lane];  // words 128 .. 255: whatever of them is in use moves down
       // (uniform base in the descriptor, the lane in the vector offset, the stream position in the scalar offset: no
       // vector instruction for the address)
       __builtin_amdgcn_raw_buffer_store_b32((int)v, out_rsrc, (int)lane4, (int)(flushed << 1), NT ? 2 : 0);
+      if (lane4 < wb - wlimit) ring32[lane] = up;  // (a half-used last dword brings a stale upper half along: the next word overwrites it)
       flushed += 128u;
+      wb -= 256u;
     }
   };
   // state update x += (x / f) * (512 - f) + start, the quotient by the frequency's reciprocal {m, shc}
@@ -427,7 +436,6 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
         u32 ad4;  // row address of the token four further on (past the last block: row 0, read and never used)
         if constexpr (i >= 4) ad4 = row_addr_cnt<NIB, i - 4, NT>(w, col);
         else ad4 = row_addr_cnt<NIB, 28 + i, NT>(wn, col);
-        const u32 wbase = ring_addr + ((wcur & (ENC_RING_WORDS - 1)) << 1);  // scalar
         u32 tt, cnt, ra;
         if constexpr (NIB) {
           asm volatile("v_lshrrev_b32_e32 %[ra], 20, %[e2]\n\t"
@@ -441,7 +449,7 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
                        "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
                        "s_mov_b64 exec, %[full]"
                        : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
-                       : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wbase), [full] "s"(full_exec)
+                       : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wb), [full] "s"(full_exec)
                        : "vcc", "scc", "memory");
         } else {
           asm volatile("v_lshlrev_b32_sdwa %[ra], 3, %[e2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
@@ -456,13 +464,13 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
                        "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
                        "s_mov_b64 exec, %[full]"
                        : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
-                       : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wbase), [full] "s"(full_exec)
+                       : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wb), [full] "s"(full_exec)
                        : "vcc", "scc", "memory");
         }
         const u32x2_t R2 = *(const __attribute__((address_space(3))) u32x2_t*)(size_t)(rtab_addr + ra);
         const ET E4 = entry_at(ad4);
-        wcur += cnt;
-        flush_ring();
+        asm("s_lshl1_add_u32 %0, %1, %0" : "+s"(wb) : "s"(cnt) : "scc");  // wb += 2 * cnt
+        if constexpr ((i & 1) == 0) flush_ring();
         if constexpr (NIB) rans_put_nib(E0, R0.x, R0.y);
         else rans_put_byte(E0, R0.x, R0.y);
         E0 = E1; E1 = E2; E2 = E3; E3 = E4;
@@ -475,9 +483,11 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
   if (s.nib) pass2(BoolTag<true>{});
   else pass2(BoolTag<false>{});
   x = s.active ? x : LMC_COUNTS_L;  // idle lanes (channel >= C) carry the initial state
-  // the words still in the ring (< 128 + 64)
+  // the words still in the buffer (< 128)
   wave_lds_fence();
-  for (u32 k = flushed + lane; k < wcur; k += 64) out[k] = ring[k & (ENC_RING_WORDS - 1)];
+  const u32 pending = (wb - ring_addr) >> 1;
+  u32 wcur = flushed + pending;  // words of the stream
+  for (u32 k = (u32)lane; k < pending; k += 64) out[flushed + k] = ring[k];
   // tail: states, pad
   out[wcur + 2 * lane] = (u16)x;
   out[wcur + 2 * lane + 1] = (u16)(x >> 16);
