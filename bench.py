@@ -119,18 +119,36 @@ def cpu_baseline(nchunks_sample):
     t0 = time.perf_counter()
     orc.encode_blobs_parallel(bits, code, H, D, bins, 1)  # warm, and what ONE core takes for a chunk
     one = time.perf_counter() - t0
-    # rounds of one chunk per thread until the sample is spent or ~20 s have gone
-    per_round = max(1, min(threads, nchunks_sample))
-    done, t0 = 0, time.perf_counter()
-    while done < nchunks_sample and (done == 0 or time.perf_counter() - t0 < 20.0):
-        orc.encode_blobs_parallel(bits, code, H, D, bins, per_round)
-        done += per_round
-    dt = time.perf_counter() - t0
-    raw = kv.numel() * 2 * done
-    out = {"value": round(raw / dt / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
-           "one_chunk_one_core_s": round(one, 3),
-           "sample": f"{done} chunks of 256 tokens (Llama-3-8B shape, {raw / 1e6:.0f} MB raw KV) in rounds of {per_round}, "
-                     f"oracle/lmc_oracle.c lmco_encode_blobs_parallel: one chunk per OpenMP thread, {threads} threads"}
+    # Thread scaling: t threads, one chunk each -- a warm round (the threads' buffers and the output
+    # arena are allocated and first-touched there, by the thread that uses them), then timed rounds.  Round 4's
+    # 9.6 MB/s per core at 256 threads against 200 MB/s alone was the allocator: every chunk malloc'ed, page-faulted
+    # and freed ~66 MB of temporaries plus its 18 MB output slot, and 256 threads queued for the process's memory-map
+    # lock (oracle/lmc_oracle.c: ws_get keeps the buffers per thread now).  `value` is the BEST point of the table.
+    chunk_raw = kv.numel() * 2
+    table, best = [], None
+    budget_s, t_all = 24.0, time.perf_counter()
+    for t in [x for x in (1, 8, 32, 64, 128, 256, 512) if x < ncores] + [ncores]:
+        if time.perf_counter() - t_all > budget_s or t > max(1, nchunks_sample):
+            break
+        got = orc.set_threads(t)
+        orc.encode_blobs_parallel(bits, code, H, D, bins, got)  # warm at this width
+        rounds, t0 = 0, time.perf_counter()
+        while rounds < 3 and (rounds == 0 or time.perf_counter() - t0 < 1.5):
+            orc.encode_blobs_parallel(bits, code, H, D, bins, got)
+            rounds += 1
+        dt = time.perf_counter() - t0
+        row = {"threads": got, "chunks": got * rounds, "GBps": round(chunk_raw * got * rounds / dt / 1e9, 3),
+               "MBps_per_thread": round(chunk_raw * rounds / dt / 1e6, 1)}
+        table.append(row)
+        if best is None or row["GBps"] > best["GBps"]:
+            best = row
+    orc.set_threads(ncores)
+    done = sum(r["chunks"] for r in table)
+    out = {"value": best["GBps"], "unit": "GB/s", "cores": best["threads"], "kind": "port",
+           "one_chunk_one_core_s": round(one, 3), "scaling": table, "host_cores": ncores,
+           "sample": f"{done} chunks of 256 tokens (Llama-3-8B shape, {chunk_raw / 1e6:.1f} MB raw KV each) over the thread counts of "
+                     f"`scaling`, oracle/lmc_oracle.c lmco_encode_blobs_parallel: one chunk per OpenMP thread; value = the best "
+                     f"row ({best['threads']} threads), OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND', 'unset')}"}
     out["reference_formula"] = cpu_reference_formula(kv)
     out["torch_serde"] = cpu_torch_serde()
     return out
@@ -1096,10 +1114,13 @@ def ttft_hbm_tier(dev, kv, proxy, alone, meta):
     try:
         toks = torch.randint(0, 32000, (CTX,), generator=torch.Generator().manual_seed(7))
         engine.store(toks, kv)
-        side = torch.cuda.Stream(device=dev)
-        whole = []
+        # the decode runs on a HIGH-priority side stream: its waves go first wherever the model's layers leave issue
+        # slots, so a range is complete as early as the hardware allows (schedule the slack)
+        side = torch.cuda.Stream(device=dev, priority=-1)
+        whole, host_ms = [], []
         from lmcache_amd.storage_backend.serde.cachegen_device import layer_ranges
-        piped = {2: [], 4: [], 8: [], (2, 6, 24): []}  # range size, or a schedule of range sizes (small ranges first)
+        # range size, or a schedule of range sizes (small ranges first, the last entry repeats)
+        piped = {2: [], 4: [], 8: [], (2, 6, 24): [], (1, 3, 12, 16): [], (4, 28): [], 32: []}
         for r in range(6):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -1113,6 +1134,7 @@ def ttft_hbm_tier(dev, kv, proxy, alone, meta):
                 t0 = time.perf_counter()
                 with torch.cuda.stream(side):        # one decode launch per range of layers on a side stream ...
                     res = engine.retrieve_layerwise(toks, layers_per_launch=step)
+                host_ms.append((time.perf_counter() - t0) * 1e3)  # hashing, look-ups, launches: the GPU idles until the first launch
                 for l0, l1 in layer_ranges(L, step):  # ... the model's layers of a range wait for THAT range's KV only
                     res.wait_layer(l0)
                     for l in range(l0, l1):
@@ -1128,7 +1150,7 @@ def ttft_hbm_tier(dev, kv, proxy, alone, meta):
         return {"retrieve_then_step_ms": round(median(whole), 3), "ratio": round(median(whole) / alone, 3),
                 "layerwise_ms": round(med[best], 3), "layerwise_ratio": round(med[best] / alone, 3),
                 "layers_per_launch": best if isinstance(best, int) else list(best), "layerwise_ms_by_layers_per_launch": {str(k): round(v, 3) for k, v in med.items()},
-                "target": "<= 1.05", "reps": 5,
+                "target": "<= 1.05", "reps": 5, "host_ms_before_the_model_can_start": round(median(host_ms), 3),
                 "hbm_floor_ratio": round((PROXY_BYTES + 2.66e9) / PROXY_BYTES, 3),
                 "note": "encoded chunks resident in HBM (4.2x more warm context than raw KV): retrieve = decode only; "
                         "layerwise = retrieve_layerwise on a side stream, one k_decode launch per range of layers, the "

@@ -107,6 +107,10 @@ int lmc_ctx_reserve(lmc_ctx* ctx, int L, int H, int D, int chunk_tokens, int max
 #define LMC_STATUS_LOOKBACK_TIMEOUT 8u
 #define LMC_STATUS_BAD_SCALES 16u     /* decode: a plane's scales do not match their checksum (lmc_format.h: scsum) */
 #define LMC_STATUS_HOST_ARENA_FULL 32u /* lmc_store_chunks: the pinned arena cannot take the job's blobs */
+/* A decode that raises any bit leaves the destination rows of the blobs concerned UNDEFINED (some of a plane's
+ * waves may have stored before another wave saw the damage: BAD_SCALES is found by the plane's first wave only,
+ * BAD_STREAM at the end of a stream).  A caller that decodes into live storage -- the paged entry points -- must
+ * treat those tokens as not retrieved; lmcache_amd's engine turns every non-zero status into a miss. */
 /* The context's sticky status word.  `clear` resets it. */
 int lmc_device_status(lmc_ctx* ctx, int clear);
 
@@ -115,9 +119,11 @@ int lmc_device_status(lmc_ctx* ctx, int clear);
  * chunks of 1 .. 65535 tokens.  Outside them the entry points return LMC_ERR_INVALID. */
 #define LMC_MAX_PLANES 256
 #define LMC_MAX_CHANNELS 4096
+#define LMC_FUSED_MAX_CHANNELS 1024 /* widest plane the fused encode kernel takes (k_fused.h) */
 
 /* Which kernels lmc_encode_chunks launches.  The fused kernel (one workgroup quantises, codes and places a
- * whole (chunk, plane): k_fused.h) covers 256 < C <= 1024 channels per plane; every other geometry takes
+ * run of whole planes of a chunk: k_fused.h) covers the 256-token chunks of planes of up to
+ * LMC_FUSED_MAX_CHANNELS channels; wider planes, other chunk lengths and a ragged last chunk take
  * k_quantize + k_cdf_encode whatever the setting.
  *   AUTO (default)  fused when the job has more (chunk, plane) pairs than the chip has workgroup slots
  *                   (4 per CU), where it is the faster of the two;

@@ -258,15 +258,15 @@ class LMCacheEngine:
         if got == 0:
             return LayerwiseRetrieval((), ret_mask, [], [])
         blob = box["blob"].narrow(2 if fmt == "vllm" else 3, 0, got)
-        events = []
-        for _, job in jobs:
-            if job is not None and job.layer_events:
-                events = list(job.layer_events)
-        if not events:  # the backend finished (or queued) everything in one piece
+        # one list of (first layer after the range, event) per decode job: a retrieve that spans several stores is
+        # several runs (local_backend.get_kv_range), i.e. several jobs, and layer l is complete when EVERY job's range
+        # that holds l is (round 4 kept only the last job's events and was right only because all jobs share a stream)
+        event_sets = [list(job.layer_events) for _, job in jobs if job is not None and job.layer_events]
+        if not event_sets:  # the backend finished (or queued) everything in one piece
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(blob.device))
-            events = [(box["L"], ev)]
-        return LayerwiseRetrieval(self._blob_to_tuple_kv(blob), ret_mask, events, jobs)
+            event_sets = [[(box["L"], ev)]]
+        return LayerwiseRetrieval(self._blob_to_tuple_kv(blob), ret_mask, event_sets[-1], jobs, event_sets)
 
     def _retrieve_into(self, tokens: torch.Tensor, mask: Optional[torch.Tensor], make_dst,
                        layers_per_launch: Optional[int] = None, jobs_out: Optional[list] = None) -> Tuple[int, torch.Tensor]:
@@ -356,8 +356,9 @@ class LMCacheEngine:
 class LayerwiseRetrieval:
     """What retrieve_layerwise returns: the KV tuple (being filled layer by layer), ret_mask, and the events."""
 
-    def __init__(self, kv, ret_mask, layer_events, jobs):
+    def __init__(self, kv, ret_mask, layer_events, jobs, event_sets=None):
         self.kv, self.ret_mask, self.layer_events, self._jobs = kv, ret_mask, layer_events, jobs
+        self._event_sets = event_sets if event_sets is not None else ([layer_events] if layer_events else [])
 
     def wait_layer(self, layer: int, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Make `stream` (default: the current one) wait until the KV of `layer` is complete.  No host wait."""
@@ -371,11 +372,13 @@ class LayerwiseRetrieval:
             else:
                 st.wait_event(ev)
 
-        for end, ev in self.layer_events:
-            if layer < end:
-                wait(ev)
-                return
-        wait(self.layer_events[-1][1])
+        for events in self._event_sets:  # every decode job of the retrieve: the range of ITS events that holds `layer`
+            for end, ev in events:
+                if layer < end:
+                    wait(ev)
+                    break
+            else:
+                wait(events[-1][1])
 
     def finish(self) -> None:
         """Host-side completion: waits for the decode and raises NativeError if a blob did not check out."""

@@ -358,17 +358,24 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
   const u32 wlimit = ring_addr + 256u;
   u32 flushed = 0;     // words already in global memory (a multiple of 128), wave-uniform
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, (int)0xfffffff0u, 0x00020000);
-  const u32 lane4 = 4u * (u32)lane;
-  u32* const ring32 = reinterpret_cast<u32*>(ring);
   auto flush_ring = [&]() {
-    if (__builtin_expect(wb >= wlimit, 0)) {
+#ifndef LMC_FLUSH_LIKELY
+#define LMC_FLUSH_LIKELY 0  // 0: the flush is laid out behind the loop (the common path falls through an untaken branch)
+#endif
+    if (__builtin_expect(wb >= wlimit, LMC_FLUSH_LIKELY)) {
       wave_lds_fence();
-      const u32 v = ring32[lane];
-      const u32 up = ring32[64 + lane];  // words 128 .. 255: whatever of them is in use moves down
-      // (uniform base in the descriptor, the lane in the vector offset, the stream position in the scalar offset: no
-      // vector instruction for the address)
-      __builtin_amdgcn_raw_buffer_store_b32((int)v, out_rsrc, (int)lane4, (int)(flushed << 1), NT ? 2 : 0);
-      if (lane4 < wb - wlimit) ring32[lane] = up;  // (a half-used last dword brings a stale upper half along: the next word overwrites it)
+      // (the lane's slot address is worked out HERE, behind an opaque asm: hoisted out of the token loop it becomes one
+      // more live register, which the 64-VGPR kernels spill -- and its reload in this block waits for vmcnt(0), i.e.
+      // for the symbol prefetch and the previous flush's store: measured +4 % on k_cdf_encode)
+      u32 lane_here = (u32)lane;
+      asm volatile("" : "+v"(lane_here));  // (opaque: what follows cannot be computed outside this block)
+      const u32 slot_addr = ring_addr + 4u * lane_here;
+      const u32 v = *(lds_u32w)(size_t)slot_addr;
+      const u32 up = *(lds_u32w)(size_t)(slot_addr + 256u);  // words 128 .. 255: whatever of them is in use moves down
+      // (uniform base in the descriptor, the lane in the vector offset, the stream position in the scalar offset)
+      const u32 voff = 4u * lane_here;
+      __builtin_amdgcn_raw_buffer_store_b32((int)v, out_rsrc, (int)voff, (int)(flushed << 1), NT ? 2 : 0);
+      if (voff < wb - wlimit) *(lds_u32w)(size_t)slot_addr = up;  // (a half-used last dword brings a stale upper half along: the next word overwrites it)
       flushed += 128u;
       wb -= 256u;
     }
@@ -470,7 +477,10 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
         const u32x2_t R2 = *(const __attribute__((address_space(3))) u32x2_t*)(size_t)(rtab_addr + ra);
         const ET E4 = entry_at(ad4);
         asm("s_lshl1_add_u32 %0, %1, %0" : "+s"(wb) : "s"(cnt) : "scc");  // wb += 2 * cnt
-        if constexpr ((i & 1) == 0) flush_ring();
+#ifndef LMC_FLUSH_EVERY
+#define LMC_FLUSH_EVERY 2  // tokens between two tests of the staging buffer (1 or 2: the buffer holds 128 + 2 x 64 words)
+#endif
+        if constexpr (LMC_FLUSH_EVERY == 1 || (i & 1) == 0) flush_ring();
         if constexpr (NIB) rans_put_nib(E0, R0.x, R0.y);
         else rans_put_byte(E0, R0.x, R0.y);
         E0 = E1; E1 = E2; E2 = E3; E3 = E4;

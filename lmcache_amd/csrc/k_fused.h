@@ -29,15 +29,16 @@
 //   C <= 128   (GL = 16)  8 planes per item, <= 16 streams; a wave quantises four row octs at a time, 16 lanes each
 //   C <= 256   (GL = 32)  4 planes per item, <= 16 streams; two row octs at a time
 //   C <= 1024  (GL = 64)  1 plane, <= 16 streams (NITER = 1 or 2 channel runs per lane)
-//   C <= 4096  (SPLIT = 2 / 4)  1 plane, <= 64 streams: 2 / 4 waves share a row oct (quantize_oct_fused), a wave codes
-//              4 / 8 streams and parks their counts in a global stash between its two passes
-// Every 256-token chunk of every geometry lmc_encode_chunks accepts comes through here (C = 128 is the Llama-3-70B
-// TP = 8 rank, C = 4096 BASELINE configs[0]); a ragged last chunk takes the two-kernel path.
+// Planes of more than 1024 channels (C = 4096 is BASELINE configs[0]) take the two-kernel path: a fused form for them
+// (2 / 4 waves sharing a row oct, the counts of a wave's 4 / 8 streams parked in a global stash between the passes)
+// was built in round 4, bit-exact, and never beat k_quantize + k_cdf_encode below eight generations of workgroups --
+// which no BASELINE configuration reaches -- so round 5 removed it.  A ragged last chunk takes
+// the two-kernel path as well.
 #pragma once
 #include "k_encode_counts.h"
 #include "k_quantize.h"
 
-#define FUSED_MAX_NS 64  // streams per work item
+#define FUSED_MAX_NS 16  // streams per work item
 #ifndef FUSED_WAVES
 #define FUSED_WAVES 8  // waves per workgroup: 4 workgroups per CU
 #endif
@@ -57,28 +58,7 @@ struct FusedArgs {
   long long scale_stride;
   u32 epoch;  // 1 .. 2^30 - 1
   int pl, ipc;   // planes per work item, items per chunk = ceil(P / pl)
-  u32* stash;    // SPLIT geometries: FUSED_STASH_DWORDS per stream of the job, where a stream's counts wait for pass 2
 };
-#define FUSED_STASH_DWORDS (9 * 64)  // pk[8] of every lane, then one row: lane k < 8 holds wor[k], lane 8 the head size
-
-// A stream's CountsState to / from its stash slot (coalesced rows of 256 bytes; written and read by the same wave).
-__device__ __forceinline__ void counts_state_store(const CountsState& cs, u32* slot, int lane) {
-#pragma unroll
-  for (int k = 0; k < 8; k++) slot[k * 64 + lane] = cs.pk[k];
-  u32 row = cs.head;
-#pragma unroll
-  for (int k = 0; k < 8; k++) row = lane == k ? cs.wor[k] : row;
-  slot[8 * 64 + lane] = row;
-}
-__device__ __forceinline__ void counts_state_load(CountsState& cs, const u32* slot, int lane) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own stores have left it
-#pragma unroll
-  for (int k = 0; k < 8; k++) cs.pk[k] = slot[k * 64 + lane];
-  const u32 row = slot[8 * 64 + lane];
-#pragma unroll
-  for (int k = 0; k < 8; k++) cs.wor[k] = (u32)__builtin_amdgcn_readlane((int)row, k);
-  cs.head = (u32)__builtin_amdgcn_readlane((int)row, 8);
-}
 
 __device__ __forceinline__ void aggE_store(unsigned long long* p, unsigned long long flag, u32 epoch, u32 v) {
   __hip_atomic_store(p, (flag << 62) | ((unsigned long long)epoch << 32) | (unsigned long long)v, __ATOMIC_RELAXED,
@@ -120,23 +100,18 @@ __device__ __forceinline__ u32 lookback_exclusive_epoch(unsigned long long* agg,
 // quant_special on zero / inf / NaN rows), two rows in flight, one row quad of accumulators at a time: a byte
 // plane stores each quad as soon as it is complete; a nibble plane parks the first quad's 8 * NITER dwords in
 // the wave's idle LDS slice and merges them with the second (byte k = token k | token 4 + k << 4).
-// FULL: every lane of every iteration holds channels of the plane (C == SPLIT * NITER * 512: Llama / Mistral GQA
+// FULL: every lane of every iteration holds channels of the plane (C == NITER * 512: Llama / Mistral GQA
 // shapes), so no per-lane validity is tested and no register is zero-filled for absent channels.
-// SPLIT > 1 (planes of more than 1024 channels): SPLIT waves share the oct, wave `slice` holds channels
-// [slice, slice + 1) * NITER * 512 of every row, and the row maxima of a row pair meet in LDS: xm[2][2][SPLIT], the
-// halves used alternately -- the pair after next overwrites a half only behind the barrier at which every wave has
-// read it -- so ONE workgroup barrier per row pair, executed by every wave of the workgroup (the octs are dealt out
-// evenly: lmc_api.hip only launches whole 256-token chunks).
-template <int NITER, int DT, bool NIB, bool FULL = false, int SPLIT = 1>
+template <int NITER, int DT, bool NIB, bool FULL = false>
 __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16* pbase, int tok0, int Tc, int t_first,
                                                    bool q1valid, int C, float maxf, u32* sym_out, u16* scale_out,
-                                                   uint4* park, int lane, int slice = 0, u32* xm = nullptr) {
+                                                   uint4* park, int lane) {
   long long coff[NITER];
   int c0[NITER];
   bool cval[NITER];
 #pragma unroll
   for (int it = 0; it < NITER; it++) {
-    c0[it] = ((slice * NITER + it) * 64 + lane) * 8;
+    c0[it] = (it * 64 + lane) * 8;
     cval[it] = FULL || c0[it] < C;
     const int h = c0[it] / src.D, d = c0[it] - h * src.D;
     coff[it] = (long long)h * src.stride_head + d;
@@ -174,23 +149,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
         mrow[r] = max(m & 0xffffu, m >> 16);
       }
       wave_max2_u32(mrow[0], mrow[1]);  // wave-uniform from here on
-      if constexpr (SPLIT > 1) {
-        u32* const half = xm + ((hq * 2 + (r0 >> 1)) & 1) * 2 * SPLIT;
-        if (lane == 0) {
-          half[slice] = mrow[0];
-          half[SPLIT + slice] = mrow[1];
-        }
-        __syncthreads();
-        u32 m0 = 0, m1 = 0;
-#pragma unroll
-        for (int k = 0; k < SPLIT; k++) {
-          m0 = max(m0, half[k]);
-          m1 = max(m1, half[SPLIT + k]);
-        }
-        mrow[0] = (u32)__builtin_amdgcn_readfirstlane((int)m0);
-        mrow[1] = (u32)__builtin_amdgcn_readfirstlane((int)m1);
-      }
-      if (lane == 0 && slice == 0) {
+      if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < 2; r++)
           if (tv[r]) scale_out[4 * hq + r0 + r] = (u16)mrow[r];
@@ -267,18 +226,15 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
   }
 }
 
-template <int GL, int NITER, int SPLIT, int DT, int NW>
+template <int GL, int NITER, int DT, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_fused(FusedArgs fa) {
-  static_assert(GL == 64 || (NITER == 1 && SPLIT == 1), "narrow planes: one channel run per lane");
-  static_assert(SPLIT == 1 || (GL == 64 && NITER == 2 && NW % SPLIT == 0), "wide planes: SPLIT waves x 1024 channels");
-  constexpr bool STASH = SPLIT > 1;  // more than two streams per wave: their counts wait in global memory
+  static_assert(GL == 64 || NITER == 1, "narrow planes: one channel run per lane");
   const EncodeArgs& a = fa.e;
   // (4 KiB aligned, the 4 KiB table slices first: every slice starts at a multiple of 4 KiB, which the row addressing
   // of the counts coder uses -- row_addr_cnt ALIGNED)
   __shared__ __attribute__((aligned(4096))) u32 lds_all[NW * (CNT_TAB_DWORDS + ENC_RING_DWORDS)];  // the tables, then the staging rings
   __shared__ __attribute__((aligned(16))) u32 rtab_lds[RTAB_LDS_DWORDS];  // reciprocals of the counts model's frequencies, bound table
   __shared__ u32 st_alloc[FUSED_MAX_NS];  // allocation of the item's group streams
-  __shared__ u32 xmax[SPLIT > 1 ? (NW / SPLIT) * 4 * SPLIT : 1];  // wide planes: the row maxima of the waves that share an oct
   __shared__ u32 wg_excl;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -330,28 +286,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       const int bins = (int)a.bins.b[p];
       const float maxf = (float)(bins / 2 - 1);
       const bool nib = lmc_sym_nibbles(bins);
-      const bool full = a.C == SPLIT * NITER * 512;  // no absent channels: the variant without per-lane validity
+      const bool full = a.C == NITER * 512;  // no absent channels: the variant without per-lane validity
       u32* const sym_pc = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.sym_stride;
       u16* const scl = reinterpret_cast<u16*>(scl0) + (long long)p * Tc;
       const u16* const pbase = lmc_plane_base(fa.src, p);
-      const int slice = wave % SPLIT;
-      u32* const xm = xmax + (wave / SPLIT) * 4 * SPLIT;
 #pragma unroll 1
-      for (int oct = wave / SPLIT; oct < TO; oct += NW / SPLIT) {
+      for (int oct = wave; oct < TO; oct += NW) {
         const bool q1valid = 2 * oct + 1 < a.TQ;
         if (full) {  // wave-uniform
           if (nib)
-            quantize_oct_fused<NITER, DT, true, true, SPLIT>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                                             sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane, slice, xm);
+            quantize_oct_fused<NITER, DT, true, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                             sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
           else
-            quantize_oct_fused<NITER, DT, false, true, SPLIT>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                                              sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane, slice, xm);
+            quantize_oct_fused<NITER, DT, false, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                              sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
         } else if (nib)
-          quantize_oct_fused<NITER, DT, true, false, SPLIT>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                                            sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane, slice, xm);
+          quantize_oct_fused<NITER, DT, true, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                            sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
         else
-          quantize_oct_fused<NITER, DT, false, false, SPLIT>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                                             sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane, slice, xm);
+          quantize_oct_fused<NITER, DT, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                             sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -364,23 +318,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const int pj = (int)((u32)j / (u32)a.G);
     return counts_stream_of(a, chunk, p0 + pj, j - pj * a.G, lane);
   };
-  u32* const stash0 = STASH ? fa.stash + (((long long)chunk * a.P + p0) * a.G) * FUSED_STASH_DWORDS : nullptr;
-  CountsState cs0, cs1;  // !STASH: of stream `wave`, and of stream `wave + NW`
+  CountsState cs0, cs1;  // of stream `wave`, and of stream `wave + NW`
   auto pass1 = [&](int j, CountsState& cs) {
     if (j < NS) {  // wave-uniform
       const CountsStream s = stream_of(j);
       const u32 alloc = counts_hist_stream<true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
       if (lane == 0) st_alloc[j] = alloc;
-      if constexpr (STASH) counts_state_store(cs, stash0 + (long long)j * FUSED_STASH_DWORDS, lane);
     }
   };
-  if constexpr (STASH) {
-#pragma unroll 1
-    for (int j = wave; j < NS; j += NW) pass1(j, cs0);
-  } else {
-    pass1(wave, cs0);
-    pass1(wave + NW, cs1);
-  }
+  pass1(wave, cs0);
+  pass1(wave + NW, cs1);
   __syncthreads();
 
   // ---- placement: one look-back per item, BEFORE the streams are coded ------------------------------------------
@@ -420,16 +367,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       wave_lds_fence();  // the next stream reuses this wave's LDS slices
     }
   };
-  if constexpr (STASH) {
-#pragma unroll 1
-    for (int j = wave; j < NS; j += NW) {
-      counts_state_load(cs0, stash0 + (long long)j * FUSED_STASH_DWORDS, lane);
-      pass2(j, cs0);
-    }
-  } else {
-    pass2(wave, cs0);
-    pass2(wave + NW, cs1);
-  }
+  pass2(wave, cs0);
+  pass2(wave + NW, cs1);
   // The chunk's last item knows the chunk's size: header, static sections, size word.
   if (p0 + np == a.P && wave == NW - 1) {
     write_blob_static(blob, bo, a, (u32)Tc, wg_excl + wg_total, lane);

@@ -41,7 +41,6 @@ struct lmc_ctx {
   struct Workspace {
     u32* sym4 = nullptr;  size_t sym4_bytes = 0;       // symbols between the quantise stage and the coder
     u8* scratch = nullptr; size_t scratch_bytes = 0;   // two-kernel path: the streams before they are placed
-    u32* stash = nullptr; size_t stash_bytes = 0;      // fused encode of wide planes: the streams' counts between the two passes
     unsigned long long* agg = nullptr; size_t agg_bytes = 0;  // look-back granules of the in-kernel compaction
     hipEvent_t ws_free = nullptr;  // recorded after the last kernel that touches the workspace
     bool ws_used = false;
@@ -53,6 +52,7 @@ struct lmc_ctx {
   Workspace ws[2];
   int num_cus = 256;
   int enc_path = LMC_ENCODE_PATH_AUTO;  // lmc_ctx_set_encode_path
+  int fused_pl = 0;                     // LMC_FUSED_PL at lmc_ctx_create (A/B switch of tools/probes: planes per work item of narrow planes; 0 = the built-in choice)
   u32 epoch = 0;                        // of the last fused launch (tags its look-back granules)
   unsigned long long* pack_table = nullptr;  // device copy of a pack's offset table while it is written (lmc_store_pack)
   size_t pack_table_bytes = 0;
@@ -104,6 +104,7 @@ int lmc_ctx_create(int device, lmc_ctx** out) {
   {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->num_cus = v;
+    if (const char* e = getenv("LMC_FUSED_PL")) c->fused_pl = atoi(e);  // read ONCE: never in the encode path
   }
   hipError_t e = hipHostMalloc((void**)&c->status_h, 64, hipHostMallocMapped | hipHostMallocPortable);
   if (e != hipSuccess) { g_last_hip = (int)e; delete c; return LMC_ERR_HIP; }
@@ -123,7 +124,6 @@ int lmc_ctx_destroy(lmc_ctx* c) {
     if (w.ws_used) (void)hipEventSynchronize(w.ws_free);
     if (w.sym4) (void)hipFree(w.sym4);
     if (w.scratch) (void)hipFree(w.scratch);
-    if (w.stash) (void)hipFree(w.stash);
     if (w.agg) (void)hipFree(w.agg);
     if (w.ticket) (void)hipFree(w.ticket);
     if (w.ws_free) (void)hipEventDestroy(w.ws_free);
@@ -262,31 +262,27 @@ static int ws_grow(void** p, size_t* have, size_t need) {
 // The fused encode for a plane width (k_fused.h: lanes per quantise task, channel runs per lane, waves per row).
 template <int DT>
 static void launch_fused(int C, dim3 grid, dim3 block, hipStream_t s, const FusedArgs& fa) {
-  if (C <= 128) hipLaunchKernelGGL((k_encode_fused<16, 1, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
-  else if (C <= 256) hipLaunchKernelGGL((k_encode_fused<32, 1, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
-  else if (C <= 512) hipLaunchKernelGGL((k_encode_fused<64, 1, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
-  else if (C <= 1024) hipLaunchKernelGGL((k_encode_fused<64, 2, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
-  else if (C <= 2048) hipLaunchKernelGGL((k_encode_fused<64, 2, 2, DT, FUSED_WAVES>), grid, block, 0, s, fa);
-  else hipLaunchKernelGGL((k_encode_fused<64, 2, 4, DT, FUSED_WAVES>), grid, block, 0, s, fa);
+  if (C <= 128) hipLaunchKernelGGL((k_encode_fused<16, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
+  else if (C <= 256) hipLaunchKernelGGL((k_encode_fused<32, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
+  else if (C <= 512) hipLaunchKernelGGL((k_encode_fused<64, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
+  else hipLaunchKernelGGL((k_encode_fused<64, 2, DT, FUSED_WAVES>), grid, block, 0, s, fa);  // C <= LMC_FUSED_MAX_CHANNELS
 }
 
 // caller holds ctx->mu.  The symbol workspace and the look-back granules of `max_chunks` chunks, stream scratch for
 // `scratch_chunks` of them (only the general coder launch -- chunk lengths other than 256, a ragged last chunk -- codes
 // into scratch slots; the fused kernel and the counts-only coder launch code straight into the blobs).
-static int reserve_locked(lmc_ctx::Workspace* c, int L, int H, int D, int chunk_tokens, int max_chunks, int scratch_chunks, bool stash = false) {
+static int reserve_locked(lmc_ctx::Workspace* c, int L, int H, int D, int chunk_tokens, int max_chunks, int scratch_chunks) {
   const size_t P = 2 * (size_t)L, C = (size_t)H * D, G = (C + 63) / 64, TQ = ((size_t)chunk_tokens + 3) / 4;
   const size_t need_sym = (size_t)max_chunks * P * TQ * C * 4;
   const size_t need_scr = (size_t)scratch_chunks * P * G * lmc_group_cap_bytes((uint32_t)chunk_tokens);
-  const size_t need_stash = stash ? (size_t)max_chunks * P * G * FUSED_STASH_DWORDS * 4 : 0;
   const size_t need_agg = (size_t)max_chunks * P * G * 8;
-  if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && need_agg <= c->agg_bytes && need_stash <= c->stash_bytes)
+  if (need_sym <= c->sym4_bytes && need_scr <= c->scratch_bytes && need_agg <= c->agg_bytes)
     return LMC_OK;
   // growing frees memory that queued kernels may still use: wait for them (this call only)
   if (c->ws_used) HIP_TRY(hipEventSynchronize(c->ws_free));
   int rc;
   if ((rc = ws_grow((void**)&c->sym4, &c->sym4_bytes, need_sym))) return rc;
   if ((rc = ws_grow((void**)&c->scratch, &c->scratch_bytes, need_scr))) return rc;
-  if ((rc = ws_grow((void**)&c->stash, &c->stash_bytes, need_stash))) return rc;
   const size_t agg_before = c->agg_bytes;
   if ((rc = ws_grow((void**)&c->agg, &c->agg_bytes, need_agg))) return rc;
   // fresh granules must not look like a published value of some epoch (k_fused.h)
@@ -360,20 +356,18 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   // k_fused.h codes the 256-token chunks (the counts model) of every plane width: a work item is a run of whole planes
   // of one chunk -- 8 planes of <= 128 channels, 4 of <= 256, else one
   const int nfull = (tok_end - tok_begin) / chunk_tokens;  // chunks of exactly chunk_tokens tokens; a ragged one may follow
-  const bool fused_fits = chunk_tokens == (int)LMC_COUNTS_T && nfull > 0;
+  // (planes of more than 1024 channels: two kernels -- the fused form built for them in round 4 never won below eight
+  // generations of workgroups and was removed, k_fused.h)
+  const bool fused_fits = chunk_tokens == (int)LMC_COUNTS_T && nfull > 0 && C <= LMC_FUSED_MAX_CHANNELS;
   // planes per work item: narrow planes are grouped until an item has about eight streams -- one per wave (C = 128,
   // 80 layers, 128 chunks, measured: 4 planes = 8 streams per item 0.65 ms, 8 planes 0.68, 2 planes 0.80)
   int pl = C <= 256 ? (8 / G > 1 ? 8 / G : 1) : 1;
-  if (const char* e = getenv("LMC_FUSED_PL")) { const int v = atoi(e); if (v >= 1 && v * G <= 16 && C <= 256) pl = v; }  // A/B switch (tools/probes)
+  if (c->fused_pl >= 1 && c->fused_pl * G <= 16 && C <= 256) pl = c->fused_pl;  // A/B switch (tools/probes), read at lmc_ctx_create
   const int ipc = (P + pl - 1) / pl;
   // AUTO: the fused kernel pays once its workgroups fill the slots of the chip (4 per CU): measured on MI355X with
   // 64 planes of 1024 channels, 4 / 8 / 12 / 16 / 32 / 64 chunks: fused / two-kernel time = 1.27 / 1.16 / 1.05 / 1.00 /
   // 0.91 / 0.90 (tools/probes/encode_ab.hip)
-  // Planes of more than 1024 channels (one item = 2 MB of raw KV, 64 streams): at one generation of workgroups nothing
-  // overlaps and the fused kernel loses (C = 4096, 16 chunks: 1.43-1.55 vs 1.12-1.14 ms), at four generations the two
-  // are level (C = 2048 / 4096, 16 k tokens: 2.198 vs 2.204 / 4.41-4.60 vs 4.34-4.41 ms), at eight it is ahead (C = 2048,
-  // 32 k tokens: 3.94 vs 4.32 ms; tools/probes/wide_plane_paths.py) -- AUTO takes it from eight generations on.
-  const long long auto_min = (C > 1024 ? 32ll : 4ll) * c->num_cus;
+  const long long auto_min = 4ll * c->num_cus;
   const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
                                     (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * ipc >= auto_min));
   // chunks that go through the general coder launch (scratch slots): every chunk of a job whose chunks are not 256 tokens
@@ -393,7 +387,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     else (void)hipGetLastError();  // hipErrorNotReady
   }
   if (!w) w = &c->ws[0];
-  int rc = reserve_locked(w, L, H, D, chunk_tokens, nchunks, scratch_chunks, fused && C > 1024);
+  int rc = reserve_locked(w, L, H, D, chunk_tokens, nchunks, scratch_chunks);
   if (rc) return rc;
   if (w->ws_used) HIP_TRY(hipStreamWaitEvent(s, w->ws_free, 0));
   // (A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next: the kernels clear the
@@ -480,7 +474,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     c->epoch = (c->epoch + 1u) & 0x3fffffffu;
     if (!c->epoch) c->epoch = 1u;
     fa.epoch = c->epoch;
-    fa.pl = pl; fa.ipc = ipc; fa.stash = w->stash;
+    fa.pl = pl; fa.ipc = ipc;
     const dim3 grid((unsigned)((long long)nfull * ipc)), block(64 * FUSED_WAVES);
     fa.e.ticket_base = w->tickets_drawn;
     if ((rc = prof_mark(c, s))) return rc;

@@ -350,10 +350,19 @@ class XgmiConnector(RemoteConnector):
         if state == _PENDING and roff == offset:
             struct.pack_into("<I", self._dir, off, _DEAD)
 
-    def _publish(self, slot: int, offset: int, nbytes: int, cap: int, gen: int) -> None:
+    def _publish(self, slot: int, offset: int, nbytes: int, cap: int, gen: int, key: str) -> bool:
+        """Make the extent visible -- if the slot is still this write's: a pending reservation of exactly this extent,
+        or the key's own published record (an overwrite).  A slow writer whose reservation was taken over after
+        _PENDING_TIMEOUT_S, retired and re-used for ANOTHER key must not stamp its extent over that key's record
+        (ADVICE r04): its write is dropped (the bytes stay unreferenced in the arena).  Caller holds the lock."""
         off = self._rec_off(slot)
-        _, owner, _, _, _, klen, _ = _REC.unpack_from(self._dir, off)
+        state, owner, roff, _, _, klen, _ = _REC.unpack_from(self._dir, off)
+        kb = key.encode("utf-8")
+        same_key = klen == len(kb) and self._dir[off + _REC.size:off + _REC.size + klen] == kb
+        if not same_key or not ((state == _PENDING and roff == offset) or state == _FULL):
+            return False
         _REC.pack_into(self._dir, off, _FULL, owner, offset, nbytes, cap, klen, gen & 0xffffffff)
+        return True
 
     def _lookup(self, key: str) -> Optional[tuple]:
         with self._locked():
@@ -457,7 +466,7 @@ class XgmiConnector(RemoteConnector):
                 self._abandon(slot, offset)  # the key is not left "being written" for ever
             raise
         with self._locked():
-            self._publish(slot, offset, n, cap, gen)
+            self._publish(slot, offset, n, cap, gen, key)
 
     def get_device(self, key: str) -> Optional[torch.Tensor]:
         """The blob as a uint8 tensor on THIS rank's device: a view of the own arena, or a copy out of the

@@ -235,7 +235,17 @@ class LMCLocalBackend(LMCBackendInterface):
         if blocking:
             self._put_chunk_now(key, kv_chunk, fmt)
         else:
-            self.put_queue.put(lambda: self._put_chunk_now(key, kv_chunk, fmt))
+            # the worker thread queues its work on ITS current stream: order it behind the stream that produced the chunk
+            ready = None
+            if kv_chunk.is_cuda:
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(kv_chunk.device))
+
+            def queued():
+                if ready is not None:
+                    torch.cuda.current_stream(kv_chunk.device).wait_event(ready)
+                self._put_chunk_now(key, kv_chunk, fmt)
+            self.put_queue.put(queued)
 
     @_lmcache_nvtx_annotate
     def get(self, key: CacheEngineKey) -> Optional[torch.Tensor]:
@@ -502,6 +512,7 @@ class LMCLocalDiskBackend(LMCBackendInterface):
         self._staging = None                   # PinnedArena, created on first encoded put
         self._read_buf: Optional[native.PinnedBuffer] = None
         self.dst_device = "cuda"
+        self._cuda_device = torch.cuda.current_device() if torch.cuda.is_available() else None
         self.put_queue: "queue.Queue" = queue.Queue()
         self.put_thread: Optional[threading.Thread] = threading.Thread(target=self.put_worker, daemon=True)
         self.put_thread.start()
@@ -514,15 +525,23 @@ class LMCLocalDiskBackend(LMCBackendInterface):
         return self.path + key.to_string().replace("/", "-") + (".lmc" if self.encoded else ".pt")
 
     def put_worker(self):
-        stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        # the worker's own stream on the ENGINE's device (a thread starts on device 0), ordered behind whatever produced
+        # each chunk: put() records an event on the caller's stream -- the engine fills the chunk with copy_kv on that
+        # stream and returns at once -- and the queued put waits for it before it reads the tensor
+        stream = None
+        if self._cuda_device is not None:
+            torch.cuda.set_device(self._cuda_device)
+            stream = torch.cuda.Stream()
         while True:
             item = self.put_queue.get()
             if isinstance(item, LocalBackendEndSignal):
                 break
-            key, value = item
+            key, value, ready = item
             try:
                 if stream is not None:
                     with torch.cuda.stream(stream):
+                        if ready is not None:
+                            stream.wait_event(ready)
                         self.put_blocking(key, value)
                 else:
                     self.put_blocking(key, value)
@@ -571,7 +590,11 @@ class LMCLocalDiskBackend(LMCBackendInterface):
         if blocking:
             self.put_blocking(key, kv_chunk)
         else:
-            self.put_queue.put((key, kv_chunk))
+            ready = None
+            if kv_chunk.is_cuda:
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(kv_chunk.device))
+            self.put_queue.put((key, kv_chunk, ready))
 
     @_lmcache_nvtx_annotate
     def get(self, key: CacheEngineKey) -> Optional[torch.Tensor]:

@@ -186,14 +186,20 @@ def set_threads(n: int) -> int:
     return int(lib().lmco_set_threads(n))
 
 
+_par_out = None  # the output arena of encode_blobs_parallel, kept between calls (a fresh np.empty of n x 18 MB is page-faulted by the workers every time)
+
+
 def encode_blobs_parallel(kv_bits: np.ndarray, dtype: int, H: int, D: int, bins: np.ndarray, n: int) -> List[int]:
     """The same chunk n times, one chunk per OpenMP thread (OMP_NUM_THREADS): the CPU baseline's timed call.
     Returns the blob sizes."""
+    global _par_out
     L, two, T, C = kv_bits.shape
     assert two == 2 and C == H * D
     bins = np.ascontiguousarray(bins, dtype=np.int32)
     stride = (blob_bound(L, T, H, D) + 63) & ~63
-    blobs = np.empty(n * stride, np.uint8)
+    if _par_out is None or _par_out.size < n * stride:
+        _par_out = np.empty(n * stride, np.uint8)
+    blobs = _par_out
     sizes = np.zeros(n, np.uint64)
     rc = lib().lmco_encode_blobs_parallel(_p(np.ascontiguousarray(kv_bits)), 0, dtype, L, T, H, D, _p(bins), n, _p(blobs),
                                           stride, _p(sizes))

@@ -678,11 +678,12 @@ FUSED_SHAPES = [
     (3, 256, 256, 1, 64, torch.float16, "outlier"),   # C = 64: one group stream per plane, 6 planes in one item
     (5, 512, 256, 2, 128, torch.bfloat16, "rand"),    # C = 256: items of 4, 4 and 2 planes
     (2, 256, 256, 1, 200, torch.bfloat16, "randn"),   # C = 200: the 32-lane task with a partial last group
-    # wide planes: 2 / 4 waves per row oct, 4 / 8 streams per wave through the stash
+    # planes of more than LMC_FUSED_MAX_CHANNELS = 1024 channels: two kernels whatever the setting (the fused form built
+    # for them in round 4 was removed in round 5) -- the wide k_quantize variants (2 / 4 waves per row oct) run here
     (1, 512, 256, 32, 128, torch.float16, "rand"),    # C = 4096 (BASELINE configs[0])
     (2, 256, 256, 16, 128, torch.bfloat16, "randn"),  # C = 2048
     (1, 256, 256, 25, 128, torch.bfloat16, "outlier"),# C = 3200: partial channel runs in the last wave of a row
-    (1, 256, 256, 9, 136, torch.bfloat16, "randn"),   # C = 1224: SPLIT = 2 with an almost empty second slice
+    (1, 256, 256, 9, 136, torch.bfloat16, "randn"),   # C = 1224: an almost empty second slice
     (2, 236, 236, 8, 128, torch.float16, "outlier"),  # tests/test_serde.py:87-107 chunk length: not a fused geometry
     (1, 300, 300, 8, 128, torch.bfloat16, "randn"),   # T > 256 in one chunk (two-byte counts): not a fused geometry
     (2, 9, 4, 3, 128, torch.bfloat16, "randn"),       # chunks shorter than a row oct: not a fused geometry

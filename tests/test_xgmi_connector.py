@@ -143,6 +143,38 @@ def test_failed_and_abandoned_writes_do_not_wedge_a_key():
         conn.unlink()
 
 
+def test_a_late_publish_never_lands_on_another_keys_record():
+    """a slow writer whose pending slot was taken over, retired and re-used for another key must not
+    publish its extent over that key's record."""
+    import struct
+    from lmcache_amd.storage_backend.connector import xgmi_connector as xc
+    os.environ["LMC_XGMI_ARENA_MB"] = "2"
+    conn = xc.XgmiConnector(_name("late"), 1, device="cpu", nslots=64)
+    try:
+        with conn._locked():
+            owner, offset, slot, gen, cap = conn._reserve("slow", 64)   # the slow writer reserves ...
+            conn._abandon(slot, offset)                                   # ... is given up on (as a take-over + failure would)
+        # the retired slot goes to another key if that key probes over it: force it by writing the record by hand
+        conn.set("other", b"o" * 32)
+        oslot = conn._find("other")[1]
+        with conn._locked():
+            rec_other = bytes(conn._dir[conn._rec_off(oslot):conn._rec_off(oslot) + xc._REC.size + 5])
+            # the slow writer wakes up and publishes with ITS slot number, which now holds `other`
+            assert conn._publish(oslot, offset, 64, cap, gen, "slow") is False
+            assert bytes(conn._dir[conn._rec_off(oslot):conn._rec_off(oslot) + xc._REC.size + 5]) == rec_other
+            # its own retired slot: not a pending reservation of this extent any more -> dropped as well
+            assert conn._publish(slot, offset, 64, cap, gen, "slow") is False
+        assert conn.get("other") == b"o" * 32 and not conn.exists("slow")
+        # the normal path still publishes: pending reservation of exactly this extent, and an overwrite of a published key
+        conn.set("slow", b"s" * 64)
+        assert conn.get("slow") == b"s" * 64
+        conn.set("slow", b"t" * 65)
+        assert conn.get("slow") == b"t" * 65
+    finally:
+        conn.close()
+        conn.unlink()
+
+
 def test_no_pickle_in_the_connectors():
     """Peers exchange fixed-layout binary records (directory, arena exports, SPMD exchange): nothing in the connector
     package unpickles bytes another process wrote."""
