@@ -78,17 +78,22 @@
  *       start = cdf[s], freq = cdf[s+1] - cdf[s], total 2^16, state in
  *       [2^16, 2^32):   emit while x >= freq << 16;
  *       x = (x / freq << 16) + x % freq + start.
- *   LMC_MODEL_COUNTS (1) T == 256 (the reference's chunk size).  The counts
- *       themselves: a channel's 256 symbols give counts that sum to 2^8, so
- *       freq = 2 * count, start = 2 * (number of smaller symbols), total 2^9
+ *   LMC_MODEL_COUNTS (1) 2 <= T <= 256 (every chunk of the reference's chunk size 256 and below, a ragged last
+ *       chunk included; round 5 -- rounds 3-4 coded T == 256 only this way and every other length on CDF16).
+ *       MODEL counts n[s] that sum to 2^8 (lmc_counts_model): for T == 256 the channel's symbol counts themselves;
+ *       for T < 256 the counts scaled by 256 / T with the rounding carried along the cumulative sum,
+ *       n[s] = floor(256 C_s / T) - floor(256 C_(s-1) / T), C_s = number of tokens with a symbol <= s -- every
+ *       occurring symbol keeps n >= its count >= 1, absent symbols keep 0.  Then
+ *       freq = 2 * n, start = 2 * (sum of n below), total 2^9
  *       (the factor 2 keeps every frequency >= 2, which lets the encoder divide
  *       with one multiply-high by a 32-bit reciprocal: lmc_rans_magic), state in
  *       [2^15, 2^31):  emit while x >= freq << 22;
  *       x = (x / freq << 9) + x % freq + start.
- *       A channel whose 256 symbols are all equal would need count 256: it is
- *       coded with count 255 and a count of 1 for symbol 0 (for symbol 1 if the
+ *       A channel whose symbols are all equal would need n = 256: it is
+ *       coded with 255 and a count of 1 for symbol 0 (for symbol 1 if the
  *       channel's own symbol is 0) -- lmc_counts_model.  The code length is the
- *       channel's empirical entropy to within the 31 bits of final state.
+ *       channel's empirical entropy to within the 31 bits of final state (T < 256: plus the
+ *       rounding of the scaled counts, < 0.5 % on 236-token chunks).
  * See DESIGN.md "Entropy coder" for the recurrences and their bounds.
  */
 #ifndef LMC_FORMAT_H
@@ -115,7 +120,8 @@ extern "C" {
 
 #define LMC_MODEL_CDF16 0u
 #define LMC_MODEL_COUNTS 1u
-#define LMC_COUNTS_T 256u          /* chunk length the counts model codes */
+#define LMC_COUNTS_T 256u          /* longest chunk the counts model codes (its probabilities are out of 2^8) ... */
+#define LMC_COUNTS_T_MIN 2u        /* ... and the shortest (T = 1 has no 32-bit reciprocal; it stays on CDF16) */
 #define LMC_COUNTS_BITS 9u         /* its probabilities are 2 * count out of 2^9 */
 #define LMC_COUNTS_L (1u << 15)    /* ... and its state lives in [2^15, 2^31) */
 #define LMC_CDF_SCALE (65536u - (LMC_LP - 1u)) /* 2^16 - (Lp-1), cachegen_encoder.py:117-119 */
@@ -165,15 +171,28 @@ static inline uint32_t lmc_head_bytes(uint32_t R, uint32_t W) { return lmc_r16((
 static inline uint32_t lmc_head_cap_bytes(uint32_t T) { return lmc_head_bytes(31u, 31u * lmc_bit_width(lmc_stored_count(T, T))); }
 
 /* The coder model of a chunk of T tokens. */
-static inline uint32_t lmc_model_for(uint32_t T) { return T == LMC_COUNTS_T ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16; }
+static inline uint32_t lmc_model_for(uint32_t T) { return (T >= LMC_COUNTS_T_MIN && T <= LMC_COUNTS_T) ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16; }
 
-/* LMC_MODEL_COUNTS: the counts the coder runs on, from a channel's exact counts cnt[0 .. R) (sum 256, R >= 2):
- * themselves, except that a count of 256 becomes 255 and symbol 0 (symbol 1 if the channel's only symbol is 0)
- * gets 1.  freq[s] = 2 * c[s], start[s] = 2 * sum of c below s. */
-static inline void lmc_counts_model(const uint32_t* cnt, uint32_t R, uint32_t* c) {
-  for (uint32_t s = 0; s < R; s++) c[s] = cnt[s];
+/* floor(256 * x / T) for x <= T <= 256 the way the kernels compute it: one multiply-high by ceil(2^32 / T).  Exact: the
+ * estimate exceeds 256 x / T by 256 x e / (T 2^32) with e = ceil(2^32 / T) T - 2^32 < T, i.e. by less than 2^-16 < 1 / T. */
+static inline uint32_t lmc_counts_scale_magic(uint32_t T) { return (uint32_t)((0x100000000ull + T - 1u) / T); }  /* T >= 2 */
+static inline uint32_t lmc_counts_scaled(uint32_t x, uint32_t magic) { return (uint32_t)(((uint64_t)(x << 8) * magic) >> 32); }
+
+/* LMC_MODEL_COUNTS: the counts the coder runs on, from a channel's exact counts cnt[0 .. R) (sum T, 2 <= T <= 256,
+ * R >= 2): n[s] = floor(256 C_s / T) - floor(256 C_(s-1) / T) over the cumulative counts C (T == 256: cnt itself);
+ * then a count of 256 becomes 255 and symbol 0 (symbol 1 if the channel's only symbol is 0) gets 1.
+ * freq[s] = 2 * c[s], start[s] = 2 * sum of c below s. */
+static inline void lmc_counts_model(const uint32_t* cnt, uint32_t R, uint32_t T, uint32_t* c) {
+  const uint32_t magic = lmc_counts_scale_magic(T);
+  uint32_t cum = 0, prev = 0;
+  for (uint32_t s = 0; s < R; s++) {
+    cum += cnt[s];
+    const uint32_t now = T == LMC_COUNTS_T ? cum : lmc_counts_scaled(cum, magic);
+    c[s] = now - prev;
+    prev = now;
+  }
   for (uint32_t s = 0; s < R; s++)
-    if (cnt[s] >= LMC_COUNTS_T) { c[s] = LMC_COUNTS_T - 1u; c[s == 0u ? 1u : 0u] = 1u; break; }
+    if (c[s] >= LMC_COUNTS_T) { c[s] = LMC_COUNTS_T - 1u; c[s == 0u ? 1u : 0u] = 1u; break; }
 }
 
 /* Reciprocal of the frequency f = 2 * count (count 1 .. 255) for the counts model's encoder:
@@ -217,6 +236,32 @@ static inline void lmc_rans_magic(uint32_t count, uint32_t* magic, uint32_t* shi
   11861, 11549, 11235, 10919, 10602, 10283, 9963, 9641, 9318, 8993, 8666, 8338, 8009, 7678, 7345, 7011, 6676, \
   6339, 6000, 5660, 5319, 4976, 4631, 4286, 3938, 3590, 3239, 2888, 2535, 2180, 1825, 0
 static const uint16_t lmc_counts_bits[257] = {LMC_COUNTS_BITS_LIST};
+
+/* T < 256: a symbol with model count n occurs cnt <= n times, and each occurrence costs the bracket above with c = n:
+ * lmc_counts_bpo[n] = ceil(256 (log2(256 / n) + log2(1 + 2 n / 2^15))) + 1 (units of 2^-8 bit per OCCURRENCE), and
+ * S = sum over the symbols of cnt[s] * lmc_counts_bpo[n[s]].  (T == 256 keeps lmc_counts_bits -- per symbol, rounded once
+ * -- so that its blobs are byte for byte those of rounds 3-4.) */
+#define LMC_COUNTS_BPO_LIST \
+  0, 2050, 1794, 1644, 1538, 1455, 1388, 1331, 1282, 1238, 1199, 1164, 1132, 1102, 1075, 1050, 1026, 1003, 982, \
+  962, 944, 926, 908, 892, 876, 861, 847, 833, 819, 807, 794, 782, 770, 759, 748, 737, 727, 717, 707, 697, 688, \
+  679, 670, 661, 653, 645, 637, 629, 621, 613, 606, 599, 591, 584, 577, 571, 564, 558, 551, 545, 539, 533, 527, \
+  521, 515, 509, 504, 498, 493, 487, 482, 477, 472, 467, 462, 457, 452, 447, 442, 438, 433, 428, 424, 419, 415, \
+  411, 406, 402, 398, 394, 390, 386, 382, 378, 374, 370, 366, 362, 358, 355, 351, 347, 344, 340, 337, 333, 330, \
+  326, 323, 319, 316, 313, 309, 306, 303, 300, 296, 293, 290, 287, 284, 281, 278, 275, 272, 269, 266, 263, 260, \
+  258, 255, 252, 249, 246, 244, 241, 238, 235, 233, 230, 228, 225, 222, 220, 217, 215, 212, 210, 207, 205, 202, \
+  200, 197, 195, 193, 190, 188, 186, 183, 181, 179, 176, 174, 172, 170, 167, 165, 163, 161, 159, 157, 154, 152, \
+  150, 148, 146, 144, 142, 140, 138, 136, 134, 132, 130, 128, 126, 124, 122, 120, 118, 116, 114, 112, 110, 108, \
+  106, 105, 103, 101, 99, 97, 95, 94, 92, 90, 88, 86, 85, 83, 81, 79, 78, 76, 74, 72, 71, 69, 67, 66, 64, 62, 61, \
+  59, 57, 56, 54, 53, 51, 49, 48, 46, 45, 43, 41, 40, 38, 37, 35, 34, 32, 31, 29, 28, 26, 25, 23, 22, 20, 19, 17, \
+  16, 14, 13, 12, 10, 9, 0
+static const uint16_t lmc_counts_bpo[257] = {LMC_COUNTS_BPO_LIST};
+
+/* S of one channel: exact counts cnt, model counts n (lmc_counts_model), chunk length T. */
+static inline uint32_t lmc_counts_lane_S(const uint32_t* cnt, const uint32_t* n, uint32_t R, uint32_t T) {
+  uint32_t S = 0;
+  for (uint32_t s = 0; s < R; s++) S += T == LMC_COUNTS_T ? lmc_counts_bits[n[s]] : cnt[s] * lmc_counts_bpo[n[s]];
+  return S;
+}
 
 /* Upper bound of the 16-bit words one lane emits, from S = sum over the symbols of lmc_counts_bits[model count]. */
 static inline uint32_t lmc_counts_lane_words(uint32_t S) { return (S + 6u * ((S >> 12) + 2u)) >> 12; }

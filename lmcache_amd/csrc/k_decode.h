@@ -91,10 +91,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   auto hdw = [&](int i) { return (u32)__builtin_amdgcn_readfirstlane((int)hd[i]); };
   const u32 T = hdw(4);
   const u32 src_dtype = hdw(2);
-  const bool counts_model = hdw(22) == LMC_MODEL_COUNTS;  // wave-uniform: the coder ran on the symbol counts (T == 256)
+  const bool counts_model = hdw(22) == LMC_MODEL_COUNTS;  // wave-uniform: the coder ran on the symbol counts (2 <= T <= 256)
   const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.G);
   if (hdw(0) != LMC_BLOB_MAGIC || (hdw(1) & 0xffffu) != LMC_BLOB_VERSION || hdw(7) != (u32)a.C || T == 0u || T > 65535u ||
-      hdw(22) != (T == LMC_COUNTS_T ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16) ||
+      hdw(22) != lmc_model_for_dev(T) ||
       hdw(8) != (u32)a.P || hdw(15) != bo.streams ||
       // every section offset is a function of the fields checked above; the blob must also fit its slot
       (!SYMOUT && (T > (u32)a.chunk_tokens ||
@@ -161,6 +161,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
             else if ((hreg[i] >> 16) == 255u) hreg[i] += (deficit & 0xffffu) << 16;
           }
         }
+      }
+      if (counts_model && T != LMC_COUNTS_T) {
+        // chunks below 256 tokens (round 5): the MODEL counts are the counts scaled to a sum of 256 along the cumulative
+        // sum, n[s] = floor(256 C_s / T) - floor(256 C_(s-1) / T) (lmc_format.h: lmc_counts_model; the quotient by one
+        // multiply-high, exact for C <= T <= 256), and a channel with one symbol -- n = 256 -- becomes 255 + 1
+        const u32 magic = lmc_counts_scale_magic_dev(T);
+        u32 cum = 0, prev = 0, big = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          cum = min(cum + (hreg[i] & 0xffffu), T);  // (min: a damaged head cannot push a count past 256)
+          const u32 n0 = __umulhi(cum << 8, magic);
+          cum = min(cum + (hreg[i] >> 16), T);
+          const u32 n1 = __umulhi(cum << 8, magic);
+          hreg[i] = (n0 - prev) | ((n1 - n0) << 16);
+          prev = n1;
+          big |= hreg[i];
+        }
+        const bool first = (hreg[0] & 0xffffu) == 256u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) hreg[i] -= (hreg[i] >> 8) & 0x00010001u;  // 256 -> 255 (no other count has bit 8)
+        if (big & 0x01000100u) hreg[0] += first ? 0x10000u : 1u;
       }
     }
     wave_lds_fence();  // the staging is dead (every lane holds its counts): the table takes its place

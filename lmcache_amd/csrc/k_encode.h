@@ -103,7 +103,7 @@ __device__ __forceinline__ void write_blob_static(u8* blob, const BlobOff& bo, c
       case 16: v = stream_bytes; break;
       case 17: v = bo.streams + stream_bytes; break;
       case 21: v = bo.scsum; break;
-      case 22: v = T == LMC_COUNTS_T ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16; break;  // lmc_model_for
+      case 22: v = lmc_model_for_dev(T); break;
       default: v = 0;
     }
     reinterpret_cast<u32*>(blob)[lane] = v;

@@ -1,5 +1,6 @@
-// k_encode_counts.h -- the group-stream coder under LMC_MODEL_COUNTS (include/lmc_format.h): chunks of exactly
-// 256 tokens, the reference's chunk size (lmcache/config.py: chunk_size 256).  Stands where
+// k_encode_counts.h -- the group-stream coder under LMC_MODEL_COUNTS (include/lmc_format.h): chunks of 2 .. 256 tokens
+// (256 is the reference's chunk size, lmcache/config.py: chunk_size 256; since round 5 shorter chunks -- a ragged last
+// chunk, chunk_size 128 -- are coded on the counts scaled to a sum of 256, lmc_counts_model).  Stands where
 // torchac_cuda.calculate_cdf + encode_fast_new stand (cachegen_encoder.py:241-262, 287-289); the counts it
 // stores are what the reference's CDF is a function of (lmc_calculate_cdf still exports that CDF).
 //
@@ -51,22 +52,27 @@ __device__ const RansRtab g_rans_rtab = make_rans_rtab();
 // lmc_counts_bits (lmc_format.h), the stream-length bound's table: read once per symbol and stream, from the
 // workgroup's LDS copy behind the reciprocals (u16 entries)
 #define BITS_DWORDS 132  // 257 u16, rounded up to 16 bytes
-#define RTAB_LDS_DWORDS (RTAB_DWORDS + BITS_DWORDS)
+// ... and lmc_counts_bpo behind it, the per-occurrence table of chunks below 256 tokens (round 5)
+#define RTAB_LDS_DWORDS (RTAB_DWORDS + 2 * BITS_DWORDS)
 struct CountsBits {
-  u32 v[BITS_DWORDS];
+  u32 v[2 * BITS_DWORDS];
 };
 constexpr CountsBits make_counts_bits() {
   constexpr u16 t[257] = {LMC_COUNTS_BITS_LIST};
+  constexpr u16 o[257] = {LMC_COUNTS_BPO_LIST};
   CountsBits r{};
   for (int i = 0; i < 257; i++) r.v[i >> 1] |= (u32)t[i] << (16 * (i & 1));
+  for (int i = 0; i < 257; i++) r.v[BITS_DWORDS + (i >> 1)] |= (u32)o[i] << (16 * (i & 1));
   return r;
 }
 __device__ const CountsBits g_counts_bits = make_counts_bits();
+// the counts coder's staging buffer per wave: 128 + 2 x 64 words (counts_code_stream)
+#define CNT_RING_DWORDS 128
 
 // every thread of the workgroup takes part; the caller synchronises before the first use
 __device__ __forceinline__ void rtab_to_lds(u32* rtab_lds) {
   for (u32 i = threadIdx.x; i < RTAB_DWORDS; i += blockDim.x) rtab_lds[i] = g_rans_rtab.v[i];
-  for (u32 i = threadIdx.x; i < BITS_DWORDS; i += blockDim.x) rtab_lds[RTAB_DWORDS + i] = g_counts_bits.v[i];
+  for (u32 i = threadIdx.x; i < 2 * BITS_DWORDS; i += blockDim.x) rtab_lds[RTAB_DWORDS + i] = g_counts_bits.v[i];
 }
 
 // the coding pass reads a symbol dword for the last time: the load says so (non-temporal), so that what is touched
@@ -117,9 +123,10 @@ __device__ __forceinline__ u32 row_addr_cnt(const u32* w, u32 base) {
 }
 
 
-// One group stream of a 256-token chunk, as its wave sees it.
+// One group stream of a chunk of T <= 256 tokens, as its wave sees it.
 struct CountsStream {
   int chunk, p, g, c;
+  int T;             // tokens of the chunk (wave-uniform; a ragged last chunk has fewer than a.chunk_tokens)
   bool active, nib;  // nib is wave-uniform
   const u32* symq;   // this lane's column of the plane-chunk's symbol workspace
   u32 R;             // symbols the plane's quantiser can emit
@@ -131,6 +138,7 @@ __device__ __forceinline__ CountsStream counts_stream_of(const EncodeArgs& a, in
   s.p = p;
   s.chunk = chunk;
   s.c = s.g * 64 + lane;
+  s.T = min(a.chunk_tokens, a.tok_end - (a.tok_begin + chunk * a.chunk_tokens));
   s.active = s.c < a.C;
   s.symq = a.sym4 + ((long long)s.chunk * a.P + s.p) * a.sym_stride + s.c;
   s.nib = lmc_sym_nibbles((int)a.bins.b[s.p]);
@@ -169,15 +177,36 @@ LMC_SDWA_BYTE_OP(sdwa_byte_or, "v_or_b32_sdwa")        // a | byte K of b
 // Packed as the stored counts are: mp[k] = four model counts (the fix-ups touch symbols 0 and 1 only, and neither
 // carries out of its byte: a count that grows was 0).
 template <int NS>
-__device__ __forceinline__ void counts_model_pk(const u32 (&pk)[8], bool active, u32 (&mp)[NS / 4]) {
-  u32 sum = 0;
+__device__ __forceinline__ void counts_model_pk(const u32 (&pk)[8], bool active, u32 T, u32 (&mp)[NS / 4]) {
+  if (T == LMC_COUNTS_T) {  // (wave-uniform)
+    u32 sum = 0;
 #pragma unroll
-  for (int k = 0; k < NS / 4; k++) sum = __builtin_amdgcn_sad_u8(pk[k], 0u, sum);
-  const u32 deficit = LMC_COUNTS_T - sum;  // 0, or 1 for a constant channel (256 for a lane without a channel)
-  const bool first = (pk[0] & 0xffu) == 255u;
+    for (int k = 0; k < NS / 4; k++) sum = __builtin_amdgcn_sad_u8(pk[k], 0u, sum);
+    const u32 deficit = LMC_COUNTS_T - sum;  // 0, or 1 for a constant channel (256 for a lane without a channel)
+    const bool first = (pk[0] & 0xffu) == 255u;
 #pragma unroll
-  for (int k = 0; k < NS / 4; k++) mp[k] = pk[k];
-  mp[0] += first ? deficit << 8 : deficit;
+    for (int k = 0; k < NS / 4; k++) mp[k] = pk[k];
+    mp[0] += first ? deficit << 8 : deficit;
+  } else {
+    // chunks below 256 tokens (round 5): the counts scaled to a sum of 256 along the cumulative sum,
+    // n[s] = floor(256 C_s / T) - floor(256 C_(s-1) / T) (lmc_format.h: lmc_counts_model; one multiply-high per symbol,
+    // exact for C <= T <= 256); a channel with a single symbol comes out at 256: 255, and a count of 1 on symbol 0 / 1.
+    // Per stream, not per token: plain code.
+    const u32 magic = lmc_counts_scale_magic_dev(T);
+    u32 cum = 0, prev = 0, big = 0, first = 0;
+#pragma unroll
+    for (int k = 0; k < NS / 4; k++) mp[k] = 0;
+    static_for<NS>([&](auto itag) {
+      constexpr int i = decltype(itag)::value;
+      cum += (pk[i >> 2] >> (8 * (i & 3))) & 0xffu;
+      const u32 now = __umulhi(cum << 8, magic);
+      u32 n = now - prev;
+      prev = now;
+      if (n >= LMC_COUNTS_T) { big = 1u; first = i == 0 ? 1u : 0u; n = LMC_COUNTS_T - 1u; }
+      mp[i >> 2] |= n << (8 * (i & 3));
+    });
+    if (big) mp[0] += first ? 1u << 8 : 1u;
+  }
   if (!active) mp[0] = 0x01ffu;  // (its stored counts are all 0)
 }
 // The table of a <= 16-symbol plane from this lane's MODEL counts: entry = count << 23 | 2 * (symbols below) -- the
@@ -214,25 +243,27 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
                                                   int lane, CountsState& cs) {
   typedef __attribute__((address_space(3))) u32* lds_u32w;
   typedef const __attribute__((address_space(3))) u16* lds_u16p;
-  constexpr int Tc = (int)LMC_COUNTS_T;
+  const int Tc = __builtin_amdgcn_readfirstlane(s.T);  // 2 .. 256, wave-uniform (said so: the loops below run on scalar counters)
   const u32 tab_addr = (u32)(size_t)(lds_u32w)tabmem;
   if (ALIGNED && (tab_addr & 0xfffu)) __builtin_trap();  // (wave-uniform: the layout is static)
   u16* const tab16 = reinterpret_cast<u16*>(tabmem);
   auto pass1 = [&](auto nib_tag) {
     constexpr bool NIB = decltype(nib_tag)::value;
     constexpr int DPB = NIB ? 4 : 8;  // dwords per 32-token block
-    constexpr int NB = Tc / 32;
+    const int NB = Tc >> 5, rem = Tc & 31;                    // whole 32-token blocks, tokens of the last partial one
+    const int rows = NIB ? (Tc + 7) >> 3 : (Tc + 3) >> 2;     // workspace dwords of the lane's column that hold tokens
 #pragma unroll
     for (int i = 0; i < 16; i++) tabmem[i * 64 + lane] = 0;
     const u32 col = NIB ? tab_addr + 4u * (u32)lane : tab_addr + 4u * (u32)(lane >> 1);
     const u32 one = NIB ? 1u : 1u << ((lane & 1) * 16);
     u32 w[DPB], wn[DPB];
 #pragma unroll
-    for (int j = 0; j < DPB; j++) w[j] = s.active ? s.symq[(long long)j * a.C] : 0u;
+    for (int j = 0; j < DPB; j++) w[j] = (s.active && j < rows) ? s.symq[(long long)j * a.C] : 0u;
     for (int b = 0; b < NB; b++) {
-      if (b + 1 < NB) {
+      if (b + 1 < NB || rem) {
 #pragma unroll
-        for (int j = 0; j < DPB; j++) wn[j] = s.active ? s.symq[(long long)((b + 1) * DPB + j) * a.C] : 0u;
+        for (int j = 0; j < DPB; j++)
+          wn[j] = (s.active && (b + 1) * DPB + j < rows) ? s.symq[(long long)((b + 1) * DPB + j) * a.C] : 0u;
       }
       static_for<32>([&](auto itag) {
         constexpr int i = decltype(itag)::value;
@@ -242,13 +273,24 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
 #pragma unroll
       for (int j = 0; j < DPB; j++) w[j] = wn[j];
     }
+    // the partial block of a chunk whose length is no multiple of 32 (a ragged last chunk, chunk_size 236 ...): a plain
+    // loop, the token's dword picked by wave-uniform selects
+    for (int i = 0; i < rem; i++) {
+      const int j = NIB ? i >> 3 : i >> 2;
+      u32 wd = w[0];
+#pragma unroll
+      for (int k = 1; k < DPB; k++) wd = j == k ? w[k] : wd;
+      const u32 sym = NIB ? (wd >> (8 * (i & 3) + 4 * ((i >> 2) & 1))) & 15u : (wd >> (8 * (i & 3))) & 0xffu;
+      const u32 ad = col + (sym << (NIB ? 8 : 7));
+      __hip_atomic_fetch_add((lds_u32w)(size_t)ad, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
   };
   if (s.nib) pass1(BoolTag<true>{});
   else pass1(BoolTag<false>{});
   wave_lds_fence();  // every lane's ds_add has landed
 
   if (s.g == 0) {  // one wave per (chunk, plane): checksum of the plane's scales (written by the quantise stage)
-    const BlobOff bo = lmc_blob_off((u32)a.P, LMC_COUNTS_T, (u32)a.G);
+    const BlobOff bo = lmc_blob_off((u32)a.P, (u32)Tc, (u32)a.G);
     u8* const blob0 = a.blobs + (long long)s.chunk * a.blob_stride;
     const u32 sum = scale_checksum(reinterpret_cast<const u16*>(blob0 + bo.scales) + (long long)s.p * Tc, (u32)Tc, lane);
     if (lane == 0) reinterpret_cast<u32*>(blob0 + bo.scsum)[s.p] = sum;
@@ -301,8 +343,30 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
     const u32 bits_of_1 = (u32) * (lds_u16p)(size_t)(bits_addr + 2u);
     S += sum == LMC_COUNTS_T - 1u ? bits_of_1 : 0u;
   };
-  if (s.nib) bound(IntTag<16>{});
-  else bound(IntTag<32>{});
+  // chunks below 256 tokens: S = sum of count * lmc_counts_bpo[model count] (lmc_format.h), the model counts worked out
+  // as counts_model_pk does
+  auto bound_T = [&](auto ns_tag) {
+    constexpr int NS = decltype(ns_tag)::value;
+    const u32 magic = lmc_counts_scale_magic_dev((u32)Tc);
+    const u32 bpo_addr = bits_addr + 4u * BITS_DWORDS;
+    u32 cum = 0, prev = 0;
+    static_for<NS>([&](auto itag) {
+      constexpr int i = decltype(itag)::value;
+      const u32 c = (cs.pk[i >> 2] >> (8 * (i & 3))) & 0xffu;
+      cum += c;
+      const u32 now = __umulhi(cum << 8, magic);
+      const u32 n = min(now - prev, LMC_COUNTS_T - 1u);
+      prev = now;
+      S += c * (u32) * (lds_u16p)(size_t)(bpo_addr + 2u * n);
+    });
+  };
+  if (Tc == (int)LMC_COUNTS_T) {
+    if (s.nib) bound(IntTag<16>{});
+    else bound(IntTag<32>{});
+  } else {
+    if (s.nib) bound_T(IntTag<16>{});
+    else bound_T(IntTag<32>{});
+  }
   const u32 lw = s.active ? (S + 6u * ((S >> 12) + 2u)) >> 12 : 0u;  // lmc_counts_lane_words
   const u32 words = (u32)__builtin_amdgcn_readfirstlane((int)wave_sum_u32(lw));
   return (cs.head + 2u * (words + 128u) + 15u) & ~15u;  // lmc_counts_alloc_bytes
@@ -315,11 +379,11 @@ __device__ __forceinline__ void counts_open_stream(const CountsStream& s, const 
   wave_lds_fence();
   if (s.nib) {
     u32 mp[4];
-    counts_model_pk<16>(cs.pk, s.active, mp);
+    counts_model_pk<16>(cs.pk, s.active, (u32)s.T, mp);
     counts_table_nib_pk(mp, tabmem, lane);
   } else {
     u32 mp[8];
-    counts_model_pk<32>(cs.pk, s.active, mp);
+    counts_model_pk<32>(cs.pk, s.active, (u32)s.T, mp);
     counts_table_byte_pk(mp, reinterpret_cast<u16*>(tabmem), lane);
   }
   wave_lds_fence();
@@ -338,7 +402,7 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
                                                   const u32* rtab, int lane, u16* const out_v) {
   typedef __attribute__((address_space(3))) u32* lds_u32w;
   typedef __attribute__((address_space(3))) u16* lds_u16w;
-  constexpr int Tc = (int)LMC_COUNTS_T;
+  const int Tc = __builtin_amdgcn_readfirstlane(s.T);  // 2 .. 256, wave-uniform (said so: the loops below run on scalar counters)
   const u32 tab_addr = (u32)(size_t)(lds_u32w)tabmem;
   if (NT && (tab_addr & 0xfffu)) __builtin_trap();  // (wave-uniform: the layout is static)
   const u32 rtab_addr = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(lds_u32w) const_cast<u32*>(rtab));
@@ -351,7 +415,7 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
   // scalar instruction -- and every SECOND token one compare asks whether the first 128 words are complete.  If so
   // they leave with one coalesced 256-byte store, the < 128 words behind them move down to the buffer's start and
   // wb steps back by 256 bytes.  Two steps add at most 128 words to fewer than 128: 256 words = 512 B of the wave's
-  // ENC_RING_DWORDS.  What this removes from every token step: s_sub / s_cmpk / a TAKEN s_cbranch (now every second
+  // CNT_RING_DWORDS.  What this removes from every token step: s_sub / s_cmpk / a TAKEN s_cbranch (now every second
   // step), s_lshl / s_and / s_add of the cursor -- 3.3 + 0.9 ns of the step's 24.2 in the issue-slot replica
   // (tools/probes/issue_model.py, profiles/r05_issue_model.md).
   u32 wb = ring_addr;
@@ -404,7 +468,8 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
   auto pass2 = [&](auto nib_tag) {
     constexpr bool NIB = decltype(nib_tag)::value;
     constexpr int DPB = NIB ? 4 : 8;
-    constexpr int NB = Tc / 32;
+    const int NB = Tc >> 5, rem = Tc & 31;                 // whole 32-token blocks; tokens of the partial block behind them
+    const int rows = NIB ? (Tc + 7) >> 3 : (Tc + 3) >> 2;  // workspace dwords of the lane's column that hold tokens
     const u32 col = NIB ? tab_addr + 4u * (u32)lane : tab_addr + 2u * (u32)lane;  // LDS address of tab[0][lane]
     // A byte plane's 16-bit entries travel as _Float16: the blocks below only ever take them apart by SDWA byte
     // selects, so the register's upper half does not matter -- but an integer of 16 bits that lives across the
@@ -420,9 +485,69 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
       else ra = ((u32)__builtin_bit_cast(u16, e) & 0xffu) << 3;
       return *(const __attribute__((address_space(3))) u32x2_t*)(size_t)(rtab_addr + ra);
     };
+    // the word append of one step: under exec = emitting lanes -- v_cmpx on the state's upper half against the entry's
+    // (count << 7), mbcnt rank, ds_write_b16 into the staging buffer, x >>= 16, exec restored; also works out the
+    // address of the reciprocal of entry e2 (the main loop's pipeline) and returns the number of words
+    auto emit = [&](ET e0, ET e2, u32& ra) -> u32 {
+      u32 tt, cnt;
+      if constexpr (NIB) {
+        asm volatile("v_lshrrev_b32_e32 %[ra], 20, %[e2]\n\t"
+                     "v_cmpx_ge_u32_sdwa vcc, %[x], %[e0] src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                     "s_nop 0\n\t"
+                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                     "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
+                     "ds_write_b16 %[t], %[x]\n\t"
+                     "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                     "s_mov_b64 exec, %[full]"
+                     : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
+                     : [e0] "v"(e0), [e2] "v"(e2), [wb] "s"(wb), [full] "s"(full_exec)
+                     : "vcc", "scc", "memory");
+      } else {
+        asm volatile("v_lshlrev_b32_sdwa %[ra], 3, %[e2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                     "v_lshlrev_b32_sdwa %[t], 23, %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                     "v_cmpx_ge_u32_e32 vcc, %[x], %[t]\n\t"
+                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                     "s_nop 0\n\t"
+                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                     "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
+                     "ds_write_b16 %[t], %[x]\n\t"
+                     "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
+                     "s_mov_b64 exec, %[full]"
+                     : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
+                     : [e0] "v"(e0), [e2] "v"(e2), [wb] "s"(wb), [full] "s"(full_exec)
+                     : "vcc", "scc", "memory");
+      }
+      return cnt;
+    };
     u32 w[DPB], wn[DPB];
+    // the last whole block (the first one coded), and in wn the partial block behind it
 #pragma unroll
-    for (int j = 0; j < DPB; j++) w[j] = s.active ? LMC_SYM_LAST_LOAD(s.symq + (long long)((NB - 1) * DPB + j) * a.C) : 0u;
+    for (int j = 0; j < DPB; j++) {
+      w[j] = (NB > 0 && s.active) ? LMC_SYM_LAST_LOAD(s.symq + (long long)((NB - 1) * DPB + j) * a.C) : 0u;
+      wn[j] = (rem && s.active && NB * DPB + j < rows) ? LMC_SYM_LAST_LOAD(s.symq + (long long)(NB * DPB + j) * a.C) : 0u;
+    }
+    // ---- the partial block of a chunk whose length is no multiple of 32 (tokens Tc - 1 .. 32 NB; round 5): a plain
+    // loop -- the token's dword by wave-uniform selects, entry and reciprocal fetched where they are needed, the buffer
+    // tested after every token.  At most 31 of a chunk's tokens come through here.
+    for (int i = rem - 1; i >= 0; i--) {
+      const int j = NIB ? i >> 3 : i >> 2;
+      u32 wd = wn[0];
+#pragma unroll
+      for (int k = 1; k < DPB; k++) wd = j == k ? wn[k] : wd;
+      const u32 sym = NIB ? (wd >> (8 * (i & 3) + 4 * ((i >> 2) & 1))) & 15u : (wd >> (8 * (i & 3))) & 0xffu;
+      const ET E = entry_at(col + (sym << (NIB ? 8 : 7)));
+      const u32x2_t R = rtab_of(E);
+      u32 ra_unused;
+      const u32 cnt = emit(E, E, ra_unused);
+      asm("s_lshl1_add_u32 %0, %1, %0" : "+s"(wb) : "s"(cnt) : "scc");
+      flush_ring();
+      if constexpr (NIB) rans_put_nib(E, R.x, R.y);
+      else rans_put_byte(E, R.x, R.y);
+    }
+    if (NB == 0) return;
     // The table pipeline: the entry of a token is requested FOUR steps ahead, its reciprocal TWO (from an entry that
     // landed two steps earlier), so the wait in front of a step's block covers requests that are two steps old and
     // leaves the previous step's three LDS operations in flight.  The step's asm block works out the address of the
@@ -443,37 +568,8 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
         u32 ad4;  // row address of the token four further on (past the last block: row 0, read and never used)
         if constexpr (i >= 4) ad4 = row_addr_cnt<NIB, i - 4, NT>(w, col);
         else ad4 = row_addr_cnt<NIB, 28 + i, NT>(wn, col);
-        u32 tt, cnt, ra;
-        if constexpr (NIB) {
-          asm volatile("v_lshrrev_b32_e32 %[ra], 20, %[e2]\n\t"
-                       "v_cmpx_ge_u32_sdwa vcc, %[x], %[e0] src0_sel:WORD_1 src1_sel:WORD_1\n\t"
-                       "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                       "s_nop 0\n\t"
-                       "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                       "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                       "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
-                       "ds_write_b16 %[t], %[x]\n\t"
-                       "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                       "s_mov_b64 exec, %[full]"
-                       : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
-                       : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wb), [full] "s"(full_exec)
-                       : "vcc", "scc", "memory");
-        } else {
-          asm volatile("v_lshlrev_b32_sdwa %[ra], 3, %[e2] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-                       "v_lshlrev_b32_sdwa %[t], 23, %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
-                       "v_cmpx_ge_u32_e32 vcc, %[x], %[t]\n\t"
-                       "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                       "s_nop 0\n\t"
-                       "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-                       "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-                       "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
-                       "ds_write_b16 %[t], %[x]\n\t"
-                       "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
-                       "s_mov_b64 exec, %[full]"
-                       : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
-                       : [e0] "v"(E0), [e2] "v"(E2), [wb] "s"(wb), [full] "s"(full_exec)
-                       : "vcc", "scc", "memory");
-        }
+        u32 ra;
+        const u32 cnt = emit(E0, E2, ra);
         const u32x2_t R2 = *(const __attribute__((address_space(3))) u32x2_t*)(size_t)(rtab_addr + ra);
         const ET E4 = entry_at(ad4);
         asm("s_lshl1_add_u32 %0, %1, %0" : "+s"(wb) : "s"(cnt) : "scc");  // wb += 2 * cnt
@@ -522,7 +618,8 @@ template <bool QUADSYM, bool ENCODE, int NW = ENC_WAVES, bool COUNTS_ONLY = fals
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 8 : 4, 8))) void k_cdf_encode(EncodeArgs a) {
   static_assert(!COUNTS_ONLY || (QUADSYM && ENCODE), "the counts coder reads the workspace and places its streams");
   constexpr int TAB_DWORDS = COUNTS_ONLY ? CNT_TAB_DWORDS : ENC_TAB_DWORDS;
-  __shared__ __attribute__((aligned(4096))) u32 lds_all[NW * (TAB_DWORDS + ENC_RING_DWORDS)];  // the tables, then the staging rings (counts-only launch: 4 KiB slices at multiples of 4 KiB, row_addr_cnt ALIGNED)
+  constexpr int RING_DWORDS = COUNTS_ONLY ? CNT_RING_DWORDS : ENC_RING_DWORDS;  // (the CDF16 coder's ring is 256 + 64 words)
+  __shared__ __attribute__((aligned(4096))) u32 lds_all[NW * (TAB_DWORDS + RING_DWORDS)];  // the tables, then the staging rings (counts-only launch: 4 KiB slices at multiples of 4 KiB, row_addr_cnt ALIGNED)
   __shared__ __attribute__((aligned(16))) u32 rtab_lds[ENCODE ? RTAB_LDS_DWORDS : 4];     // counts model: reciprocals, bound table
   if (ENCODE && QUADSYM) {
     rtab_to_lds(rtab_lds);
@@ -558,7 +655,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
   const long long gid = (long long)chunk_i * npg + pg_i;
   if (gid >= ngroups_total) return;
   PendingTile t;
-  u16* const wring = reinterpret_cast<u16*>(lds_all + NW * TAB_DWORDS + wave * ENC_RING_DWORDS);
+  u16* const wring = reinterpret_cast<u16*>(lds_all + NW * TAB_DWORDS + wave * RING_DWORDS);
   u32 alloc = 0;  // the stream's allocation in the blob
   auto counts_stream = [&]() {
     const u32 p_i = pg_i / (u32)a.G;
@@ -568,7 +665,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
     u8* const slot = a.scratch + gid * (long long)a.cap;
     counts_open_stream(s, cs, slot, hist, lane);
     t.exact = cs.head + counts_code_stream<false>(a, s, hist, wring, rtab_lds, lane, reinterpret_cast<u16*>(slot + cs.head));
-    t.chunk = s.chunk; t.pg = s.p * a.G + s.g; t.T = LMC_COUNTS_T; t.out = reinterpret_cast<const u16*>(slot);
+    t.chunk = s.chunk; t.pg = s.p * a.G + s.g; t.T = (u32)s.T; t.out = reinterpret_cast<const u16*>(slot);
     if (lane == 0 && (t.exact > alloc || t.exact + 16 > a.cap)) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);
   };
   if constexpr (COUNTS_ONLY) {
@@ -602,7 +699,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
     }
     __syncthreads();
     const u32 beg = wg_excl + before;
-    const BlobOff bo = lmc_blob_off((u32)a.P, LMC_COUNTS_T, (u32)a.G);
+    const BlobOff bo = lmc_blob_off((u32)a.P, (u32)s.T, (u32)a.G);
     u8* const blob = a.blobs + (long long)chunk_i * a.blob_stride;
     u8* const out = blob + bo.streams + beg;
     counts_open_stream(s, cs, out, hist, lane);
@@ -616,15 +713,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
       if (exact > alloc) atomicOr(a.status, LMC_ST_STREAM_OVERFLOW);  // the bound is a theorem: never
     }
     if ((int)pg_i == n - 1) {  // the chunk's last stream knows the chunk's size: header, static sections, size word
-      write_blob_static(blob, bo, a, LMC_COUNTS_T, wg_excl + wg_total, lane);
+      write_blob_static(blob, bo, a, (u32)s.T, wg_excl + wg_total, lane);
       if (lane == 0) a.sizes[chunk_i] = bo.streams + wg_excl + wg_total;
     }
     return;
   } else if constexpr (ENCODE && QUADSYM) {
-    // 256-token chunks are coded on their symbol counts (LMC_MODEL_COUNTS), every other length on the 16-bit CDF
+    // chunks of 2 .. 256 tokens are coded on their symbol counts (LMC_MODEL_COUNTS), every other length on the 16-bit CDF
     const int chunk_of = (int)chunk_i;
     const bool counts_model =
-        min(a.chunk_tokens, a.tok_end - (a.tok_begin + chunk_of * a.chunk_tokens)) == (int)LMC_COUNTS_T;  // wave-uniform
+        lmc_model_for_dev((u32)min(a.chunk_tokens, a.tok_end - (a.tok_begin + chunk_of * a.chunk_tokens))) == LMC_MODEL_COUNTS;  // wave-uniform
     if (counts_model) counts_stream();
     else {
       encode_group_stream<QUADSYM, ENCODE>(a, gid, hist, wring, lane, t);

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   const EncodeArgs& a = fa.e;
   // (4 KiB aligned, the 4 KiB table slices first: every slice starts at a multiple of 4 KiB, which the row addressing
   // of the counts coder uses -- row_addr_cnt ALIGNED)
-  __shared__ __attribute__((aligned(4096))) u32 lds_all[NW * (CNT_TAB_DWORDS + ENC_RING_DWORDS)];  // the tables, then the staging rings
+  __shared__ __attribute__((aligned(4096))) u32 lds_all[NW * (CNT_TAB_DWORDS + CNT_RING_DWORDS)];  // the tables, then the staging buffers
   __shared__ __attribute__((aligned(16))) u32 rtab_lds[RTAB_LDS_DWORDS];  // reciprocals of the counts model's frequencies, bound table
   __shared__ u32 st_alloc[FUSED_MAX_NS];  // allocation of the item's group streams
   __shared__ u32 wg_excl;
@@ -246,9 +246,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   const int p0 = it * fa.pl, np = min(fa.pl, a.P - p0);  // the item's planes
   const int NS = np * a.G;                               // ... and streams: j -> plane p0 + j / G, group j % G
   const int tok0 = a.tok_begin + chunk * a.chunk_tokens;
-  constexpr int Tc = (int)LMC_COUNTS_T;  // lmc_api.hip hands this kernel full 256-token chunks only
+  const int Tc = a.chunk_tokens;  // lmc_api.hip hands this kernel the job's FULL chunks only: 32 .. 256 tokens each (round 5; 256 before)
   u32* const hist = lds_all + wave * CNT_TAB_DWORDS;  // this wave's table slice ...
-  u16* const ring = reinterpret_cast<u16*>(lds_all + NW * CNT_TAB_DWORDS + wave * ENC_RING_DWORDS);  // ... and staging ring
+  u16* const ring = reinterpret_cast<u16*>(lds_all + NW * CNT_TAB_DWORDS + wave * CNT_RING_DWORDS);  // ... and staging buffer
 
   rtab_to_lds(rtab_lds);  // visible to the coder waves behind the barrier that ends phase A
   // A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next (k_offload, k_pack_scan,
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   if (p0 + np == a.P && threadIdx.x == 64 * (NW - 1)) a.sizes[chunk] = 0u;
   // ---- phase A: quantise the item's planes ------------------------------------------------------------------
   {
-    constexpr int TO = (Tc + 7) >> 3;  // row octs of a plane-chunk
+    const int TO = (Tc + 7) >> 3;  // row octs of a plane-chunk
     uint4* const park = reinterpret_cast<uint4*>(hist);  // the wave's table slice is idle until pass 1
     u8* const scl0 = fa.scale_base + (long long)chunk * fa.scale_stride;
     // Waves that fetch run at raised priority: their (few) instructions go first, so the loads are out early and
@@ -267,19 +267,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     __builtin_amdgcn_s_setprio(LMC_FUSED_PRIO_A);
     if constexpr (GL < 64) {
       // narrow planes: a wave takes RPW row octs of one plane at a time, GL lanes each (quantize_task, k_quantize.h)
-      constexpr int RPW = 64 / GL, OG = TO / RPW;  // octs per wave pass, oct groups per plane
+      constexpr int RPW = 64 / GL;                // octs per wave pass
+      const int OG = (TO + RPW - 1) / RPW;        // oct groups per plane (the last one may be partial: Tc / 8 need not divide)
       const int sub = lane / GL, sl = lane % GL;
 #pragma unroll 1
       for (int task = wave; task < np * OG; task += NW) {
-        const int p = p0 + task / OG, oct = (task % OG) * RPW + sub;
+        const int p = p0 + task / OG;
+        int oct = (task % OG) * RPW + sub;
+        const bool ovalid = oct < TO;             // (per lane group)
+        if (!ovalid) oct = 0;
         const int bins = (int)a.bins.b[p];
         const float maxf = (float)(bins / 2 - 1);
         const bool nib = lmc_sym_nibbles(bins);
         u32* const sym_out = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.sym_stride + (long long)oct * (nib ? 1 : 2) * a.C;
         u16* const scale_out = reinterpret_cast<u16*>(scl0) + (long long)p * Tc + oct * 8;
         const bool q1valid = 2 * oct + 1 < a.TQ;
-        if (nib) quantize_task<GL, 1, DT, true, true, 4, 2>(fa.src, p, tok0, Tc, oct * 8, true, q1valid, a.C, maxf, sym_out, nullptr, scale_out, sl);
-        else quantize_task<GL, 1, DT, true, false, 4, 2>(fa.src, p, tok0, Tc, oct * 8, true, q1valid, a.C, maxf, sym_out, nullptr, scale_out, sl);
+        if (nib) quantize_task<GL, 1, DT, true, true, 4, 2>(fa.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out, nullptr, scale_out, sl);
+        else quantize_task<GL, 1, DT, true, false, 4, 2>(fa.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out, nullptr, scale_out, sl);
       }
     } else {
       const int p = p0;

@@ -6,6 +6,7 @@
 // kernel of a job and waited on by the first kernel of the next one.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <stdlib.h>
@@ -358,7 +359,9 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   const int nfull = (tok_end - tok_begin) / chunk_tokens;  // chunks of exactly chunk_tokens tokens; a ragged one may follow
   // (planes of more than 1024 channels: two kernels -- the fused form built for them in round 4 never won below eight
   // generations of workgroups and was removed, k_fused.h)
-  const bool fused_fits = chunk_tokens == (int)LMC_COUNTS_T && nfull > 0 && C <= LMC_FUSED_MAX_CHANNELS;
+  // chunk lengths: the counts model (and with it the counts-only coder launch) codes 2 .. 256 tokens, the fused kernel
+  // takes the job's full chunks of 32 .. 256 tokens (round 5; both were 256 only)
+  const bool fused_fits = chunk_tokens >= 32 && chunk_tokens <= (int)LMC_COUNTS_T && nfull > 0 && C <= LMC_FUSED_MAX_CHANNELS;
   // planes per work item: narrow planes are grouped until an item has about eight streams -- one per wave (C = 128,
   // 80 layers, 128 chunks, measured: 4 planes = 8 streams per item 0.65 ms, 8 planes 0.68, 2 planes 0.80)
   int pl = C <= 256 ? (8 / G > 1 ? 8 / G : 1) : 1;
@@ -370,10 +373,13 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   const long long auto_min = 4ll * c->num_cus;
   const bool fused = fused_fits && (c->enc_path == LMC_ENCODE_PATH_FUSED ||
                                     (c->enc_path == LMC_ENCODE_PATH_AUTO && (long long)nfull * ipc >= auto_min));
-  // chunks that go through the general coder launch (scratch slots): every chunk of a job whose chunks are not 256 tokens
-  // long or whose streams do not fill 8-wave workgroups, else only a ragged last one
-  const bool general_only = chunk_tokens != (int)LMC_COUNTS_T || ((long long)P * G) % 8 != 0;
-  const int scratch_chunks = general_only ? (fused ? nchunks - nfull : nchunks) : nchunks - nfull;
+  // chunks that go through the general coder launch (scratch slots): every chunk of a job whose chunks are longer than
+  // 256 tokens or whose streams do not fill 8-wave workgroups, a ragged last chunk of a single token
+  const int tail_tokens = (tok_end - tok_begin) - nfull * chunk_tokens;  // 0: no ragged chunk
+  const bool counts_geometry = chunk_tokens <= (int)LMC_COUNTS_T && ((long long)P * G) % 8 == 0;
+  const bool general_only = !counts_geometry || chunk_tokens < (int)LMC_COUNTS_T_MIN;
+  const bool tail_general = tail_tokens > 0 && (general_only || tail_tokens < (int)LMC_COUNTS_T_MIN);
+  const int scratch_chunks = general_only ? (fused ? nchunks - nfull : nchunks) : (tail_general ? 1 : 0);
   // which workspace: the one this stream used last (stream order alone keeps the jobs apart), else an idle one, else --
   // both busy with other streams' jobs -- the first, behind its job
   lmc_ctx::Workspace* w = nullptr;
@@ -451,8 +457,10 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     if ((r = launch_quant<true>(qa, s))) return r;
     if ((r = prof_mark(c, s))) return r;
     const long long ngroups = (long long)n * PG;
-    // launches of 256-token chunks only take the counts-only coder: 8 waves per workgroup, 32 waves per CU
-    const bool counts_only = chunk_tokens == (int)LMC_COUNTS_T && e2.tok_begin + n * chunk_tokens <= tok_end && PG % 8 == 0;
+    // launches whose chunks all have 2 .. 256 tokens (a ragged last chunk included) take the counts-only coder: 8 waves
+    // per workgroup, 32 waves per CU
+    const int last_tokens = std::min(chunk_tokens, tok_end - (e2.tok_begin + (n - 1) * chunk_tokens));
+    const bool counts_only = !general_only && last_tokens >= (int)LMC_COUNTS_T_MIN;
     const int nw = counts_only ? 8 : ENC_WAVES;
     const unsigned nwg = (unsigned)((ngroups + nw - 1) / nw);
     e2.ticket_base = w->tickets_drawn;
@@ -485,8 +493,8 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     w->tickets_drawn += grid.x;
     if ((rc = prof_mark(c, s))) return rc;
     if (nfull < nchunks && (rc = two_kernels(nfull, nchunks - nfull))) return rc;  // the ragged last chunk
-  } else if (nfull > 0 && nfull < nchunks && chunk_tokens == (int)LMC_COUNTS_T) {
-    // the full chunks with the counts-only coder, the ragged last one with the general one
+  } else if (nfull > 0 && nfull < nchunks && !general_only && tail_general) {
+    // the full chunks with the counts-only coder, a one-token last chunk with the general one
     if ((rc = two_kernels(0, nfull)) || (rc = two_kernels(nfull, nchunks - nfull))) return rc;
   } else {
     if ((rc = two_kernels(0, nchunks))) return rc;

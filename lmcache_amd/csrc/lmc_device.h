@@ -53,6 +53,13 @@ __device__ __forceinline__ long long lmc_tok_off(const KvAddr& a, int t) {
   return (long long)t * a.stride_token;
 }
 
+// Device twins of lmc_format.h's lmc_model_for / lmc_counts_scale_magic (ceil(2^32 / T) = floor((2^32 - 1) / T) + 1 for
+// every T >= 2: a power of two divides 2^32, any other T does not).
+__device__ __forceinline__ u32 lmc_model_for_dev(u32 T) {
+  return (T >= LMC_COUNTS_T_MIN && T <= LMC_COUNTS_T) ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16;
+}
+__device__ __forceinline__ u32 lmc_counts_scale_magic_dev(u32 T) { return 0xffffffffu / T + 1u; }
+
 // Workspace symbol format of a plane: symbols are 0 .. bins - 2, so planes with bins <= 17 pack two per byte
 // (k_quantize.h writes, k_encode.h reads).
 __device__ __forceinline__ bool lmc_sym_nibbles(int bins) { return bins <= 17; }

@@ -157,14 +157,15 @@ class PackJob:
 def pack_cap(n: int, L: int, T: int, H: int, D: int, bins: Sequence[int]) -> int:
     """Bytes a pack of n T-token chunks can need: the static sections plus, per group stream, its largest head (every
     symbol of the plane at the widest count) and the coder's bound -- a lane emits at most T * log2(symbols) + 48 bits
-    (DESIGN.md "stream bound") -- with 3 % on top."""
+    (DESIGN.md "stream bound"; chunks below 256 tokens: + 1.44 bit per symbol kind for the rounding of the scaled model
+    counts, lmc_format.h) -- with 3 % on top."""
     import math
     G = (H * D + native.LANES - 1) // native.LANES
     static = native.r16(native.blob_static_bytes(L, T, H, D))
     width = (255 if T == 256 else T).bit_length()
     streams = 0
     for b in bins:
-        lane_bytes = math.ceil((T * math.log2(max(2, b - 1)) * 1.03 + 64) / 8) + 4
+        lane_bytes = math.ceil((T * math.log2(max(2, b - 1)) * 1.03 + 128) / 8) + 4
         head = native.r16(((b - 1 + 7) & ~7) + 8 * (b - 1) * width)
         streams += G * (head + native.r16(native.LANES * lane_bytes))
     return min(native.pack_bound(n, L, T, H, D), native.r16(256 + 8 * (2 * L * n + 1)) + n * (static + streams))

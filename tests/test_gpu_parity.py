@@ -684,9 +684,17 @@ FUSED_SHAPES = [
     (2, 256, 256, 16, 128, torch.bfloat16, "randn"),  # C = 2048
     (1, 256, 256, 25, 128, torch.bfloat16, "outlier"),# C = 3200: partial channel runs in the last wave of a row
     (1, 256, 256, 9, 136, torch.bfloat16, "randn"),   # C = 1224: an almost empty second slice
-    (2, 236, 236, 8, 128, torch.float16, "outlier"),  # tests/test_serde.py:87-107 chunk length: not a fused geometry
-    (1, 300, 300, 8, 128, torch.bfloat16, "randn"),   # T > 256 in one chunk (two-byte counts): not a fused geometry
-    (2, 9, 4, 3, 128, torch.bfloat16, "randn"),       # chunks shorter than a row oct: not a fused geometry
+    # chunk lengths below 256 (round 5: the counts model scaled to a sum of 256; fused from 32 tokens on)
+    (2, 236, 236, 8, 128, torch.float16, "outlier"),  # tests/test_serde.py:87-107 chunk length: 7 whole 32-token blocks + 12 tokens
+    (2, 472, 236, 8, 128, torch.bfloat16, "rand"),    # two of them
+    (2, 300, 128, 8, 128, torch.float16, "randn"),    # chunk_size 128: two fused chunks + a tail of 44 tokens (counts-only launch)
+    (1, 165, 32, 4, 128, torch.bfloat16, "randn"),    # one block per chunk, tail of 5 tokens
+    (2, 200, 40, 3, 128, torch.bfloat16, "outlier"),  # C = 384, chunks of 40 = one block + 8 tokens
+    (3, 250, 100, 1, 128, torch.bfloat16, "randn"),   # narrow planes: 13 row octs = 3 full oct groups + 1 partial, tail of 50
+    (2, 255, 255, 2, 128, torch.bfloat16, "rand"),    # the longest scaled chunk
+    (1, 300, 300, 8, 128, torch.bfloat16, "randn"),   # T > 256 in one chunk (two-byte counts): CDF16, not a fused geometry
+    (2, 9, 4, 3, 128, torch.bfloat16, "randn"),       # chunks shorter than a row oct (counts-only launch); the 1-token tail is CDF16
+    (1, 67, 33, 1, 72, torch.bfloat16, "randn"),      # P G = 4: streams do not fill 8-wave workgroups -> general launch, counts model per stream
 ]
 
 

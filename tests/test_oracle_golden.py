@@ -243,6 +243,83 @@ def test_counts_bound_table_and_adversarial_streams(oracle):
     assert all(not raw[e:n].any() for e, n in zip(gdir[:, 1], ends))
 
 
+def test_counts_model_below_256_tokens_bound_and_roundtrip(oracle):
+    """Round 5: LMC_MODEL_COUNTS codes every chunk of 2 .. 256 tokens (lmc_format.h: lmc_counts_model scales the counts to
+    a sum of 256 along the cumulative sum; the stream bound of T < 256 is sum cnt * lmc_counts_bpo[model count]).
+    (1) the per-occurrence table is what its comment says; (2) the model: sums to 256, keeps every occurring symbol at
+    >= its count, absent ones at 0, is the identity at T = 256, and its multiply-high scaling is the exact quotient;
+    (3) the bound holds (lmco_encode_blob fails otherwise) and the round trip is exact on stress channels at
+    T = 2, 3, 31, 33, 128, 236, 255; (4) the allocation slack on iid symbols stays below 2 %; T = 1 stays CDF16."""
+    import math, re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "include", "lmc_format.h")).read()
+    body = re.search(r"#define LMC_COUNTS_BPO_LIST(.*?)\nstatic const", src, re.S).group(1)
+    tab = [int(v) for v in body.replace("\\", " ").replace("\n", " ").split(",")]
+    assert len(tab) == 257 and tab[0] == 0 and tab[256] == 0
+    for n in range(1, 256):
+        assert tab[n] == math.ceil(256 * (math.log2(256 / n) + math.log2(1 + 2 * n / 32768))) + 1, n
+    # (2) the model, restated in Python
+    rng = np.random.default_rng(5)
+
+    def model(cnt, T):
+        cum = np.cumsum(cnt)
+        N = cum if T == 256 else (cum * 256) // T
+        n = np.diff(np.concatenate([[0], N]))
+        if n.max() >= 256:
+            s = int(n.argmax())
+            n[s] = 255
+            n[1 if s == 0 else 0] = 1
+        return n
+    for T in (2, 3, 7, 31, 33, 100, 128, 236, 255, 256):
+        magic = (2**32 + T - 1) // T
+        for x in range(T + 1):
+            assert ((x << 8) * magic) >> 32 == (256 * x) // T, (T, x)
+        for _ in range(50):
+            k = int(rng.integers(1, 16))
+            cnt = np.bincount(rng.integers(0, k, T), minlength=15)
+            n = model(cnt.copy(), T)
+            assert n.sum() == 256 and ((n > 0) == (cnt > 0)).all() or cnt.max() == T
+            if cnt.max() < T:
+                assert (n >= cnt).all()
+            if T == 256 and cnt.max() < 256:
+                assert (n == cnt).all()
+    # (3) + (4) through the oracle's blob encoder (it checks every stream against its allocation)
+    L, H, D = 1, 1, 64
+    bins = np.array([32, 16], np.int32)
+
+    def encode_symbols(sym_k, sym_v, T):
+        out = np.zeros((L, 2, T, H * D), np.float32)
+        for kv, (sy, b) in enumerate(((sym_k, 32), (sym_v, 16))):
+            M = b // 2 - 1
+            out[0, kv] = (sy.astype(np.float32) - M)
+            out[0, kv, :, 0] = M
+        import torch
+        bits, code = oracle.torch_to_bits(torch.from_numpy(out).to(torch.bfloat16))
+        blob = oracle.encode_blob(bits, code, H, D, bins)
+        sym, _ = oracle.quantize(bits, code, bins)
+        assert np.array_equal(oracle.decode_blob_symbols(blob), sym)
+        return blob
+    for T in (2, 3, 31, 33, 128, 236, 255):
+        assert oracle.parse_header(encode_symbols(np.zeros((T, 64), np.int64), np.zeros((T, 64), np.int64), T))["model"] == 1
+        cases = [np.zeros((T, 64), np.int64), rng.integers(0, 15, (T, 64)), np.sort(rng.integers(0, 15, (T, 64)), axis=0)]
+        for dom in (1, 2, 5, T // 2, T - 1):
+            if 0 < dom < T:
+                s = np.full((T, 64), 7, np.int64)
+                s[np.linspace(0, T - 1, dom).astype(int)] = rng.integers(0, 14, (dom, 64))
+                cases.append(s)
+        for s in cases:
+            s = np.clip(s, 0, 14)
+            encode_symbols(np.clip(s * 2, 0, 30), s, T)
+    for T in (128, 236):
+        s = rng.integers(0, 15, (T, 64))
+        blob = encode_symbols(s * 2, s, T)
+        h = oracle.parse_header(blob)
+        gdir = oracle.stream_dir(blob)
+        used = int((gdir[:, 1] - gdir[:, 0]).sum())
+        assert used <= h["stream_bytes"] <= used * 1.02 + 32, (T, used, h["stream_bytes"])
+    one = encode_symbols(np.zeros((1, 64), np.int64), np.zeros((1, 64), np.int64), 1)
+    assert oracle.parse_header(one)["model"] == 0
+
+
 def test_stream_head_is_the_bit_sliced_counts(oracle):
     """lmc_format.h "head": widths = significant bits of the largest stored count of a symbol over the 64 lanes, the
     counts as 8-byte bit planes, most significant first; a count of 256 is stored as 255 (T <= 256); idle lanes store 0;
