@@ -50,6 +50,11 @@ L, H, D = 32, 8, 128
 CTX, CHUNK = 16384, 256
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_GIPS = 614.4    # wave-instructions/s the chip can issue: 1024 SIMDs x 2.4 GHz / 4 cycles (same guide)
+# Issue-slot prices measured on MI355X at 8 waves per SIMD (tools/probes/valu_rates.py, tools/probes/issue_model.py;
+# profiles/r05_issue_model.md), ns of SIMD time per wave-instruction:
+ISSUE_NS = {"valu_fast": 1.05,    # v_add/sub/and/or/xor/lshrrev/mov/mul_f32/add_f32 without modifiers
+            "valu_normal": 1.85,  # every other VALU instruction (VOP3, SDWA, DPP, cvt, cmp, mbcnt, lshlrev, packed, mul_hi ...)
+            "salu_beside_valu": 0.43}  # what a scalar instruction ADDS to a VALU-bound step (alone: 0.94; a taken branch: + 1.5)
 PROXY_BYTES = 16 * (1 << 30)  # one Llama-3-8B decode step streams ~16 GB of bf16 weights
 STUB = os.environ.get("LMC_BENCH_STUB") == "1"
 
@@ -100,6 +105,77 @@ def load_latest_profile():
             return json.load(f)
     except Exception:
         return None
+
+
+def issue_roof(prof, gpu_ms_per_step):
+    """The issue-slot floor of the dominant kernel: its VALU instructions priced by class (the static class mix of its
+    hot loops x the dynamic count of the PMC pass) plus what its scalar instructions add beside them, per SIMD."""
+    k = (prof.get("kernels") or {}).get(prof.get("dominant_kernel") or "", {})
+    if not k or "valu_insts" not in k or "salu_insts" not in k:
+        return None
+    fast = k.get("valu_fast_share", 0.3)
+    valu_ns = k["valu_insts"] * (fast * ISSUE_NS["valu_fast"] + (1 - fast) * ISSUE_NS["valu_normal"])
+    salu_ns = k["salu_insts"] * ISSUE_NS["salu_beside_valu"]
+    floor_ms = (valu_ns + salu_ns) / 1024.0 / 1e6  # 1024 SIMDs
+    return {"bound": "issue slots (VALU by class + SALU)", "floor_ms": round(floor_ms, 4),
+            "frac": round(floor_ms / gpu_ms_per_step, 4), "valu_ms": round(valu_ns / 1024.0 / 1e6, 4),
+            "salu_ms": round(salu_ns / 1024.0 / 1e6, 4), "valu_insts": k["valu_insts"], "salu_insts": k["salu_insts"],
+            "valu_fast_share": fast, "prices_ns": ISSUE_NS,
+            "note": "floor = (VALU instructions x class price + SALU instructions x their measured cost beside a VALU stream) "
+                    "/ 1024 SIMDs; frac = floor / measured step: what is left is waiting (barriers, look-back, loads in phase A)"}
+
+
+# ---------------------------------------------------------------------------------------------- clock / power
+class GpuSampler:
+    """Shader clock and board power of the GPU while the bench runs, from the amdgpu hwmon files of ITS PCI device
+    (freq1_input, power1_average): a thread that reads them every millisecond and never touches the GPU.  VERDICT r04 #7:
+    fresh boxes differ by +- 7 % on the same build; the line says what clock and power the timed region ran at."""
+
+    def __init__(self, dev_index):
+        import glob
+        import threading
+        self.dir = None
+        try:
+            p = torch.cuda.get_device_properties(dev_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            hw = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if hw:
+                self.dir = hw[0]
+        except Exception:
+            self.dir = None
+        self.samples = []  # (t, MHz, W)
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.dir else None
+
+    def _read(self, name, scale):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return int(f.read()) / scale
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append((time.perf_counter(), self._read("freq1_input", 1e6), self._read("power1_average", 1e6)))
+            time.sleep(0.001)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+
+    def stop(self):
+        if self._thread:
+            self._stop.set()
+            self._thread.join()
+
+    def window(self, t0, t1):
+        rows = [r for r in self.samples if t0 <= r[0] <= t1 and r[1] is not None]
+        if not rows:
+            return None
+        mhz = sorted(r[1] for r in rows)
+        w = sorted(r[2] for r in rows if r[2] is not None)
+        return {"samples": len(rows), "sclk_MHz_median": mhz[len(mhz) // 2], "sclk_MHz_min": mhz[0],
+                "power_W_median": w[len(w) // 2] if w else None, "source": self.dir}
 
 
 # ---------------------------------------------------------------------------------------------- CPU baselines
@@ -315,11 +391,10 @@ def time_encode(ctx, layout, ntok, chunk, bins, blobs, stride, sizes, sp, stream
     return ev0.elapsed_time(ev1) / reps
 
 
-def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=False):
+def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=False, cs=256):
     stage(f"shape {name}")
     """Encode / decode rate of another geometry (HBM-resident, one job)."""
     from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
-    cs = 256
     kv = make_kv(dev, 0, "rand", nl, ntok, nh, hd, dtype)
     lay = native.KVLayout.from_kv_tuple(kv, "vllm")
     bins = CacheGenConfig.from_model_name(model).plane_bins(nl)
@@ -357,7 +432,7 @@ def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=Fal
     e1.record()
     torch.cuda.synchronize()
     tdec = e0.elapsed_time(e1) / 20
-    return {"workload": name, "raw_kv_MB": round(raw / 1e6, 1), "chunks": n,
+    return {"workload": name, "raw_kv_MB": round(raw / 1e6, 1), "chunks": n, "chunk_tokens": cs,
             "encode_ms": round(tenc, 3), "encode_GBps_raw": round(raw / tenc / 1e6, 1),
             "decode_ms": round(tdec, 3), "decode_GBps_raw": round(raw / tdec / 1e6, 1),
             "compression": round(raw / int(sizes.sum()), 3)}
@@ -397,6 +472,9 @@ def main(argv=None):
                          "replicated-instance split, lmcache_amd.distributed.shard_chunks), value = the context's bytes / "
                          "max-over-ranks time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-legs", action="store_true",
+                    help="for the rocprofv3 passes: after the timed region also 5 jobs of the two-kernel path and 5 HBM-resident "
+                         "decodes of the context (k_quantize, k_cdf_encode, k_decode rows in the same database), then the line")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region and the roofline")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the cpu_baseline sample (0 = auto)")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the exchange leg")
@@ -476,6 +554,10 @@ def main(argv=None):
     # first ~50 ms of work below its sustained clock (tools/probes/encode_ab.hip, alternating rounds: the first 40
     # jobs average 1.23 ms, every later round 1.185), which is longer than W + K steps of this workload.  The
     # same full steps on the same buffers, ~0.25 s of them.
+    sampler = GpuSampler(local_rank) if (not STUB and rank == 0) else None
+    if sampler:
+        sampler.start()
+    t_ramp0 = time.perf_counter()
     ramp_steps = 0
     if not STUB and args.ramp_ms > 0:
         t_r = time.perf_counter()
@@ -505,6 +587,8 @@ def main(argv=None):
     sync()
     elapsed = time.perf_counter() - t0
     barrier()
+    if sampler:
+        sampler.stop()
     gpu_ms_per_step = elapsed * 1e3 / args.steps if STUB else ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
     if ctx is not None:
         ctx.raise_on_status("bench")
@@ -526,6 +610,10 @@ def main(argv=None):
                       "sharding": (f"one context, chunks i mod {world} == rank ({len(my_chunks)} chunks on rank 0)" if strong
                                    else f"{world} x independent contexts"),
                       "numa_node": numa},
+           "gpu_state": None if not sampler else {
+               "timed_region": sampler.window(t0, t0 + elapsed), "ramp_and_warmup": sampler.window(t_ramp0, t0),
+               "note": "amdgpu hwmon of the bench's GPU sampled every ms by a host thread: the shader clock and board power "
+                       "the timed K steps ran at (fresh boxes differ by +- 7 % on one build; DESIGN.md section 6)"},
            "clock_ramp": {"untimed_steps_before_warmup": ramp_steps, "ms": args.ramp_ms,
                           "why": "a GPU fresh out of idle runs its first ~50 ms below its sustained clock; W + K steps "
                                  "of this workload are shorter than that (--ramp-ms 0 turns it off)"}}
@@ -594,6 +682,8 @@ def main(argv=None):
                     "frac": round(valu_insts / (gpu_ms_per_step / 1e3) / 1e9 / VALU_PEAK_GIPS, 4),
                     "valu_insts_per_step": valu_insts,
                     "valu_busy_dominant_kernel": prof.get("valu_busy_dominant_kernel")},
+                # ... priced by instruction class, with the scalar side (VERDICT r04 #1a): profiles/r05_issue_model.md
+                "issue": issue_roof(prof, gpu_ms_per_step),
                 "profile_source": prof.get("source"),
                 "note": "achieved = (raw KV read once + blob written once) per step / HIP-event time of one step "
                         "(the whole encode job: one k_encode_fused launch) on the launch stream over the timed region; "
@@ -601,6 +691,17 @@ def main(argv=None):
                         "instruction count come from the rocprofv3 PMC passes summarised in profiles/latest.json "
                         "(FETCH_SIZE doubled for the 16-B/lane streams per MI355X_MICROARCH.md)"}
     res["roofline"] = roofline
+    if args.profile_legs:
+        ctx.set_encode_path("two_kernels")
+        for _ in range(5):
+            step()
+        ctx.set_encode_path("auto")
+        out_kv = tuple((torch.empty_like(k), torch.empty_like(v)) for k, v in kv)
+        ol = native.KVLayout.from_kv_tuple(out_kv, "vllm")
+        for _ in range(5):
+            ctx.decode_chunks(blobs.data_ptr(), stride, nchunks, ol, 0, CHUNK)
+        torch.cuda.synchronize()
+        ctx.raise_on_status("profile legs")
     res["encode_paths"] = encode_paths_ab(ctx, step, stream, max(5, min(20, args.steps)))
     # what ONE store() out of idle costs (the timed region above is steady state: the clock ramp is outside it)
     cold = []
@@ -976,7 +1077,15 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
                              80, 1, 128, torch.bfloat16, 32768, "Llama-3-70B"),
                   shape_rate(native, ctx, dev, "configs[4]: Mistral-7B, 8 x 2048 tokens, decode + scatter into paged "
                                                "NHBD blocks at random slots", 32, 8, 128, torch.bfloat16, 16384,
-                             "mistralai/Mistral-7B-Instruct-v0.2", paged=True)]
+                             "mistralai/Mistral-7B-Instruct-v0.2", paged=True),
+                  # chunk lengths other than 256 (the reference's encode_function takes any, its
+                  # tests/test_serde.py:87-107 uses 236): the counts model scaled to a sum of 256 + the fused kernel
+                  shape_rate(native, ctx, dev, "Llama-3-8B bf16, 16 284 tokens in chunks of 236 (tests/test_serde.py:87-107's length)",
+                             32, 8, 128, torch.bfloat16, 69 * 236, MODEL, cs=236),
+                  shape_rate(native, ctx, dev, "Llama-3-8B bf16, 16k tokens, chunk_size = 128",
+                             32, 8, 128, torch.bfloat16, 16384, MODEL, cs=128),
+                  shape_rate(native, ctx, dev, "Llama-3-8B bf16, 16 484 tokens, chunk_size 256 + a ragged last chunk of 100",
+                             32, 8, 128, torch.bfloat16, 16384 + 100, MODEL)]
     except Exception as e:
         others = [{"error": repr(e)}]
     res["other_configs"] = others

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       // then takes its row with two v_readlane and the store goes through a descriptor based at that row
       long long tok_off2 = 0;
       if (PAGED && !SYMOUT) tok_off2 = (t0 + (u32)lane < T) ? lmc_tok_off(a.dst, tdst0 + (int)(t0 + (u32)lane)) * 2 : 0ll;
-      for (u32 i = 0; i < nt; i++) {
+      auto one_token = [&](u32 i) {
         float lv = 0.0f;
         const u32 sa = decode_token(top_tag, model_tag, lv);
         if (SYMOUT) {
@@ -579,7 +579,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
             soff += (u32)row_step;
           }
         }
-      }
+      };
+      // (four tokens per trip -- the back edge is a taken scalar branch per token -- measured the same within the box
+      // noise in round 5: 0.894 - 0.911 against 0.903 - 0.962 ms, alternating builds; the decoder's VALU pipes are 98 %
+      // busy and a scalar branch costs it nothing)
+      for (u32 i = 0; i < nt; i++) one_token(i);
     }
   };
   auto run_src = [&](auto src_tag) {

@@ -32,6 +32,13 @@ assert min(CAL[k] for k in ("rd16_nt", "rd4", "rd4_nt", "rd16", "rd_lds16")) > 0
     "the read patterns no longer share one FETCH_SIZE factor: split the kernels' reads by pattern"
 
 
+# Share of a kernel's DYNAMIC VALU instructions that are of the fast class (v_add / sub / and / or / xor / lshrrev / mov /
+# mul_f32 / add_f32 without modifiers: 1.05 ns per wave-instruction per SIMD against 1.85 for the rest; tools/probes/
+# valu_rates.py): the static class mix of the kernel's hot loops (tools/isa_cycles.py --between ...) weighted by what
+# each loop contributes per token step -- profiles/r05_issue_model.md has the table.
+FAST_SHARE = {"k_encode_fused": 0.27, "k_cdf_encode": 0.24, "k_decode": 0.48, "k_quantize": 0.37}
+
+
 def counters(path):
     db = sqlite3.connect(path)
     rows = db.execute("select kernel_name, counter_name, avg(value), avg(duration), count(*) from counters_collection "
@@ -64,7 +71,9 @@ def main(argv):
         hbm = (fetch_kib * factor + write_kib * wfactor) * 1024.0
         res["kernels"][k] = {"avg_us_profiled": round(sq_ns / 1e3, 1), "hbm_bytes": int(hbm),
                              "fetch_bytes": int(fetch_kib * factor * 1024.0), "write_bytes": int(write_kib * wfactor * 1024.0),
-                             "valu_insts": int(insts),
+                             "valu_insts": int(insts), "salu_insts": int(csq[k]["SQ_INSTS_SALU"][0]),
+                             "lds_insts": int(csq[k]["SQ_INSTS_LDS"][0]), "valu_fast_share": FAST_SHARE[k],
+                             "wait_any_frac": round(csq[k]["SQ_WAIT_ANY"][0] / csq[k]["SQ_WAVE_CYCLES"][0], 3),
                              "valu_busy": round(busy, 3), "clock_GHz": round(clock_ghz, 3)}
         default_path = k == "k_encode_fused" or (k != "k_decode" and "k_encode_fused" not in csq)
         if default_path:
