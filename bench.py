@@ -156,7 +156,10 @@ class GpuSampler:
 
     def _run(self):
         while not self._stop.is_set():
-            self.samples.append((time.perf_counter(), self._read("freq1_input", 1e6), self._read("power1_average", 1e6)))
+            w = self._read("power1_average", 1e6)
+            if w is None:
+                w = self._read("power1_input", 1e6)
+            self.samples.append((time.perf_counter(), self._read("freq1_input", 1e6), w))
             time.sleep(0.001)
 
     def start(self):

@@ -102,7 +102,9 @@ __device__ __forceinline__ u32 lookback_exclusive_epoch(unsigned long long* agg,
 // the wave's idle LDS slice and merges them with the second (byte k = token k | token 4 + k << 4).
 // FULL: every lane of every iteration holds channels of the plane (C == NITER * 512: Llama / Mistral GQA
 // shapes), so no per-lane validity is tested and no register is zero-filled for absent channels.
-template <int NITER, int DT, bool NIB, bool FULL = false>
+// ALLROWS: all eight rows of the oct are tokens of the chunk (every oct but the last one of a chunk whose length is no
+// multiple of 8): no per-row test, no zero fill -- what the kernel had when it only took 256-token chunks.
+template <int NITER, int DT, bool NIB, bool FULL = false, bool ALLROWS = true>
 __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16* pbase, int tok0, int Tc, int t_first,
                                                    bool q1valid, int C, float maxf, u32* sym_out, u16* scale_out,
                                                    uint4* park, int lane) {
@@ -127,7 +129,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         const int t = t_first + 4 * hq + r0 + r;
-        tv[r] = t < Tc;
+        tv[r] = ALLROWS || t < Tc;
         const u16* rowp = pbase + (tv[r] ? lmc_tok_off(src, tok0 + t) : 0);
 #pragma unroll
         for (int it = 0; it < NITER; it++) {
@@ -297,19 +299,27 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll 1
       for (int oct = wave; oct < TO; oct += NW) {
         const bool q1valid = 2 * oct + 1 < a.TQ;
-        if (full) {  // wave-uniform
+        const bool allrows = oct * 8 + 8 <= Tc;  // wave-uniform: false only for the last oct of a chunk of 8 k + r tokens
+        if (!allrows) {  // (the variant with per-lane channel validity takes the per-row test as well: two instances, not four)
+          if (nib)
+            quantize_oct_fused<NITER, DT, true, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                              sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
+          else
+            quantize_oct_fused<NITER, DT, false, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+                                                               sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
+        } else if (full) {  // wave-uniform
           if (nib)
             quantize_oct_fused<NITER, DT, true, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                                             sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
+                                                      sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
           else
             quantize_oct_fused<NITER, DT, false, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                                              sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
+                                                       sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
         } else if (nib)
           quantize_oct_fused<NITER, DT, true, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                                            sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
+                                                     sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
         else
           quantize_oct_fused<NITER, DT, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
-                                                             sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
+                                                      sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
       }
     }
     __builtin_amdgcn_s_setprio(0);
