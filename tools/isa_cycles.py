@@ -20,7 +20,10 @@ MI355X, 8 waves per SIMD, ns per wave-instruction per SIMD; 1 cycle = 0.43 ns at
 
 --between PATTERN --nth N   the instructions from the N-th line matching PATTERN up to (not including) the next
                             match: one iteration of an unrolled loop.  Without it: the whole kernel.
-The kernel is the first whose mangled name contains KERNEL.  LDS / VMEM / SALU instructions are counted, not priced.
+The kernel is the first whose mangled name contains KERNEL.  LDS / VMEM instructions are counted, not priced.  Round 5
+prices the scalar side as well (tools/probes/issue_model.py, profiles/r05_issue_model.md): a scalar instruction adds
+0.43 ns to a VALU-bound step of a full SIMD (1.95 ns when it runs alone), s_nop / an idle s_waitcnt 0.8, and a branch
+1.3 ns per instruction when it falls through, 2.0 - 3.6 when it is taken (the listing cannot tell: both are shown).
 """
 import re
 import sys
@@ -109,6 +112,10 @@ def main(argv):
     print(f"  VALU issue time   {ns:.1f} ns per wave = {ns / 0.43:.0f} cycles at 2.3 GHz "
           f"(x 8 waves per SIMD = {8 * ns:.0f} ns per token step of a full SIMD)")
     print("  other: " + ", ".join(f"{k} {v}" for k, v in other.items() if v))
+    salu_ns = other["salu"] * 0.43 + other["branch"] * 0.43
+    print(f"  scalar side beside the VALU stream: {other['salu'] + other['branch']} instructions = +{salu_ns:.1f} ns per step "
+          f"(if every branch is taken: +{salu_ns + other['branch'] * 1.5:.1f}); issue floor of the stretch "
+          f"{ns + salu_ns:.1f} ns per wave-step")
     print("  " + " ".join(f"{m}:{c}" for m, c in sorted(per.items(), key=lambda kv: -kv[1])))
 
 
