@@ -182,6 +182,31 @@ def test_same_retrieve_store_lossless(fmt, backend):
         engine.close()
 
 
+@pytest.mark.parametrize("cs", [128, 236, 40])
+@pytest.mark.parametrize("backend", ["cachegen-host", "cachegen-hbm"])
+def test_chunk_sizes_below_256_through_the_engine_equal_the_oracle(backend, cs, oracle):
+    """Round 5: every chunk of 2 .. 256 tokens is coded on the counts model (scaled to a sum of 256) and, from 32 tokens
+    on, by the fused kernel; store -> retrieve through the engine -- packs in the pinned tier, blobs in the HBM tier, a
+    ragged last chunk -- returns exactly do_dequantize(torch_quant_vectorized(x)) per chunk."""
+    fmt, nl = "vllm", 4
+    num_tokens = 5 * cs + 17
+    tokens = generate_tokens(num_tokens, "cuda")
+    kv_cache = generate_kv_cache(num_tokens, fmt, "cuda", num_layers=nl)
+    engine = LMCacheEngine(make_cfg(backend, cs), dumb_metadata(fmt, MODEL))
+    try:
+        engine.store(tokens, kv_cache)
+        retrieved_cache, ret_mask = engine.retrieve(tokens)
+        assert int(torch.sum(ret_mask)) == num_tokens
+        for t0 in range(0, num_tokens, cs):
+            t1 = min(num_tokens, t0 + cs)
+            part = tuple((k[t0:t1], v[t0:t1]) for k, v in kv_cache)
+            want = oracle_roundtrip(oracle, part, fmt, MODEL, torch.bfloat16)
+            got = to_blob(tuple((k[t0:t1], v[t0:t1]) for k, v in retrieved_cache)).cpu()
+            assert torch.equal(got, want), f"chunk at {t0}"
+    finally:
+        engine.close()
+
+
 @pytest.mark.parametrize("fmt", ["vllm", "huggingface"])
 @pytest.mark.parametrize("backend", ["cachegen-host", "cachegen-hbm", "mem://cachegen:1", "mem://cachegenpipe:1",
                                      "xgmi://cg:1", "xgmi://cgpipe:1"])
