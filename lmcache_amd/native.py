@@ -71,7 +71,7 @@ def _write_kernel_resources(remarks: str) -> None:
             sys.stderr.write(line + "\n")
     demangled = {}
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + list(table), stdout=subprocess.PIPE, text=True).stdout.split("\n")
+        out = subprocess.run(["c++filt"] + list(table), stdout=subprocess.PIPE, text=True).stdout.split("\n")
         demangled = dict(zip(table, out))
     except Exception:
         pass
