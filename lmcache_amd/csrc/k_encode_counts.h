@@ -114,11 +114,25 @@ __device__ __forceinline__ u32 row_addr_cnt(const u32* w, u32 base) {
       u32 r;
       asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w[I >> 3]), "s"(0xf00u), "v"(base));
       return r;
+    } else if constexpr (ALIGNED && POS > 8) {
+      // (round 5) the field moved DOWN to bits 8 .. 11 by a v_lshrrev -- the fast class, 1.05 ns against 1.85 for v_bfe --
+      // then merged into the aligned column address: one fast + one normal instruction instead of two normal ones
+      u32 r;
+      asm("v_lshrrev_b32_e32 %0, %2, %1\n\tv_and_or_b32 %0, %0, %3, %4" : "=&v"(r) : "v"(w[I >> 3]), "n"(POS - 8), "s"(0xf00u), "v"(base));
+      return r;
     } else {
       return row_addr_sh<POS, 4, 8>(w[I >> 3], base);
     }
   } else {
-    return row_addr_sh<8 * (I & 3), 8, 7>(w[I >> 2], base);
+    constexpr int POS = 8 * (I & 3);
+    if constexpr (ALIGNED && POS >= 8) {
+      // rows of 128 B: symbol << 7.  Symbols are < 32, so the field is bits 7 .. 11 -- below the 4 KiB alignment of the slice
+      u32 r;
+      asm("v_lshrrev_b32_e32 %0, %2, %1\n\tv_and_or_b32 %0, %0, %3, %4" : "=&v"(r) : "v"(w[I >> 2]), "n"(POS - 7), "s"(0xf80u), "v"(base));
+      return r;
+    } else {
+      return row_addr_sh<POS, 8, 7>(w[I >> 2], base);
+    }
   }
 }
 
