@@ -403,12 +403,14 @@ __device__ __forceinline__ void counts_open_stream(const CountsStream& s, const 
   wave_lds_fence();
 }
 
-// ---- pass 2: interleaved rANS, tokens 255 .. 0 -----------------------------------------------------------------
-// `tabmem` holds the stream's table, `ring` is the wave's staging ring (ENC_RING_DWORDS), `rtab` the workgroup's copy
-// of g_rans_rtab.  The words of a step go to the ring (256 slots + a 64-slot extension: a step never wraps); whenever
-// 128 words have gathered they leave with one coalesced 256-byte store to `out` (wave-uniform).  NT: the stores are
-// non-temporal (the stream is at its final place: nobody reads it again) -- the callers that code in place are the
-// 8-wave layouts, whose table slices are 4 KiB aligned (row_addr_cnt's ALIGNED).
+// ---- pass 2: interleaved rANS, tokens T - 1 .. 0 -----------------------------------------------------------------
+// `tabmem` holds the stream's table, `ring` is the wave's staging buffer (CNT_RING_DWORDS = 256 words, used linearly:
+// see below), `rtab` the workgroup's copy of g_rans_rtab.  The words of a step go to the buffer behind the words still
+// waiting in it; whenever its first 128 words are complete they leave with one coalesced 256-byte store to `out`
+// (wave-uniform) and the rest moves down.  NT: the stores are non-temporal (the stream is at its final place: nobody
+// reads it again) -- the callers that code in place are the 8-wave layouts, whose table slices are 4 KiB aligned
+// (row_addr_cnt's ALIGNED).  The chunk's whole 32-token blocks run through the unrolled, software-pipelined loop; the
+// <= 31 tokens behind them (chunk lengths that are no multiple of 32) through a plain loop in front of it.
 // Returns the exact length in bytes of words + states (the head in front of `out` not counted); the 64 states follow
 // the words, then zeros up to a multiple of 16 (`out` is 16-byte aligned).
 template <bool NT>
@@ -566,8 +568,9 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
     // landed two steps earlier), so the wait in front of a step's block covers requests that are two steps old and
     // leaves the previous step's three LDS operations in flight.  The step's asm block works out the address of the
     // reciprocal and appends the step's words -- under exec = emitting lanes: v_cmpx on the state's upper half against
-    // the entry's (count << 7), mbcnt rank, ds_write_b16 into the ring, x >>= 16, exec restored -- and the loads are
-    // plain loads the compiler tracks, issued right behind the block (behind the ring store in the LDS queue).
+    // the entry's (count << 7), mbcnt rank, ds_write_b16 into the staging buffer, x >>= 16, exec restored (`emit` above) --
+    // and the loads are plain loads the compiler tracks, issued right behind the block (behind the buffer store in the
+    // LDS queue).
     ET E0 = entry_at(row_addr_cnt<NIB, 31, NT>(w, col));
     ET E1 = entry_at(row_addr_cnt<NIB, 30, NT>(w, col));
     ET E2 = entry_at(row_addr_cnt<NIB, 29, NT>(w, col));
