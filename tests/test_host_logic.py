@@ -449,3 +449,36 @@ def test_scratch_of_the_hot_kernels_is_what_design_md_says():
         assert v["ScratchSize"] == 0, (name, v)
     for name, v in one("k_encode_fused").items():
         assert v["LDS Size"] * 4 <= 160 * 1024, (name, v)   # four workgroups per CU
+
+
+def test_prefix_hash_chain_kept_between_calls_gives_the_same_digests():
+    """Round 5: _prefix_hashes_of keeps the last call's token bytes and digests and resumes the SHA-256 chain at the first
+    chunk that differs (lookup / retrieve / store of one prompt, the next turn of a conversation).  Whatever the overlap
+    with the previous call -- none, a prefix of whole chunks, a change inside a chunk, a shorter or longer prompt, another
+    chunk size in between -- the digests are those of the reference's chain (cache_engine.py:58-96)."""
+    import hashlib
+    import random
+    from lmcache_amd.cache_engine import LMCacheEngine
+    e = LMCacheEngine.__new__(LMCacheEngine)
+
+    def plain(toks, cs):
+        r, out = "", []
+        for s0 in range(0, len(toks), cs):
+            r = hashlib.sha256(r.encode("ascii") + toks[s0:s0 + cs].numpy().tobytes()).hexdigest()
+            out.append(r)
+        return out
+    rnd = random.Random(3)
+    base = torch.randint(0, 32000, (3000,))
+    for trial in range(150):
+        e.chunk_size = rnd.choice([256, 256, 256, 100])
+        n = rnd.randint(1, 4000)
+        t = torch.randint(0, 32000, (n,))
+        k = rnd.randint(0, min(n, len(base)))
+        t[:k] = base[:k]
+        if rnd.random() < 0.3:
+            t[rnd.randrange(n)] += 1
+        assert e._prefix_hashes_of(t) == plain(t, e.chunk_size), trial
+        skip = rnd.randint(0, 3)
+        assert e._prefix_hashes_of(t, skip) == plain(t, e.chunk_size)[skip:], trial
+        if rnd.random() < 0.5:
+            base = t.clone()
