@@ -564,10 +564,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
           if (active) *((LMC_GLOBAL int8_t*)(ubase + (u64)(t0 + i) * a.C) + lane_off) = (int8_t)sym;
         } else {
           const float scale = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), (int)i));
-          const float val = lv * scale;
+          float val = lv * scale;
           u16 bits;
           if (DT_OUT == LMC_DTYPE_BF16) bits = __builtin_bit_cast(unsigned short, (__bf16)val);  // v_cvt_pk_bf16_f32, RNE
-          else bits = (u16)f2fp16(val);
+          else {
+            // The product is rounded to fp32 FIRST and to fp16 second, as the reference does (x = xq / C * max1 in fp32,
+            // then .to(float16): cachegen_decoder.py:20, 190-200).  Left to itself the compiler fuses the two into ONE
+            // v_fma_mixlo_f16 -- a single rounding of the exact product -- which differs by one fp16 ulp wherever the
+            // fp32-rounded product is an exact tie (0.4 % of the elements at 22 bins; round 5's random-geometry sweep
+            // found it, the 16- / 32-bin parity cases never hit a tie).  The empty asm keeps the multiply apart.
+            asm volatile("" : "+v"(val));
+            bits = (u16)f2fp16(val);
+          }
           if (PAGED) {
             const u32 olo = (u32)__builtin_amdgcn_readlane((int)(u32)tok_off2, (int)i);
             const u32 ohi = (u32)__builtin_amdgcn_readlane((int)(u32)((unsigned long long)tok_off2 >> 32), (int)i);
