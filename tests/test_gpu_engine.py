@@ -207,6 +207,50 @@ def test_chunk_sizes_below_256_through_the_engine_equal_the_oracle(backend, cs, 
         engine.close()
 
 
+def test_random_prompts_formats_and_chunk_sizes_through_the_engine_equal_the_oracle(oracle):
+    """A seeded sweep at the engine level (LMC_FUZZ_CASES geometries, default 10): format (vllm -> bf16 out, huggingface ->
+    fp16 out), chunk size, prompt length, layers, heads, tier (pinned packs / HBM blobs), a suffix mask -- store, then
+    retrieve, then every retrieved chunk equals do_dequantize(torch_quant_vectorized(x)) cast to the format's dtype."""
+    import os
+    rnd = np.random.default_rng(int(os.environ.get("LMC_FUZZ_SEED", "77")))
+    for case in range(int(os.environ.get("LMC_FUZZ_CASES", "10"))):
+        fmt = ["vllm", "huggingface"][int(rnd.integers(0, 2))]
+        cs = int(rnd.choice([256, 256, 128, 100, 64, 40, 236]))
+        backend = ["cachegen-host", "cachegen-hbm"][int(rnd.integers(0, 2))]
+        nl = int(rnd.integers(1, 5))
+        nh = int(rnd.choice([1, 2, 4, 8]))
+        hd = int(rnd.choice([64, 128]))
+        num_tokens = int(rnd.integers(1, 4 * cs + 50))
+        skip = int(rnd.integers(0, num_tokens)) if rnd.integers(0, 3) == 0 else 0
+        tokens = generate_tokens(num_tokens, "cuda")
+        kv_cache = generate_kv_cache(num_tokens, fmt, "cuda", num_layers=nl, num_heads=nh, head_size=hd)
+        tag = f"case {case}: {fmt} cs{cs} {backend} L{nl} H{nh} D{hd} T{num_tokens} skip{skip}"
+        engine = LMCacheEngine(make_cfg(backend, cs), dumb_metadata(fmt, MODEL))
+        try:
+            engine.store(tokens, kv_cache)
+            mask = None
+            if skip:
+                mask = torch.ones(num_tokens, dtype=torch.bool)
+                mask[:skip] = False
+            retrieved, ret_mask = engine.retrieve(tokens, mask)
+            assert int(ret_mask.sum()) == num_tokens - skip, tag
+            out_dt = torch.bfloat16 if fmt == "vllm" else torch.float16
+            tdim = 0 if fmt == "vllm" else 1
+            got_all = to_blob(retrieved).cpu()              # tokens skip .. num_tokens
+            for t0 in range(0, num_tokens, cs):
+                t1 = min(num_tokens, t0 + cs)
+                if t1 <= skip:
+                    continue
+                sl = (slice(t0, t1),) if tdim == 0 else (slice(None), slice(t0, t1))
+                want = oracle_roundtrip(oracle, tuple((k[sl], v[sl]) for k, v in kv_cache), fmt, MODEL, out_dt)
+                a = max(t0, skip)
+                w = want.narrow(2 if fmt == "vllm" else 3, a - t0, t1 - a)
+                g = got_all.narrow(2 if fmt == "vllm" else 3, a - skip, t1 - a)
+                assert g.dtype == out_dt and torch.equal(g, w), f"{tag}: chunk at {t0}"
+        finally:
+            engine.close()
+
+
 @pytest.mark.parametrize("fmt", ["vllm", "huggingface"])
 @pytest.mark.parametrize("backend", ["cachegen-host", "cachegen-hbm", "mem://cachegen:1", "mem://cachegenpipe:1",
                                      "xgmi://cg:1", "xgmi://cgpipe:1"])
