@@ -746,6 +746,54 @@ def test_paged_store_and_scatter_retrieve_of_independent_segments(layout, backen
         engine.close()
 
 
+def test_random_paged_caches_through_the_engine_equal_the_dense_path(oracle):
+    """A seeded sweep over the paged entry points (LMC_FUZZ_CASES, default 8): block size, block layout, chunk size,
+    segment length, heads -- store_paged from random slots of one cache, retrieve_into_paged into random slots of another,
+    and what lands there equals the dense retrieve() and, chunk by chunk, the oracle."""
+    import os
+    rnd = np.random.default_rng(int(os.environ.get("LMC_FUZZ_SEED", "31")))
+    for case in range(int(os.environ.get("LMC_FUZZ_CASES", "8"))):
+        layout = ["NHBD", "NBHD"][int(rnd.integers(0, 2))]
+        bs = int(rnd.choice([8, 16, 32]))
+        cs = int(rnd.choice([256, 128, 100, 236]))
+        nl, H, D = int(rnd.integers(1, 5)), int(rnd.choice([1, 2, 8])), int(rnd.choice([64, 128]))
+        seg = int(rnd.integers(1, 3 * cs + 20))
+        backend = ["cachegen-host", "cachegen-hbm"][int(rnd.integers(0, 2))]
+        tag = f"case {case}: {layout} bs{bs} cs{cs} L{nl} H{H} D{D} T{seg} {backend}"
+        engine = LMCacheEngine(make_cfg(backend, cs), dumb_metadata("vllm", MODEL))
+        try:
+            g = torch.Generator().manual_seed(100 + case)
+            nblocks = (seg + bs - 1) // bs + 5
+            shape = (2, nblocks, bs, H, D) if layout == "NBHD" else (2, nblocks, H, bs, D)
+            src = [torch.zeros(shape, dtype=torch.bfloat16, device="cuda") for _ in range(nl)]
+            dst = [torch.zeros(shape, dtype=torch.bfloat16, device="cuda") for _ in range(nl)]
+            slots_src = torch.randperm(nblocks * bs, generator=g)[:seg].to("cuda")
+            slots_dst = torch.randperm(nblocks * bs, generator=g)[:seg].to("cuda")
+            toks = generate_tokens(seg, "cuda")
+            kv = generate_kv_cache(seg, "vllm", "cuda", num_layers=nl, num_heads=H, head_size=D)
+            _paged_scatter(src, kv, slots_src, bs, layout)
+            engine.store_paged(toks, src, slots_src, bs, layout)
+            m = engine.retrieve_into_paged(toks, dst, slots_dst, bs, layout)
+            assert int(m.sum()) == seg, tag
+            torch.cuda.synchronize()
+            got = _paged_gather(dst, slots_dst, bs, layout)
+            dense, m2 = engine.retrieve(toks)
+            assert int(m2.sum()) == seg, tag
+            for (k, v), (k1, v1) in zip(got, dense):
+                assert torch.equal(k, k1) and torch.equal(v, v1), tag
+            for t0 in range(0, seg, cs):
+                t1 = min(seg, t0 + cs)
+                want = oracle_roundtrip(oracle, tuple((k[t0:t1], v[t0:t1]) for k, v in kv), "vllm", MODEL, torch.bfloat16)
+                have = to_blob(tuple((k[t0:t1], v[t0:t1]) for k, v in got)).cpu()
+                assert torch.equal(have, want), f"{tag}: chunk at {t0}"
+            used = torch.zeros(nblocks * bs, dtype=torch.bool, device="cuda")
+            used[slots_dst] = True
+            for k, v in _paged_gather(dst, (~used).nonzero().flatten(), bs, layout):
+                assert not k.any() and not v.any(), tag
+        finally:
+            engine.close()
+
+
 def test_hbm_cachegen_tier_and_layerwise_retrieve(oracle):
     """local_device="cuda" + local_serde="cachegen": encoded chunks stay in HBM.  retrieve_layerwise cuts the decode
     into one launch per range of layers and hands out an event per range; what it returns equals retrieve(), the
