@@ -720,7 +720,7 @@ def test_fused_encode_equals_two_kernel_encode_and_oracle(nat, ctx, oracle, shap
 
 def test_random_geometries_and_chunk_lengths_both_paths_equal_the_oracle(nat, ctx, oracle):
     """A seeded sweep over what round 5 opened up: chunk lengths 2 .. 256 (and a few above), ragged tails of any length,
-    plane widths 8 .. 1024 with partial channel groups, bins 4 .. 32 per plane, both dtypes, three data kinds -- every blob
+    plane widths 8 .. 4096 with partial channel groups, bins 4 .. 32 per plane, both dtypes, three data kinds -- every blob
     of both launch paths byte-equal to the oracle's, and the decode of the job equal to the oracle's decode.
     LMC_FUZZ_CASES (default 24) sets how many geometries are drawn, LMC_FUZZ_SEED the generator's seed.  (Round 5: the
     first run of this sweep found the fp16 output rounded once instead of twice -- a fused v_fma_mixlo_f16 -- at bin
@@ -730,7 +730,8 @@ def test_random_geometries_and_chunk_lengths_both_paths_equal_the_oracle(nat, ct
     for case in range(ncase):
         L = int(rnd.integers(1, 4))
         D = int(rnd.choice([8, 40, 64, 72, 128]))
-        H = int(rnd.integers(1, max(2, 1024 // D) + 1))
+        cmax = 4096 if rnd.integers(0, 5) == 0 else 1024  # (one geometry in five: planes wider than the fused kernel takes)
+        H = int(rnd.integers(1, max(2, cmax // D) + 1))
         cs = int(rnd.choice([2, 3, 7, 8, 31, 32, 33, 40, 64, 100, 128, 200, 236, 255, 256, 256, 300]))
         nchunk = int(rnd.integers(1, 4))
         tail = int(rnd.integers(0, cs))
