@@ -1268,7 +1268,10 @@ def ttft_hbm_tier(dev, kv, proxy, alone, meta):
                         "layerwise = retrieve_layerwise on a side stream, one k_decode launch per range of layers, the "
                         "model's layers of a range wait for that range's event (lmc_decode_chunks_layers).  "
                         "hbm_floor_ratio: the decode has to write 2.1 GB of KV and read 0.5 GB of blobs through the "
-                        "same HBM the 16 GB weight pass saturates, so no schedule gets below it in this proxy"}
+                        "same HBM the 16 GB weight pass saturates, so no schedule gets below it in this proxy.  The kernel "
+                        "timeline (profiles/r05_ttft_timeline.md) shows the floor that binds first: decoder and GEMVs do "
+                        "run side by side, but both are bound by the wave slots they hold, so what one gains the other "
+                        "loses -- (decode alone + step) / step = 1.31 plus the host's 0.2-0.3 ms in front of the first launch"}
     finally:
         engine.close()
 
