@@ -35,11 +35,13 @@ def _bits(t):
     return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
 
 
-@pytest.mark.parametrize("shape", [(4, 2148, 8, 128, 1), (2, 700, 3, 128, 0), (3, 256, 8, 128, 3)],
-                         ids=["9chunks_tail_1layer_ranges", "C384_whole", "1chunk_3layer_ranges"])
+@pytest.mark.parametrize("shape", [(4, 2148, 8, 128, 1), (2, 700, 3, 128, 0), (3, 256, 8, 128, 3),
+                                   (3, 745, 8, 128, 2, 100), (2, 520, 2, 64, 0, 128), (2, 130, 8, 128, 1, 40)],
+                         ids=["9chunks_tail_1layer_ranges", "C384_whole", "1chunk_3layer_ranges",
+                              "chunks_of_100_tail_45", "chunks_of_128_C128", "chunks_of_40_tail_10"])
 def test_store_then_load_through_the_c_abi_only(nat, oracle, shape):
-    L, T, H, D, lpr = shape
-    cs = 256
+    L, T, H, D, lpr = shape[:5]
+    cs = shape[5] if len(shape) > 5 else 256   # chunk lengths below 256 take the counts model too (round 5)
     n = (T + cs - 1) // cs
     g = torch.Generator().manual_seed(T)
     kv = torch.randn(L, 2, T, H, D, generator=g).to(torch.bfloat16)
@@ -103,14 +105,16 @@ def test_store_then_load_through_the_c_abi_only(nat, oracle, shape):
     meta.free()
 
 
-@pytest.mark.parametrize("shape", [(4, 2148, 8, 128, 1, 5), (2, 700, 3, 128, 0, 0), (3, 512, 8, 128, 2, 1)],
-                         ids=["9chunks_tail_1layer_ranges_prefix5", "C384_whole", "2chunks_prefix1"])
+@pytest.mark.parametrize("shape", [(4, 2148, 8, 128, 1, 5), (2, 700, 3, 128, 0, 0), (3, 512, 8, 128, 2, 1),
+                                   (3, 745, 8, 128, 2, 3, 100), (2, 300, 2, 64, 1, 2, 40)],
+                         ids=["9chunks_tail_1layer_ranges_prefix5", "C384_whole", "2chunks_prefix1",
+                              "chunks_of_100_tail_45_prefix3", "chunks_of_40_tail_20_C128_prefix2"])
 def test_pack_store_extract_load_through_the_c_abi_only(nat, oracle, shape):
     """lmc_store_pack / lmc_pack_extract / lmc_load_pack: the layer-major form of the pinned tier.  Every chunk
     extracted from the pack is the oracle's blob byte for byte; loading the whole pack, and a prefix of its chunks,
     range by range gives the oracle's decode; a pack region that is too small is flagged and leaves no pack."""
-    L, T, H, D, lpr, prefix = shape
-    cs = 256
+    L, T, H, D, lpr, prefix = shape[:6]
+    cs = shape[6] if len(shape) > 6 else 256
     n = (T + cs - 1) // cs
     g = torch.Generator().manual_seed(T + 1)
     kv = torch.randn(L, 2, T, H, D, generator=g).to(torch.bfloat16)
