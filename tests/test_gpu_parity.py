@@ -720,8 +720,8 @@ def test_fused_encode_equals_two_kernel_encode_and_oracle(nat, ctx, oracle, shap
 
 def test_random_geometries_and_chunk_lengths_both_paths_equal_the_oracle(nat, ctx, oracle):
     """A seeded sweep over what round 5 opened up: chunk lengths 2 .. 256 (and a few above), ragged tails of any length,
-    plane widths 8 .. 4096 with partial channel groups, bins 4 .. 32 per plane, both dtypes, three data kinds -- every blob
-    of both launch paths byte-equal to the oracle's, and the decode of the job equal to the oracle's decode.
+    plane widths 8 .. 4096 with partial channel groups, bins 4 .. 32 per plane, both dtypes, both layouts, three data kinds,
+    the job a token range inside a larger cache -- every blob of both launch paths byte-equal to the oracle's, and the decode of the job equal to the oracle's decode.
     LMC_FUZZ_CASES (default 24) sets how many geometries are drawn, LMC_FUZZ_SEED the generator's seed.  (Round 5: the
     first run of this sweep found the fp16 output rounded once instead of twice -- a fused v_fma_mixlo_f16 -- at bin
     counts the fixed parity cases do not use.)"""
@@ -749,16 +749,26 @@ def test_random_geometries_and_chunk_lengths_both_paths_equal_the_oracle(nat, ct
                 kv[l, kvi, t] = 0.0
             else:
                 kv[l, kvi, t, int(rnd.integers(0, H)), int(rnd.integers(0, D))] = float("inf") if special == 1 else float("nan")
-        lay = nat.KVLayout.from_chunk(kv.to(DEV), "vllm")
-        tag = f"case {case} (special {special}): L{L} T{Ttot} cs{cs} H{H} D{D} {dtype} {kind} bins{bins}"
-        fused, blob_dev, stride = encode_with_path(nat, ctx, "fused", lay, 0, Ttot, cs, bins)
-        two, _, _ = encode_with_path(nat, ctx, "two_kernels", lay, 0, Ttot, cs, bins)
+        # the job is a token range INSIDE a larger cache (tok_begin / dst_tok0 > 0, tokens behind it), in either layout
+        front, back = (int(v) for v in rnd.integers(0, 6, 2))
+        fmt = "vllm" if rnd.integers(0, 2) else "huggingface"
+        big = torch.full((L, 2, front + Ttot + back, H, D), 3.0, dtype=dtype)
+        big[:, :, front:front + Ttot] = kv
+        src = big.to(DEV) if fmt == "vllm" else big.permute(0, 1, 3, 2, 4).contiguous().to(DEV)
+        lay = nat.KVLayout.from_chunk(src, fmt)
+        tag = f"case {case} (special {special}): L{L} T{Ttot} cs{cs} H{H} D{D} {dtype} {kind} {fmt} +{front}/+{back} bins{bins}"
+        fused, blob_dev, stride = encode_with_path(nat, ctx, "fused", lay, front, front + Ttot, cs, bins)
+        two, _, _ = encode_with_path(nat, ctx, "two_kernels", lay, front, front + Ttot, cs, bins)
         n = (Ttot + cs - 1) // cs
         assert len(fused) == len(two) == n, tag
-        out = torch.zeros_like(kv, device=DEV)
-        ctx.decode_chunks(blob_dev.data_ptr(), stride, n, nat.KVLayout.from_chunk(out, "vllm"), 0, cs)
+        out = torch.zeros_like(src)
+        ctx.decode_chunks(blob_dev.data_ptr(), stride, n, nat.KVLayout.from_chunk(out, fmt), front, cs)
         torch.cuda.synchronize()
         assert ctx.status(clear=True) == 0, tag
+        out = out if fmt == "vllm" else out.permute(0, 1, 3, 2, 4)
+        assert not bits_np(out[:, :, :front].contiguous()).any() and not bits_np(out[:, :, front + Ttot:].contiguous()).any(), \
+            f"{tag}: the decode wrote outside its token range"
+        out = out[:, :, front:front + Ttot]
         code = oracle.BF16 if dtype == torch.bfloat16 else oracle.FP16
         for i in range(n):
             t0, t1 = i * cs, min(Ttot, (i + 1) * cs)
@@ -767,7 +777,7 @@ def test_random_geometries_and_chunk_lengths_both_paths_equal_the_oracle(nat, ct
             assert two[i] == ref, f"{tag}: two-kernel path, chunk {i}"
             assert fused[i] == ref, f"{tag}: fused setting, chunk {i}"
             want = oracle.decode_blob(ref, code)
-            got = bits_np(out[:, :, t0:t1]).reshape(L, 2, t1 - t0, H * D)
+            got = bits_np(out[:, :, t0:t1].contiguous()).reshape(L, 2, t1 - t0, H * D)
             # (NaN rows -- a NaN or 0 x inf product -- are NaN on both sides, whatever the payload bits of each cast)
             inf_bits = 0x7f80 if dtype == torch.bfloat16 else 0x7c00
             nan_w, nan_g = (want & 0x7fff) > inf_bits, (got & 0x7fff) > inf_bits
