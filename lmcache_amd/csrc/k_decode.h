@@ -337,7 +337,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   // free: every lane reads a slot (rank < 64 keeps it inside ring + mirror), the renormalising ones keep it.
   auto decode_pop = [&](u64 mask) {  // mask = lanes with x < L
     e -= (int)__popcll(mask);
-    const u32 sbase = ring_addr + (((u32)e & (DEC_RING_WORDS - 1)) << 1);   // scalar: slot of word e - cnt
+    // scalar: the slot of word e - cnt, ring_addr + 2 * (e % 256) -- as s_and + s_lshl1_add_u32 (left alone the compiler
+    // shifts, masks and adds: three scalar instructions of a token step that has fifteen)
+    u32 sbase = (u32)e & (DEC_RING_WORDS - 1);
+    asm("s_lshl1_add_u32 %0, %0, %1" : "+s"(sbase) : "s"(ring_addr) : "scc");
     // under exec = mask: rank, slot address, word, x = x << 16 | word; then exec is restored.  No branch around it
     // (an empty mask makes the four instructions no-ops) and no select afterwards.
     u32 t;
