@@ -503,21 +503,26 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
     };
     // the word append of one step: under exec = emitting lanes -- v_cmpx on the state's upper half against the entry's
     // (count << 7), mbcnt rank, ds_write_b16 into the staging buffer, x >>= 16, exec restored; also works out the
-    // address of the reciprocal of entry e2 (the main loop's pipeline) and returns the number of words
-    auto emit = [&](ET e0, ET e2, u32& ra) -> u32 {
-      u32 tt, cnt;
+    // address of the reciprocal of entry e2 (the main loop's pipeline) and moves the buffer's write address on:
+    // wb += 2 * words.  v_mbcnt reads the VCC that v_cmpx wrote: gfx950 wants two wait states in between (the compiler
+    // puts `s_nop 1` there), and the two scalar instructions the step needs anyway -- the word count and the new write
+    // address (into a second register: the append still uses the old one) -- are those two.  (Until round 5 an s_nop 0
+    // stood where the s_lshl1_add_u32 stands now and the address was moved on behind the block: one scalar instruction
+    // more per token.)
+    auto emit = [&](ET e0, ET e2, u32& ra) {
+      u32 tt, cnt, wbn;
       if constexpr (NIB) {
         asm volatile("v_lshrrev_b32_e32 %[ra], 20, %[e2]\n\t"
                      "v_cmpx_ge_u32_sdwa vcc, %[x], %[e0] src0_sel:WORD_1 src1_sel:WORD_1\n\t"
                      "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                     "s_nop 0\n\t"
+                     "s_lshl1_add_u32 %[wbn], %[cnt], %[wb]\n\t"
                      "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
                      "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
                      "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
                      "ds_write_b16 %[t], %[x]\n\t"
                      "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
                      "s_mov_b64 exec, %[full]"
-                     : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
+                     : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [wbn] "=&s"(wbn), [ra] "=&v"(ra)
                      : [e0] "v"(e0), [e2] "v"(e2), [wb] "s"(wb), [full] "s"(full_exec)
                      : "vcc", "scc", "memory");
       } else {
@@ -525,18 +530,18 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
                      "v_lshlrev_b32_sdwa %[t], 23, %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
                      "v_cmpx_ge_u32_e32 vcc, %[x], %[t]\n\t"
                      "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
-                     "s_nop 0\n\t"
+                     "s_lshl1_add_u32 %[wbn], %[cnt], %[wb]\n\t"
                      "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
                      "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
                      "v_lshl_add_u32 %[t], %[t], 1, %[wb]\n\t"
                      "ds_write_b16 %[t], %[x]\n\t"
                      "v_lshrrev_b32_e32 %[x], 16, %[x]\n\t"
                      "s_mov_b64 exec, %[full]"
-                     : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [ra] "=&v"(ra)
+                     : [x] "+v"(x), [t] "=&v"(tt), [cnt] "=&s"(cnt), [wbn] "=&s"(wbn), [ra] "=&v"(ra)
                      : [e0] "v"(e0), [e2] "v"(e2), [wb] "s"(wb), [full] "s"(full_exec)
                      : "vcc", "scc", "memory");
       }
-      return cnt;
+      wb = wbn;
     };
     u32 w[DPB], wn[DPB];
     // the last whole block (the first one coded), and in wn the partial block behind it
@@ -557,8 +562,7 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
       const ET E = entry_at(col + (sym << (NIB ? 8 : 7)));
       const u32x2_t R = rtab_of(E);
       u32 ra_unused;
-      const u32 cnt = emit(E, E, ra_unused);
-      asm("s_lshl1_add_u32 %0, %1, %0" : "+s"(wb) : "s"(cnt) : "scc");
+      emit(E, E, ra_unused);
       flush_ring();
       if constexpr (NIB) rans_put_nib(E, R.x, R.y);
       else rans_put_byte(E, R.x, R.y);
@@ -586,10 +590,9 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
         if constexpr (i >= 4) ad4 = row_addr_cnt<NIB, i - 4, NT>(w, col);
         else ad4 = row_addr_cnt<NIB, 28 + i, NT>(wn, col);
         u32 ra;
-        const u32 cnt = emit(E0, E2, ra);
+        emit(E0, E2, ra);  // (wb += 2 * words)
         const u32x2_t R2 = *(const __attribute__((address_space(3))) u32x2_t*)(size_t)(rtab_addr + ra);
         const ET E4 = entry_at(ad4);
-        asm("s_lshl1_add_u32 %0, %1, %0" : "+s"(wb) : "s"(cnt) : "scc");  // wb += 2 * cnt
 #ifndef LMC_FLUSH_EVERY
 #define LMC_FLUSH_EVERY 2  // tokens between two tests of the staging buffer (1 or 2: the buffer holds 128 + 2 x 64 words)
 #endif
