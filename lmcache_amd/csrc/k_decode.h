@@ -592,8 +592,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
         }
       };
       // (four tokens per trip -- the back edge is a taken scalar branch per token -- measured the same within the box
-      // noise in round 5: 0.894 - 0.911 against 0.903 - 0.962 ms, alternating builds; the decoder's VALU pipes are 98 %
-      // busy and a scalar branch costs it nothing)
+      // noise in round 5, twice: 0.894 - 0.911 against 0.903 - 0.962 ms, and over eight alternations of the two builds
+      // medians of 0.906 against 0.914 while the UNCHANGED encoder of the same two libraries differed by as much;
+      // the decoder's VALU pipes are 98 % busy and a scalar branch costs it nothing)
       for (u32 i = 0; i < nt; i++) one_token(i);
     }
   };
