@@ -71,16 +71,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   __shared__ __attribute__((aligned(16))) u8 lds_all[4 * (DEC_LUT_BYTES + DEC_WAVE_BYTES)];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform -> SGPRs
-  const long long gid = (long long)blockIdx.x * 4 + wave;
+  // (32-bit work-item arithmetic: lmc_api.hip rejects a launch of 2^31 streams or more, and a 64-bit division costs
+  // more than a hundred instructions per stream)
+  const u32 gid = blockIdx.x * 4u + (u32)wave;
   const int n = 2 * a.layer_count * a.G;  // streams of a chunk in this launch
-  if (gid >= (long long)a.nchunks * n) return;
+  if (gid >= (u32)a.nchunks * (u32)n) return;
   u8* wl = lds_all + 4 * DEC_LUT_BYTES + wave * DEC_WAVE_BYTES;
   u16* cdfT = reinterpret_cast<u16*>(wl);                           // [33][64]: entry-major, bank = lane/2
   u16* ring = reinterpret_cast<u16*>(wl + DEC_CDF_BYTES);           // stream words, word j at slot j % 256; slots 256..319 mirror 0..63
   float* lut = reinterpret_cast<float*>(lds_all + wave * DEC_LUT_BYTES);  // (q - C) / C
 
-  const int chunk = (int)(gid / n);
-  const int r = (int)(gid - (long long)chunk * n);
+  const int chunk = (int)(gid / (u32)n);
+  const int r = (int)(gid - (u32)chunk * (u32)n);
   const int pidx = r / a.G, g = r - pidx * a.G;
   // K planes of the layer range first, then their V planes (plane p = kv * L + layer)
   const int p = pidx < a.layer_count ? a.layer_begin + pidx : (a.P >> 1) + a.layer_begin + pidx - a.layer_count;

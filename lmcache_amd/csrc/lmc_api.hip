@@ -513,6 +513,8 @@ static int decode_common(lmc_ctx* c, const void* blobs, uint64_t blob_stride, in
   a.blob_ptrs = nullptr; a.layer_begin = 0; a.layer_count = L;
   a.seg_off = nullptr; a.seg_streams = nullptr; a.seg_n = 0;
   a.P = 2 * L; a.C = H * D; a.G = (a.C + 63) / 64;
+  // k_decode numbers its streams (chunk, plane, group) in 32 bits: 2^31 of them would be > 10^11 tokens in one call
+  if ((long long)nchunks * a.P * a.G >= (1ll << 31)) return LMC_ERR_INVALID;
   a.status = job_status ? job_status : c->status_h;
   return LMC_OK;
 }
