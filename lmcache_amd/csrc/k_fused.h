@@ -183,6 +183,10 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
 #pragma unroll
         for (int r = 0; r < 2; r++) {
           const u32 w[4] = {v[r][it].x, v[r][it].y, v[r][it].z, v[r][it].w};
+          // (the test stays inside the loops over runs and rows -- a wave-uniform test and two taken scalar branches per run
+          // and row, the regular path jumping over the special-row code.  ONE branch around the whole pair's conversions
+          // was built in round 5: the scheduler then interleaves both runs and both rows of the straight-line regular path
+          // and the kernel spills 184 bytes per lane instead of 20.)
           if (slow == 0u) {
             const f32x2_t f2 = {factor[r], factor[r]};
 #pragma unroll
