@@ -251,12 +251,16 @@ __device__ __forceinline__ void counts_table_byte_pk(const u32 (&mp)[8], u16* ta
 // active lanes can emit -- S = sum of lmc_counts_bits over a lane's model counts (`bits` = the workgroup's LDS copy),
 // lmc_counts_lane_words(S) words per lane -- + the 64 states.  Wave g == 0 also writes the checksum of the plane's
 // scales.  The slice is free again on return.
-template <bool ALIGNED = false>
+// PLANE (round 6, k_fused.h): the counters are already there -- the plane's histogram was taken while the plane was
+// quantised, into the workgroup's eight table slices at LDS address 0 (k_fused.h: quantize_oct_hist has the layout):
+// the lane reads its channel's 16 / 32 counters instead of 32 / 64 workspace dwords, and its slice is not touched.
+template <bool ALIGNED = false, bool PLANE = false>
 __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const CountsStream& s, u32* tabmem,
                                                   const u32* bits,
                                                   int lane, CountsState& cs) {
   typedef __attribute__((address_space(3))) u32* lds_u32w;
   typedef const __attribute__((address_space(3))) u16* lds_u16p;
+  typedef const __attribute__((address_space(3))) u8* lds_u8p;
   const int Tc = __builtin_amdgcn_readfirstlane(s.T);  // 2 .. 256, wave-uniform (said so: the loops below run on scalar counters)
   const u32 tab_addr = (u32)(size_t)(lds_u32w)tabmem;
   if (ALIGNED && (tab_addr & 0xfffu)) __builtin_trap();  // (wave-uniform: the layout is static)
@@ -299,8 +303,27 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
       __hip_atomic_fetch_add((lds_u32w)(size_t)ad, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
   };
-  if (s.nib) pass1(BoolTag<true>{});
-  else pass1(BoolTag<false>{});
+  // PLANE: the channel of this lane, c = 64 g + lane, was quantised by lane qx = (c % 512) / 8 as element e = c % 8 of
+  // its channel run it = c / 512
+  const u32 qx = (((u32)s.g & 7u) << 3) + ((u32)lane >> 3), qe = (u32)lane & 7u, qit = (u32)s.g >> 3;
+  u32 ph = 0;  // LDS byte address of this lane's counter of symbol 0 (rows of 256 B)
+  if constexpr (PLANE) {
+    if (s.nib) {
+      ph = (qit * 4u + (qe >> 1)) * 4096u + 4u * qx + 2u * (qe & 1u);
+    } else {
+      ph = (qit * 2u + (qe >> 2)) * 8192u + 4u * qx + (qe & 3u);
+      // token 0 of the chunk was left out of the counters (so that none of them can reach 256 and carry into its
+      // neighbour): add it now, unless its counter stands at 255 -- a constant channel, whose count is stored as 255 anyway
+      const u32 sym0 = s.active ? (s.symq[0] & 0xffu) : 0u;
+      const u32 a0 = ph + (sym0 << 8);
+      const u32 c0 = (u32) * (lds_u8p)(size_t)a0;
+      if (s.active && c0 != 255u)
+        __hip_atomic_fetch_add((lds_u32w)(size_t)(a0 & ~3u), 1u << (8u * (a0 & 3u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  } else {
+    if (s.nib) pass1(BoolTag<true>{});
+    else pass1(BoolTag<false>{});
+  }
   wave_lds_fence();  // every lane's ds_add has landed
 
   if (s.g == 0) {  // one wave per (chunk, plane): checksum of the plane's scales (written by the quantise stage)
@@ -326,8 +349,13 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
     else
       asm("v_min_u32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(cs.pk[i >> 2]) : "v"(c), "v"(cap));
   };
-  if (s.nib) static_for<16>([&](auto itag) { put(itag, tabmem[decltype(itag)::value * 64 + lane]); });
-  else static_for<32>([&](auto itag) { put(itag, (u32)tab16[decltype(itag)::value * 64 + lane]); });
+  if constexpr (PLANE) {
+    if (s.nib) static_for<16>([&](auto itag) { put(itag, (u32) * (lds_u16p)(size_t)(ph + 256u * decltype(itag)::value)); });
+    else static_for<32>([&](auto itag) { put(itag, (u32) * (lds_u8p)(size_t)(ph + 256u * decltype(itag)::value)); });
+  } else {
+    if (s.nib) static_for<16>([&](auto itag) { put(itag, tabmem[decltype(itag)::value * 64 + lane]); });
+    else static_for<32>([&](auto itag) { put(itag, (u32)tab16[decltype(itag)::value * 64 + lane]); });
+  }
   wave_lds_fence();  // the counters are dead: every lane holds its counts
   head_or_counts<8>(cs.pk, cs.wor);
   cs.head = head_bytes_of<8, 8>(cs.wor, s.R);

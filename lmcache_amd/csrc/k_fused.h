@@ -232,13 +232,212 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
   }
 }
 
+// ---- the plane's histogram taken WHILE it is quantised (round 6) ------------------------------------------------------
+// Pass 1 used to read every symbol back from the workspace only to count it: one of the symbols' two re-reads
+// (0.64 GB of the fused kernel's 4.6 GB of fabric traffic per 16 k context).  For planes of 257 .. 1024 channels
+// (GL == 64: one plane per work item) the quantising waves now count the symbols they hold in registers into ONE
+// histogram of the whole plane, which lives in the workgroup's eight 4 KiB table slices (idle until pass 2):
+//   <= 16 symbols  u16 counters; slice b = it * 4 + e / 2 is [16 symbols][64 lanes] dwords, lane = the QUANTISING lane
+//                  (channel (it * 64 + lane) * 8 + e), half e & 1: a wave's 64 lanes hit 64 banks, and a nibble that
+//                  sits at bits 8 .. 11 of its dword is a row address by one v_and_or_b32 (the slices are 4 KiB aligned)
+//   more symbols   u8 counters; block b = it * 2 + e / 4 is [32 symbols][64 lanes] dwords, byte e & 3.  Token 0 of the
+//                  chunk is left out, so a counter holds at most T - 1 <= 255 and never carries into its neighbour;
+//                  pass 1 adds the token back (counts_from_plane_hist).
+// The counters are LDS atomics (eight waves add into the same plane); pass 1 then reads 16 / 32 counters per lane instead
+// of 32 / 64 workspace dwords and 256 ds_add of its own.  The instruction count is the same (2 VALU + 1 ds_add per
+// symbol, moved from pass 1 into phase A); the symbols are read once, by pass 2.
+// Nibble planes pair rows (q, q + 4) -- the two tokens that share a byte of the workspace dword -- instead of parking
+// the first row quad in the table slice: the slices are the histogram now.  The high row costs one v_lshl_or_b32 per
+// element more than the byte insert of v_cvt_pk_u8_f32 alone.
+#ifndef LMC_FUSED_HIST_A
+#define LMC_FUSED_HIST_A 1
+#endif
+#ifndef LMC_FUSED_HIST_A_BYTE
+#define LMC_FUSED_HIST_A_BYTE 1  // ... for the planes with more than 16 symbols as well
+#endif
+#define PLANE_HIST_DWORDS 8192
+
+// one histogram add of the plane: counter row `sym` of the lane's column, `field` = the symbol moved to bits 8 .. 12
+template <int OFF>
+__device__ __forceinline__ void plane_hist_add(u32 ad, u32 val) {
+  typedef __attribute__((address_space(3))) u32* lds_u32w;
+  __hip_atomic_fetch_add((lds_u32w)(size_t)(ad + (u32)OFF), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// LDS byte address of counter row (bits POS .. POS + WIDTH of w) of the lane's column lane4 (= 4 * lane: the histogram
+// starts at LDS address 0 -- checked -- and rows are 256 B): one instruction when the field already sits at bit 8
+template <int POS, int WIDTH>
+__device__ __forceinline__ u32 plane_hist_row(u32 w, u32 lane4) {
+  constexpr u32 MASK = ((1u << WIDTH) - 1u) << 8;
+  u32 r;
+  if constexpr (POS == 8) asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(MASK), "v"(lane4));
+  else if constexpr (POS > 8) asm("v_lshrrev_b32_e32 %0, %2, %1\n\tv_and_or_b32 %0, %0, %3, %4" : "=&v"(r) : "v"(w), "n"(POS - 8), "s"(MASK), "v"(lane4));
+  else asm("v_lshlrev_b32_e32 %0, %2, %1\n\tv_and_or_b32 %0, %0, %3, %4" : "=&v"(r) : "v"(w), "n"(8 - POS), "s"(MASK), "v"(lane4));
+  return r;
+}
+
+// quantize_oct_fused with the histogram: one row oct by one wave, symbols to the workspace AND into the plane's counters.
+// skip0: the oct holds token 0 of the chunk (byte planes leave it out of the counters).
+template <int NITER, int DT, bool NIB, bool FULL, bool ALLROWS>
+__device__ __forceinline__ void quantize_oct_hist(const KvAddr& src, const u16* pbase, int tok0, int Tc, int t_first,
+                                                  bool q1valid, bool skip0, int C, float maxf, u32* sym_out, u16* scale_out,
+                                                  int lane) {
+  long long coff[NITER];
+  int c0[NITER];
+  bool cval[NITER];
+#pragma unroll
+  for (int it = 0; it < NITER; it++) {
+    c0[it] = (it * 64 + lane) * 8;
+    cval[it] = FULL || c0[it] < C;
+    const int h = c0[it] / src.D, d = c0[it] - h * src.D;
+    coff[it] = (long long)h * src.stride_head + d;
+  }
+  const f32x2_t maxf2 = {maxf, maxf};
+  const u32 lane4 = 4u * (u32)lane;
+  u32 o[NITER][8];  // NIB: the oct's workspace dwords (byte q = token q | token q + 4 << 4); else one row quad's (byte r = token 4 hq + r)
+  auto hist_dword = [&](auto it_tag, auto e_tag, auto hq_tag, u32 od) {
+    constexpr int it = decltype(it_tag)::value, e = decltype(e_tag)::value, hq = decltype(hq_tag)::value;
+    if constexpr (NIB) {
+      constexpr int OFF = (it * 4 + e / 2) * 4096;
+      const u32 val = (e & 1) ? 0x10000u : 1u;
+      static_for<8>([&](auto ktag) {
+        constexpr int row = decltype(ktag)::value;             // token of the oct
+        constexpr int POS = 8 * (row & 3) + 4 * (row >> 2);
+        if (ALLROWS || t_first + row < Tc) plane_hist_add<OFF>(plane_hist_row<POS, 4>(od, lane4), val);  // (wave-uniform test)
+      });
+    } else {
+      constexpr int OFF = (it * 2 + e / 4) * 8192;
+      const u32 val = 1u << (8 * (e & 3));
+      static_for<4>([&](auto ktag) {
+        constexpr int k = decltype(ktag)::value;
+        constexpr int row = 4 * hq + k;
+        const bool count = (ALLROWS || t_first + row < Tc) && !(row == 0 && skip0);  // wave-uniform
+        if (count) plane_hist_add<OFF>(plane_hist_row<8 * k, 5>(od, lane4), val);
+      });
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    // the pair's rows: NIB (q, q + 4); else (2q, 2q + 1), i.e. rows r0, r0 + 1 of quad hq
+    const int rowi[2] = {NIB ? q : 2 * q, NIB ? q + 4 : 2 * q + 1};
+    uint4 v[2][NITER];
+    bool tv[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int t = t_first + rowi[r];
+      tv[r] = ALLROWS || t < Tc;
+      const u16* rowp = pbase + (tv[r] ? lmc_tok_off(src, tok0 + t) : 0);
+#pragma unroll
+      for (int it = 0; it < NITER; it++) {
+        if (tv[r] && (FULL || cval[it])) v[r][it] = ld_global_u4_nt(rowp + coff[it]);  // streamed once
+        else v[r][it] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    u32 mrow[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      u32 m = 0;
+#pragma unroll
+      for (int it = 0; it < NITER; it++) {
+        m = pk_max_u16(m, v[r][it].x & 0x7fff7fffu);
+        m = pk_max_u16(m, v[r][it].y & 0x7fff7fffu);
+        m = pk_max_u16(m, v[r][it].z & 0x7fff7fffu);
+        m = pk_max_u16(m, v[r][it].w & 0x7fff7fffu);
+      }
+      mrow[r] = max(m & 0xffffu, m >> 16);
+    }
+    wave_max2_u32(mrow[0], mrow[1]);  // wave-uniform from here on
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+        if (tv[r]) scale_out[rowi[r]] = (u16)mrow[r];
+    }
+    float factor[2];
+    bool special[2] = {false, false};
+    u32 slow = 0;  // (an integer: see quantize_oct_fused)
+    const bool short_div = LMC_SHORT_ROW_DIV && row_div_in_range(mrow[0], DT) && row_div_in_range(mrow[1], DT);
+    if (short_div) {
+#pragma unroll
+      for (int r = 0; r < 2; r++) factor[r] = row_div_short(maxf, h2f_rt(mrow[r], DT));
+    } else {
+      bool any_special = false;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const float sf = h2f_rt(mrow[r], DT);
+        factor[r] = maxf / sf;  // IEEE fp32 division (lmc_device.h)
+        special[r] = !(__builtin_fabsf(factor[r]) < __builtin_inff()) || !(sf < __builtin_inff());
+        any_special |= special[r];
+      }
+      slow = __ballot(any_special) != 0 ? 1u : 0u;  // wave-uniform and rare
+    }
+#pragma unroll
+    for (int it = 0; it < NITER; it++) {
+      if (!FULL && !cval[it]) continue;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const u32 w[4] = {v[r][it].x, v[r][it].y, v[r][it].z, v[r][it].w};
+        // byte of the element's dword, and whether this row is the first to write the dword / its high nibble
+        const int bpos = NIB ? q : (2 * q + r) & 3;
+        const bool fresh = NIB ? (q == 0 && r == 0) : bpos == 0;
+        const bool high = NIB && r == 1;
+        if (slow == 0u) {
+          const f32x2_t f2 = {factor[r], factor[r]};
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const f32x2_t z = quant_z2(h_lo<DT>(w[k]), h_hi<DT>(w[k]), f2, maxf2);
+            if (high) {
+              o[it][2 * k] = (__builtin_amdgcn_cvt_pk_u8_f32(z.x, bpos, 0u) << 4) | o[it][2 * k];
+              o[it][2 * k + 1] = (__builtin_amdgcn_cvt_pk_u8_f32(z.y, bpos, 0u) << 4) | o[it][2 * k + 1];
+            } else {
+              o[it][2 * k] = __builtin_amdgcn_cvt_pk_u8_f32(z.x, bpos, fresh ? 0u : o[it][2 * k]);
+              o[it][2 * k + 1] = __builtin_amdgcn_cvt_pk_u8_f32(z.y, bpos, fresh ? 0u : o[it][2 * k + 1]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float xl = h_lo<DT>(w[k]), xh = h_hi<DT>(w[k]);
+            const u32 sl_ = (special[r] ? quant_special(xl, factor[r], maxf) : quant_fast(xl, factor[r], maxf)) & 0xffu;
+            const u32 sh_ = (special[r] ? quant_special(xh, factor[r], maxf) : quant_fast(xh, factor[r], maxf)) & 0xffu;
+            o[it][2 * k] = (fresh ? 0u : o[it][2 * k]) | sl_ << (8 * bpos + (high ? 4 : 0));
+            o[it][2 * k + 1] = (fresh ? 0u : o[it][2 * k + 1]) | sh_ << (8 * bpos + (high ? 4 : 0));
+          }
+        }
+      }
+    }
+    if (NIB ? q == 3 : (q & 1) == 1) {  // the oct's (NIB) / the quad's dwords are complete: to the workspace, into the counters
+      const int hq = NIB ? 0 : q >> 1;
+#pragma unroll
+      for (int it = 0; it < NITER; it++) {
+        if (!FULL && !cval[it]) continue;
+        if (!NIB && hq == 1 && !q1valid) continue;
+        u32* dst = sym_out + (NIB ? 0ll : (long long)hq * C) + c0[it];  // (byte planes: the oct's row quads are adjacent [quad][channel] rows)
+        *reinterpret_cast<uint4*>(dst) = make_uint4(o[it][0], o[it][1], o[it][2], o[it][3]);
+        *reinterpret_cast<uint4*>(dst + 4) = make_uint4(o[it][4], o[it][5], o[it][6], o[it][7]);
+      }
+      static_for<NITER>([&](auto it_tag) {
+        constexpr int it = decltype(it_tag)::value;
+        if (FULL || cval[it]) {
+          static_for<8>([&](auto e_tag) {
+            constexpr int e = decltype(e_tag)::value;
+            if (q < 2) hist_dword(it_tag, e_tag, IntTag<0>{}, o[it][e]);
+            else hist_dword(it_tag, e_tag, IntTag<1>{}, o[it][e]);
+          });
+        }
+      });
+    }
+  }
+}
+
 template <int GL, int NITER, int DT, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_fused(FusedArgs fa) {
   static_assert(GL == 64 || NITER == 1, "narrow planes: one channel run per lane");
   const EncodeArgs& a = fa.e;
   // (4 KiB aligned, the 4 KiB table slices first: every slice starts at a multiple of 4 KiB, which the row addressing
   // of the counts coder uses -- row_addr_cnt ALIGNED)
-  __shared__ __attribute__((aligned(4096))) u32 lds_all[NW * (CNT_TAB_DWORDS + CNT_RING_DWORDS)];  // the tables, then the staging buffers
+  // (GL == 64: the eight slices together are the plane's histogram during phase A and pass 1 -- PLANE_HIST_DWORDS, at LDS
+  // address 0: plane_hist_row)
+  constexpr bool HISTA = LMC_FUSED_HIST_A && GL == 64 && NW * CNT_TAB_DWORDS == PLANE_HIST_DWORDS;
+  __shared__ __attribute__((aligned(HISTA ? 32768 : 4096))) u32 lds_all[NW * (CNT_TAB_DWORDS + CNT_RING_DWORDS)];  // the tables, then the staging buffers
   __shared__ __attribute__((aligned(16))) u32 rtab_lds[RTAB_LDS_DWORDS];  // reciprocals of the counts model's frequencies, bound table
   __shared__ u32 st_alloc[FUSED_MAX_NS];  // allocation of the item's group streams
   __shared__ u32 wg_excl;
@@ -257,6 +456,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   u16* const ring = reinterpret_cast<u16*>(lds_all + NW * CNT_TAB_DWORDS + wave * CNT_RING_DWORDS);  // ... and staging buffer
 
   rtab_to_lds(rtab_lds);  // visible to the coder waves behind the barrier that ends phase A
+  // the item's plane takes its histogram while it is quantised (wave-uniform per item: GL == 64 items are one plane)
+  bool hist_a = false;
+  if constexpr (HISTA) {
+    typedef __attribute__((address_space(3))) u32* lds_u32w;
+    if ((u32)(size_t)(lds_u32w)lds_all != 0u) __builtin_trap();  // (static layout: plane_hist_row builds addresses from 0)
+    const int bins0 = (int)a.bins.b[p0];
+    hist_a = LMC_FUSED_HIST_A_BYTE || lmc_sym_nibbles(bins0);
+    if (hist_a) {
+      uint4* z = reinterpret_cast<uint4*>(lds_all);
+#pragma unroll
+      for (int i = 0; i < PLANE_HIST_DWORDS / 4 / (64 * NW); i++) z[i * 64 * NW + threadIdx.x] = make_uint4(0, 0, 0, 0);
+      __syncthreads();  // (every wave adds everywhere)
+    }
+  }
   // A size word of 0 says "this chunk's encode did not finish" to whoever reads the words next (k_offload, k_pack_scan,
   // the host).  The workgroup that will write the chunk's size clears the word of whatever job used it before -- the
   // SAME workgroup, so that both stores pass through one XCD's L2 in program order (clearing from the chunk's first
@@ -304,7 +517,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       for (int oct = wave; oct < TO; oct += NW) {
         const bool q1valid = 2 * oct + 1 < a.TQ;
         const bool allrows = oct * 8 + 8 <= Tc;  // wave-uniform: false only for the last oct of a chunk of 8 k + r tokens
-        if (!allrows) {  // (the variant with per-lane channel validity takes the per-row test as well: two instances, not four)
+        if (HISTA && hist_a) {
+          // round 6: symbols to the workspace AND into the plane's counters (quantize_oct_hist)
+          u32* const so = sym_pc + (long long)oct * (nib ? 1 : 2) * a.C;
+          if (!allrows) {
+            if (nib) quantize_oct_hist<NITER, DT, true, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+            else quantize_oct_hist<NITER, DT, false, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+          } else if (full) {
+            if (nib) quantize_oct_hist<NITER, DT, true, true, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+            else quantize_oct_hist<NITER, DT, false, true, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+          } else if (nib) quantize_oct_hist<NITER, DT, true, false, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+          else quantize_oct_hist<NITER, DT, false, false, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+        } else if (!allrows) {  // (the variant with per-lane channel validity takes the per-row test as well: two instances, not four)
           if (nib)
             quantize_oct_fused<NITER, DT, true, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
                                                               sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
@@ -340,7 +564,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   auto pass1 = [&](int j, CountsState& cs) {
     if (j < NS) {  // wave-uniform
       const CountsStream s = stream_of(j);
-      const u32 alloc = counts_hist_stream<true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
+      u32 alloc;
+      if (HISTA && hist_a) alloc = counts_hist_stream<true, true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);  // the counters are there
+      else alloc = counts_hist_stream<true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
       if (lane == 0) st_alloc[j] = alloc;
     }
   };
