@@ -263,17 +263,21 @@ __device__ __forceinline__ void plane_hist_add(u32 ad, u32 val) {
   typedef __attribute__((address_space(3))) u32* lds_u32w;
   __hip_atomic_fetch_add((lds_u32w)(size_t)(ad + (u32)OFF), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// LDS byte address of counter row (bits POS .. POS + WIDTH of w) of the lane's column lane4 (= 4 * lane: the histogram
-// starts at LDS address 0 -- checked -- and rows are 256 B): one instruction when the field already sits at bit 8
-template <int POS, int WIDTH>
-__device__ __forceinline__ u32 plane_hist_row(u32 w, u32 lane4) {
-  constexpr u32 MASK = ((1u << WIDTH) - 1u) << 8;
-  u32 r;
-  if constexpr (POS == 8) asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(MASK), "v"(lane4));
-  else if constexpr (POS > 8) asm("v_lshrrev_b32_e32 %0, %2, %1\n\tv_and_or_b32 %0, %0, %3, %4" : "=&v"(r) : "v"(w), "n"(POS - 8), "s"(MASK), "v"(lane4));
-  else asm("v_lshlrev_b32_e32 %0, %2, %1\n\tv_and_or_b32 %0, %0, %3, %4" : "=&v"(r) : "v"(w), "n"(8 - POS), "s"(MASK), "v"(lane4));
-  return r;
-}
+// LDS byte address of a symbol's counter row in the lane's column: `ad` holds 4 * lane in byte 0 (the histogram starts
+// at LDS address 0 -- checked -- and rows are 256 B), and ONE SDWA instruction writes the symbol into byte 1 and keeps
+// the rest (dst_unused:UNUSED_PRESERVE): the low nibble of byte K of w (v_and 15), its high nibble (v_lshrrev 4), or
+// the whole byte (a byte plane's symbol is < 32).  (Shift + v_and_or_b32 takes two.)
+#define LMC_HIST_ROW_OP(NAME, OPSTR)                                                                                     \
+  template <int K>                                                                                                      \
+  __device__ __forceinline__ void NAME(u32& ad, u32 w) {                                                                \
+    if constexpr (K == 0) asm(OPSTR " dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0" : "+v"(ad) : "v"(w)); \
+    else if constexpr (K == 1) asm(OPSTR " dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_1" : "+v"(ad) : "v"(w)); \
+    else if constexpr (K == 2) asm(OPSTR " dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2" : "+v"(ad) : "v"(w)); \
+    else asm(OPSTR " dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3" : "+v"(ad) : "v"(w)); \
+  }
+LMC_HIST_ROW_OP(hist_row_lo, "v_and_b32_sdwa %0, 15, %1")      // byte 1 = byte K of w & 15
+LMC_HIST_ROW_OP(hist_row_hi, "v_lshrrev_b32_sdwa %0, 4, %1")   // byte 1 = byte K of w >> 4
+LMC_HIST_ROW_OP(hist_row_byte, "v_or_b32_sdwa %0, 0, %1")      // byte 1 = byte K of w
 
 // quantize_oct_fused with the histogram: one row oct by one wave, symbols to the workspace AND into the plane's counters.
 // skip0: the oct holds token 0 of the chunk (byte planes leave it out of the counters).
@@ -294,15 +298,19 @@ __device__ __forceinline__ void quantize_oct_hist(const KvAddr& src, const u16* 
   const f32x2_t maxf2 = {maxf, maxf};
   const u32 lane4 = 4u * (u32)lane;
   u32 o[NITER][8];  // NIB: the oct's workspace dwords (byte q = token q | token q + 4 << 4); else one row quad's (byte r = token 4 hq + r)
+  u32 ad[2] = {lane4, lane4};  // two address registers in turn: a symbol's SDWA write does not wait for the previous ds_add's read
   auto hist_dword = [&](auto it_tag, auto e_tag, auto hq_tag, u32 od) {
     constexpr int it = decltype(it_tag)::value, e = decltype(e_tag)::value, hq = decltype(hq_tag)::value;
     if constexpr (NIB) {
       constexpr int OFF = (it * 4 + e / 2) * 4096;
       const u32 val = (e & 1) ? 0x10000u : 1u;
       static_for<8>([&](auto ktag) {
-        constexpr int row = decltype(ktag)::value;             // token of the oct
-        constexpr int POS = 8 * (row & 3) + 4 * (row >> 2);
-        if (ALLROWS || t_first + row < Tc) plane_hist_add<OFF>(plane_hist_row<POS, 4>(od, lane4), val);  // (wave-uniform test)
+        constexpr int row = decltype(ktag)::value;             // token of the oct: byte row & 3, high nibble from row 4 on
+        if (ALLROWS || t_first + row < Tc) {                   // (wave-uniform test)
+          if constexpr (row < 4) hist_row_lo<row & 3>(ad[row & 1], od);
+          else hist_row_hi<row & 3>(ad[row & 1], od);
+          plane_hist_add<OFF>(ad[row & 1], val);
+        }
       });
     } else {
       constexpr int OFF = (it * 2 + e / 4) * 8192;
@@ -311,7 +319,10 @@ __device__ __forceinline__ void quantize_oct_hist(const KvAddr& src, const u16* 
         constexpr int k = decltype(ktag)::value;
         constexpr int row = 4 * hq + k;
         const bool count = (ALLROWS || t_first + row < Tc) && !(row == 0 && skip0);  // wave-uniform
-        if (count) plane_hist_add<OFF>(plane_hist_row<8 * k, 5>(od, lane4), val);
+        if (count) {
+          hist_row_byte<k>(ad[k & 1], od);
+          plane_hist_add<OFF>(ad[k & 1], val);
+        }
       });
     }
   };
@@ -385,8 +396,10 @@ __device__ __forceinline__ void quantize_oct_hist(const KvAddr& src, const u16* 
           for (int k = 0; k < 4; k++) {
             const f32x2_t z = quant_z2(h_lo<DT>(w[k]), h_hi<DT>(w[k]), f2, maxf2);
             if (high) {
-              o[it][2 * k] = (__builtin_amdgcn_cvt_pk_u8_f32(z.x, bpos, 0u) << 4) | o[it][2 * k];
-              o[it][2 * k + 1] = (__builtin_amdgcn_cvt_pk_u8_f32(z.y, bpos, 0u) << 4) | o[it][2 * k + 1];
+              // (opaque: left to itself the compiler re-associates the four high rows of a dword into an accumulator of
+              // their own -- 16 more live registers, spilled -- and merges at the end)
+              asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(o[it][2 * k]) : "v"(__builtin_amdgcn_cvt_pk_u8_f32(z.x, 0, 0u)), "n"(8 * bpos + 4));
+              asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(o[it][2 * k + 1]) : "v"(__builtin_amdgcn_cvt_pk_u8_f32(z.y, 0, 0u)), "n"(8 * bpos + 4));
             } else {
               o[it][2 * k] = __builtin_amdgcn_cvt_pk_u8_f32(z.x, bpos, fresh ? 0u : o[it][2 * k]);
               o[it][2 * k + 1] = __builtin_amdgcn_cvt_pk_u8_f32(z.y, bpos, fresh ? 0u : o[it][2 * k + 1]);
@@ -462,7 +475,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     typedef __attribute__((address_space(3))) u32* lds_u32w;
     if ((u32)(size_t)(lds_u32w)lds_all != 0u) __builtin_trap();  // (static layout: plane_hist_row builds addresses from 0)
     const int bins0 = (int)a.bins.b[p0];
-    hist_a = LMC_FUSED_HIST_A_BYTE || lmc_sym_nibbles(bins0);
+    hist_a = LMC_FUSED_HIST_A_BYTE || lmc_sym_nibbles(bins0);  // (a constant with LMC_FUSED_HIST_A_BYTE: quantize_oct_fused is not instantiated then)
     if (hist_a) {
       uint4* z = reinterpret_cast<uint4*>(lds_all);
 #pragma unroll
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       for (int oct = wave; oct < TO; oct += NW) {
         const bool q1valid = 2 * oct + 1 < a.TQ;
         const bool allrows = oct * 8 + 8 <= Tc;  // wave-uniform: false only for the last oct of a chunk of 8 k + r tokens
-        if (HISTA && hist_a) {
+        if (HISTA && (LMC_FUSED_HIST_A_BYTE || hist_a)) {
           // round 6: symbols to the workspace AND into the plane's counters (quantize_oct_hist)
           u32* const so = sym_pc + (long long)oct * (nib ? 1 : 2) * a.C;
           if (!allrows) {
@@ -528,6 +541,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
             else quantize_oct_hist<NITER, DT, false, true, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
           } else if (nib) quantize_oct_hist<NITER, DT, true, false, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
           else quantize_oct_hist<NITER, DT, false, false, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+        } else if constexpr (HISTA && LMC_FUSED_HIST_A_BYTE) {
+          // (unreachable: every plane of a GL == 64 item takes the branch above)
         } else if (!allrows) {  // (the variant with per-lane channel validity takes the per-row test as well: two instances, not four)
           if (nib)
             quantize_oct_fused<NITER, DT, true, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if (j < NS) {  // wave-uniform
       const CountsStream s = stream_of(j);
       u32 alloc;
-      if (HISTA && hist_a) alloc = counts_hist_stream<true, true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);  // the counters are there
+      if (HISTA && (LMC_FUSED_HIST_A_BYTE || hist_a)) alloc = counts_hist_stream<true, true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);  // the counters are there
       else alloc = counts_hist_stream<true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
       if (lane == 0) st_alloc[j] = alloc;
     }
