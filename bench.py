@@ -53,7 +53,9 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spe
 # profiles/r05_issue_model.md), ns of SIMD time per wave-instruction:
 ISSUE_NS = {"valu_fast": 1.05,    # v_add/sub/and/or/xor/lshrrev/mov/mul_f32/add_f32 without modifiers
             "valu_normal": 1.85,  # every other VALU instruction (VOP3, SDWA, DPP, cvt, cmp, mbcnt, lshlrev, packed, mul_hi ...)
-            "salu_beside_valu": 0.43}  # what a scalar instruction ADDS to a VALU-bound step (alone: 0.94; a taken branch: + 1.5)
+            # what a scalar instruction ADDS to a VALU-bound step (alone: 0.94; a taken branch: + 1.5): two boxes measured
+            # 0.43 and 1.3 ns (profiles/r05_issue_model.md section 2) -- the floor is carried as the range between them
+            "salu_beside_valu": 0.43, "salu_beside_valu_slow_box": 1.3}
 PROXY_BYTES = 16 * (1 << 30)  # one Llama-3-8B decode step streams ~16 GB of bf16 weights
 STUB = os.environ.get("LMC_BENCH_STUB") == "1"
 
@@ -115,13 +117,39 @@ def issue_roof(prof, gpu_ms_per_step):
     fast = k.get("valu_fast_share", 0.3)
     valu_ns = k["valu_insts"] * (fast * ISSUE_NS["valu_fast"] + (1 - fast) * ISSUE_NS["valu_normal"])
     salu_ns = k["salu_insts"] * ISSUE_NS["salu_beside_valu"]
+    salu_ns_hi = k["salu_insts"] * ISSUE_NS["salu_beside_valu_slow_box"]
     floor_ms = (valu_ns + salu_ns) / 1024.0 / 1e6  # 1024 SIMDs
+    floor_hi = (valu_ns + salu_ns_hi) / 1024.0 / 1e6
     return {"bound": "issue slots (VALU by class + SALU)", "floor_ms": round(floor_ms, 4),
-            "frac": round(floor_ms / gpu_ms_per_step, 4), "valu_ms": round(valu_ns / 1024.0 / 1e6, 4),
+            "floor_ms_range": [round(floor_ms, 4), round(floor_hi, 4)],
+            "frac": round(floor_ms / gpu_ms_per_step, 4),
+            "frac_range": [round(floor_ms / gpu_ms_per_step, 4), round(min(1.0, floor_hi / gpu_ms_per_step), 4)],
+            "valu_ms": round(valu_ns / 1024.0 / 1e6, 4),
             "salu_ms": round(salu_ns / 1024.0 / 1e6, 4), "valu_insts": k["valu_insts"], "salu_insts": k["salu_insts"],
             "valu_fast_share": fast, "prices_ns": ISSUE_NS,
-            "note": "floor = (VALU instructions x class price + SALU instructions x their measured cost beside a VALU stream) "
-                    "/ 1024 SIMDs; frac = floor / measured step: what is left is waiting (barriers, look-back, loads in phase A)"}
+            "note": "a FIT, not an independent bound: floor = (VALU instructions x class price + SALU instructions x their "
+                    "measured cost beside a VALU stream) / 1024 SIMDs, prices from replicas of the token loops "
+                    "(tools/probes/issue_model.py); the range spans the two scalar prices two boxes measured (0.43 / 1.3 ns); "
+                    "frac = floor / measured step: what is left is waiting (barriers, look-back, loads in phase A)"}
+
+
+def fabric_roof(prof, gpu_ms_per_step, quantize_ms, quantize_bytes):
+    """The second roof of the dominant kernel: bytes through the fabric (L2 <-> Infinity Cache / HBM, PMC-counted and
+    calibrated: profiles/latest.json) per step / the measured step, against the rate the product's own pure-streaming
+    kernel -- k_quantize, HBM-bound -- sustains on THIS box in THIS process (its bytes are known analytically: raw KV read
+    once, symbols and scales written once)."""
+    traffic = prof.get("traffic_bytes_per_step")
+    if not traffic or not quantize_ms:
+        return None
+    rate = traffic / (gpu_ms_per_step / 1e3) / 1e9
+    ceiling = quantize_bytes / (quantize_ms / 1e3) / 1e9
+    return {"bound": "fabric (L2 fills + write-backs of the step)", "traffic": int(traffic), "rate": round(rate, 1),
+            "ceiling": round(ceiling, 1), "unit": "GB/s", "frac": round(rate / ceiling, 4),
+            "floor_ms": round(traffic / ceiling / 1e6, 4),
+            "ceiling_source": f"k_quantize on this box: {quantize_bytes} B in {quantize_ms:.4f} ms (lmc_ctx_profile, median of 5 jobs "
+                              "of the two-kernel path)",
+            "note": "traffic / algorithmic bytes = what the symbols' trip through the workspace adds; floor_ms = the step "
+                    "if it moved its present traffic at k_quantize's rate"}
 
 
 # ---------------------------------------------------------------------------------------------- clock / power
@@ -220,6 +248,8 @@ def cpu_baseline(nchunks_sample):
         table.append(row)
         if best is None or row["GBps"] > best["GBps"]:
             best = row
+    # the workers' buffers (66 MB per thread) and the output arena go back before the next legs run
+    orc.release_workspaces(max(r["threads"] for r in table))
     orc.set_threads(ncores)
     done = sum(r["chunks"] for r in table)
     out = {"value": best["GBps"], "unit": "GB/s", "cores": best["threads"], "kind": "port",
@@ -276,6 +306,24 @@ def cpu_torch_serde():
     return res
 
 
+def cpu_quota():
+    """CPUs this container may use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        return None if q == "max" else max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        return None if q <= 0 else max(1, q // per)
+    except Exception:
+        return None
+
+
 def cpu_reference_formula(kv_chunk):
     """torch_quant_vectorized (per token absmax, x * (MAX / max) + MAX, round, int8) followed by do_dequantize
     (((q - MAX) / MAX) * max) and the bf16 cast, restated line for line as CPU torch ops on one chunk
@@ -300,9 +348,11 @@ def cpu_reference_formula(kv_chunk):
 
     res = {}
     ncores = len(os.sched_getaffinity(0))
-    # torch's intra-op pool on [256 x 1024] tensors stops scaling long before 256 threads (it gets slower): the
-    # "all cores" leg uses at most 64 of them
-    nthreads_all = min(ncores, 64)
+    # torch's intra-op pool on [256 x 1024] tensors stops scaling long before 256 threads (it gets slower), and a box
+    # with 256 logical CPUs may run this container under a CPU quota of 16 (cpu.max): more runnable threads than the quota
+    # only queue (round 5 read 0.34 GB/s at 64 threads, 6 x slower than one).  The "all" leg uses what the quota allows.
+    quota = cpu_quota()
+    nthreads_all = max(1, min(ncores, 64, quota or ncores))
     before = torch.get_num_threads()
     for label, nt in (("threads_1", 1), ("threads_all", nthreads_all)):
         torch.set_num_threads(nt)
@@ -315,6 +365,7 @@ def cpu_reference_formula(kv_chunk):
         res[label + "_GBps"] = round(raw / dt / 1e9, 3)
     torch.set_num_threads(before)
     res["threads_all"] = nthreads_all
+    res["cpu_quota"] = quota
     res["sample"] = "one 256-token Llama-3-8B chunk (33.5 MB raw KV): quantise + dequantise + bf16 cast, no entropy coding"
     return res
 
@@ -393,11 +444,11 @@ def time_encode(ctx, layout, ntok, chunk, bins, blobs, stride, sizes, sp, stream
     return ev0.elapsed_time(ev1) / reps
 
 
-def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=False, cs=256):
+def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=False, cs=256, dist="rand", roundtrip=False):
+    """Encode / decode rate of another geometry or input distribution (HBM-resident, one job)."""
     stage(f"shape {name}")
-    """Encode / decode rate of another geometry (HBM-resident, one job)."""
     from lmcache_amd.storage_backend.serde.cachegen_basics import CacheGenConfig
-    kv = make_kv(dev, 0, "rand", nl, ntok, nh, hd, dtype)
+    kv = make_kv(dev, 0, dist, nl, ntok, nh, hd, dtype)
     lay = native.KVLayout.from_kv_tuple(kv, "vllm")
     bins = CacheGenConfig.from_model_name(model).plane_bins(nl)
     n = (ntok + cs - 1) // cs
@@ -434,10 +485,22 @@ def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=Fal
     e1.record()
     torch.cuda.synchronize()
     tdec = e0.elapsed_time(e1) / 20
-    return {"workload": name, "raw_kv_MB": round(raw / 1e6, 1), "chunks": n, "chunk_tokens": cs,
-            "encode_ms": round(tenc, 3), "encode_GBps_raw": round(raw / tenc / 1e6, 1),
-            "decode_ms": round(tdec, 3), "decode_GBps_raw": round(raw / tdec / 1e6, 1),
-            "compression": round(raw / int(sizes.sum()), 3)}
+    row = {"workload": name, "raw_kv_MB": round(raw / 1e6, 1), "chunks": n, "chunk_tokens": cs,
+           "encode_ms": round(tenc, 3), "encode_GBps_raw": round(raw / tenc / 1e6, 1),
+           "decode_ms": round(tdec, 3), "decode_GBps_raw": round(raw / tdec / 1e6, 1),
+           "compression": round(raw / int(sizes.sum()), 3)}
+    if roundtrip and not paged:
+        # size-independent property at full size: decode(encode(x)) reproduces x within the quantisation bound,
+        # |x^ - x| <= max1 / (2 M) + 1 ulp16(max1), per token row and plane -- checked on every plane
+        ok = True
+        for l in range(nl):
+            for kvi in range(2):
+                x, y = kv[l][kvi].float(), out[l][kvi].float()
+                mx = x.abs().amax(dim=(1, 2), keepdim=True)
+                m = bins[kvi * nl + l] // 2 - 1
+                ok = ok and bool(((y - x).abs() <= mx / (2 * m) + mx * 2.0 ** -7).all())
+        row["roundtrip_within_bound"] = ok
+    return row
 
 
 # ---------------------------------------------------------------------------------------------- main
@@ -680,7 +743,7 @@ def main(argv=None):
                 # the dominant kernel is an integer entropy coder: the roof it sits under is instruction issue, not HBM --
                 # VALU instructions priced by class, with the scalar side (VERDICT r04 #1a / weak #2: the flat 4-cycle
                 # `valu` roof of rounds 3-4 is gone): profiles/r05_issue_model.md
-                "valu_insts_per_step": valu_insts, "valu_busy_dominant_kernel": prof.get("valu_busy_dominant_kernel"),
+                "valu_insts_per_step": valu_insts,
                 "issue": issue_roof(prof, gpu_ms_per_step),
                 "profile_source": prof.get("source"),
                 "note": "achieved = (raw KV read once + blob written once) per step / HIP-event time of one step "
@@ -701,6 +764,12 @@ def main(argv=None):
         torch.cuda.synchronize()
         ctx.raise_on_status("profile legs")
     res["encode_paths"] = encode_paths_ab(ctx, step, stream, max(5, min(20, args.steps)))
+    if not strong:
+        # the fabric roof next to the issue roof: the ceiling is k_quantize's rate measured here
+        nib = sum(1 for b in bins if b <= 17)
+        elems = raw_bytes // 2
+        qbytes = raw_bytes + elems * nib // len(bins) // 2 + elems * (len(bins) - nib) // len(bins) + 2 * len(bins) * CTX
+        roofline["fabric"] = fabric_roof(prof, gpu_ms_per_step, res["encode_paths"].get("k_quantize_ms"), qbytes)
     # what ONE store() out of idle costs (the timed region above is steady state: the clock ramp is outside it)
     cold = []
     for _ in range(3):
@@ -757,7 +826,22 @@ def encode_paths_ab(ctx, step, stream, reps):
                 e1.record(stream)
                 torch.cuda.synchronize()
                 out[name + "_ms"] = round(e0.elapsed_time(e1) / reps, 4)
+        # k_quantize alone (per-kernel HIP events of the two-kernel path): the product's pure-streaming kernel, whose
+        # rate is the fabric roof's ceiling
+        ctx.set_encode_path("two_kernels")
+        ctx.profile(True)
+        q = []
+        for _ in range(5):
+            step()
+            torch.cuda.synchronize()
+            pr = ctx.profile_read()
+            if len(pr) >= 2:
+                q.append(pr[0])
+        ctx.profile(False)
+        if q:
+            out["k_quantize_ms"] = round(float(statistics.median(q)), 4)
     finally:
+        ctx.profile(False)
         ctx.set_encode_path("auto")
     out["reps"] = reps
     out["note"] = "default = auto: fused when chunks x planes > 4 x CUs (this workload: 4096 > 1024)"
@@ -1065,6 +1149,15 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
     ctx.raise_on_status("bench seeds")
     res["seeds"] = {"dist": args.dist, "ms_per_step": per_seed, "min": min(per_seed), "median": median(per_seed),
                     "GBps_raw_median": round(raw_bytes / median(per_seed) / 1e6, 1)}
+
+    stage("other distributions")
+    # ---- SURVEY.md 8d names three input distributions: the timed one (--dist, default rand) and the two others here ----
+    try:
+        res["other_dists"] = [dict(shape_rate(native, ctx, dev, f"Llama-3-8B bf16, 16k tokens, chunk_size 256, {d} KV", L, H, D,
+                                              torch.bfloat16, CTX, MODEL, dist=d, roundtrip=True), dist=d)
+                              for d in ("rand", "randn", "outlier") if d != args.dist]
+    except Exception as e:
+        res["other_dists"] = [{"error": repr(e)}]
 
     stage("other configs")
     # ---- the other BASELINE geometries, HBM-resident --------------------------------------------------------

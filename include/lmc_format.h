@@ -172,6 +172,12 @@ static inline uint32_t lmc_head_cap_bytes(uint32_t T) { return lmc_head_bytes(31
 
 /* The coder model of a chunk of T tokens. */
 static inline uint32_t lmc_model_for(uint32_t T) { return (T >= LMC_COUNTS_T_MIN && T <= LMC_COUNTS_T) ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16; }
+/* ... and what a DECODER accepts in a header's `model` word: lmc_model_for(T) is the encoder's choice, not a law of the
+ * format.  CDF16 decodes at any T (rounds 3-4 wrote their ragged and < 256-token chunks that way, and such blobs outlive a
+ * build in a remote store); COUNTS needs 2 <= T <= 256. */
+static inline int lmc_model_valid(uint32_t model, uint32_t T) {
+  return model == LMC_MODEL_CDF16 || (model == LMC_MODEL_COUNTS && T >= LMC_COUNTS_T_MIN && T <= LMC_COUNTS_T);
+}
 
 /* floor(256 * x / T) for x <= T <= 256 the way the kernels compute it: one multiply-high by ceil(2^32 / T).  Exact: the
  * estimate exceeds 256 x / T by 256 x e / (T 2^32) with e = ceil(2^32 / T) T - 2^32 < T, i.e. by less than 2^-16 < 1 / T. */

@@ -285,10 +285,14 @@ class LMCacheEngine:
         # several runs (local_backend.get_kv_range), i.e. several jobs, and layer l is complete when EVERY job's range
         # that holds l is (round 4 kept only the last job's events and was right only because all jobs share a stream)
         event_sets = [list(job.layer_events) for _, job in jobs if job is not None and job.layer_events]
-        if not event_sets:  # the backend finished (or queued) everything in one piece
+        if not event_sets or len(event_sets) < len(jobs):
+            # some run of the retrieve (or all of it) carries no per-layer events -- a backend that finished or queued its
+            # part in one piece: ONE event recorded now on the current stream, behind everything _retrieve_into queued,
+            # covers those runs for every layer (wait_layer used to skip them, which was right only while
+            # every run shared this stream AND stood in front of the other runs' events)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(blob.device))
-            event_sets = [[(box["L"], ev)]]
+            event_sets.append([(box["L"], ev)])
         return LayerwiseRetrieval(self._blob_to_tuple_kv(blob), ret_mask, event_sets[-1], jobs, event_sets)
 
     def _retrieve_into(self, tokens: torch.Tensor, mask: Optional[torch.Tensor], make_dst,
@@ -380,6 +384,8 @@ class LayerwiseRetrieval:
     """What retrieve_layerwise returns: the KV tuple (being filled layer by layer), ret_mask, and the events."""
 
     def __init__(self, kv, ret_mask, layer_events, jobs, event_sets=None):
+        # `layer_events` is the LAST run's list only (kept for callers of rounds 2-4): a retrieve that spans several
+        # stores has one list per run, and layer l is complete when every run's range that holds l is -- use wait_layer()
         self.kv, self.ret_mask, self.layer_events, self._jobs = kv, ret_mask, layer_events, jobs
         self._event_sets = event_sets if event_sets is not None else ([layer_events] if layer_events else [])
 

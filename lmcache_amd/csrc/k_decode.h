@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   const bool counts_model = hdw(22) == LMC_MODEL_COUNTS;  // wave-uniform: the coder ran on the symbol counts (2 <= T <= 256)
   const BlobOff bo = lmc_blob_off((u32)a.P, T, (u32)a.G);
   if (hdw(0) != LMC_BLOB_MAGIC || (hdw(1) & 0xffffu) != LMC_BLOB_VERSION || hdw(7) != (u32)a.C || T == 0u || T > 65535u ||
-      hdw(22) != lmc_model_for_dev(T) ||
+      !lmc_model_valid_dev(hdw(22), T) ||  // (the header's model is trusted: a round-3/4 blob of a short chunk is CDF16)
       hdw(8) != (u32)a.P || hdw(15) != bo.streams ||
       // every section offset is a function of the fields checked above; the blob must also fit its slot
       (!SYMOUT && (T > (u32)a.chunk_tokens ||

@@ -1000,7 +1000,7 @@ int lmc_blob_info(const void* blob_h, size_t nbytes, lmc_blob_header* out) {
   memcpy(&h, blob_h, sizeof h);
   if (h.magic != LMC_BLOB_MAGIC || h.version != LMC_BLOB_VERSION || h.header_bytes != LMC_HEADER_BYTES) return LMC_ERR_INVALID;
   if (h.num_layers == 0 || h.ntokens == 0 || h.num_heads == 0 || h.head_size == 0) return LMC_ERR_INVALID;
-  if (h.num_layers > LMC_MAX_PLANES / 2 || h.ntokens > 65535u || h.model != lmc_model_for(h.ntokens)) return LMC_ERR_INVALID;
+  if (h.num_layers > LMC_MAX_PLANES / 2 || h.ntokens > 65535u || !lmc_model_valid(h.model, h.ntokens)) return LMC_ERR_INVALID;
   if ((uint64_t)h.num_heads * h.head_size > LMC_MAX_CHANNELS) return LMC_ERR_INVALID;
   lmc_blob_header ref;
   memset(&ref, 0, sizeof ref);

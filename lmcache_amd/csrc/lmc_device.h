@@ -58,6 +58,9 @@ __device__ __forceinline__ long long lmc_tok_off(const KvAddr& a, int t) {
 __device__ __forceinline__ u32 lmc_model_for_dev(u32 T) {
   return (T >= LMC_COUNTS_T_MIN && T <= LMC_COUNTS_T) ? LMC_MODEL_COUNTS : LMC_MODEL_CDF16;
 }
+__device__ __forceinline__ bool lmc_model_valid_dev(u32 model, u32 T) {  // lmc_model_valid
+  return model == LMC_MODEL_CDF16 || (model == LMC_MODEL_COUNTS && T >= LMC_COUNTS_T_MIN && T <= LMC_COUNTS_T);
+}
 __device__ __forceinline__ u32 lmc_counts_scale_magic_dev(u32 T) { return 0xffffffffu / T + 1u; }
 
 // Workspace symbol format of a plane: symbols are 0 .. bins - 2, so planes with bins <= 17 pack two per byte

@@ -56,6 +56,10 @@ def lib() -> ctypes.CDLL:
         L.lmco_decode_group.restype = i32
         L.lmco_encode_blob.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, sz, vp]
         L.lmco_encode_blob.restype = i32
+        L.lmco_encode_blob_model.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, sz, vp, i32]
+        L.lmco_encode_blob_model.restype = i32
+        L.lmco_ws_release_all.argtypes = [i32]
+        L.lmco_ws_release_all.restype = None
         L.lmco_set_threads.argtypes = [i32]
         L.lmco_set_threads.restype = i32
         L.lmco_encode_blobs_parallel.argtypes = [vp, sz, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp]
@@ -167,18 +171,31 @@ def blob_bound(L: int, T: int, H: int, D: int) -> int:
     return int(lib().lmco_blob_bound(L, T, H, D))
 
 
-def encode_blob(kv_bits: np.ndarray, dtype: int, H: int, D: int, bins: np.ndarray) -> bytes:
-    """cachegen_encoder.py:266-325,352-389 with our container.  kv_bits uint16 [L,2,T,H*D]."""
+MODEL_CDF16, MODEL_COUNTS = 0, 1  # include/lmc_format.h: LMC_MODEL_*
+
+
+def encode_blob(kv_bits: np.ndarray, dtype: int, H: int, D: int, bins: np.ndarray, model: int = -1) -> bytes:
+    """cachegen_encoder.py:266-325,352-389 with our container.  kv_bits uint16 [L,2,T,H*D].
+    model: -1 = the encoder's choice for the chunk length (lmc_model_for); MODEL_CDF16 = the 16-bit CDF whatever the
+    length -- the form rounds 3-4 wrote chunks other than 256 tokens in, which a decoder must keep reading."""
     L, two, T, C = kv_bits.shape
     assert two == 2 and C == H * D
     bins = np.ascontiguousarray(bins, dtype=np.int32)
     cap = blob_bound(L, T, H, D)
     blob = np.zeros(cap, np.uint8)
     nbytes = ctypes.c_size_t(0)
-    rc = lib().lmco_encode_blob(_p(np.ascontiguousarray(kv_bits)), dtype, L, T, H, D, _p(bins), _p(blob),
-                                cap, ctypes.byref(nbytes))
+    rc = lib().lmco_encode_blob_model(_p(np.ascontiguousarray(kv_bits)), dtype, L, T, H, D, _p(bins), _p(blob),
+                                      cap, ctypes.byref(nbytes), model)
     assert rc == 0, f"lmco_encode_blob rc={rc}"
     return blob[:nbytes.value].tobytes()
+
+
+def release_workspaces(nthreads: int = 0) -> None:
+    """Free the per-thread buffers of lmco_encode_blob on every OpenMP worker (a region of `nthreads` threads; 0: as
+    many as the runtime gives) and the output arena of encode_blobs_parallel."""
+    global _par_out
+    lib().lmco_ws_release_all(nthreads)
+    _par_out = None
 
 
 def set_threads(n: int) -> int:

@@ -903,3 +903,26 @@ def test_fused_encode_of_the_70b_tp8_rank_shape_at_32k(nat, ctx, oracle):
     mx = kv.float().abs().amax(dim=(3, 4), keepdim=True)
     M = torch.tensor([b // 2 - 1 for b in bins], dtype=torch.float32, device=DEV).reshape(2, L).T.reshape(L, 2, 1, 1, 1)
     assert ((out.float() - kv.float()).abs() <= mx / (2 * M) + mx * 2.0 ** -7).all()
+
+
+@pytest.mark.parametrize("T", [44, 100, 255, 256])
+def test_round4_cdf16_blobs_of_short_chunks_still_decode(nat, ctx, oracle, T):
+    """A format-v6 blob whose header says CDF16 at a chunk length the present encoder codes on the counts model (what
+    rounds 3-4 wrote for ragged and < 256-token chunks) is decoded, not rejected as BAD_HEADER: k_decode and
+    lmc_blob_info go by the header's model word (such blobs live on in remote stores)."""
+    L, H, D = 2, 2, 128
+    kv = make_kv(L, T, H, D, torch.bfloat16, "randn", seed=T)
+    bins = [32, 16, 16, 22]
+    b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
+    old = oracle.encode_blob(b, code, H, D, np.array(bins, np.int32), model=oracle.MODEL_CDF16)
+    hdr = nat.blob_info(old)
+    assert (hdr.ntokens, hdr.total_bytes) == (T, len(old))
+    stride = nat.r16(nat.blob_bound(L, T, H, D))
+    dev = torch.zeros(stride, dtype=torch.uint8, device=DEV)
+    dev[:len(old)] = torch.frombuffer(bytearray(old), dtype=torch.uint8).to(DEV)
+    for odt, ocode in ((torch.bfloat16, oracle.BF16), (torch.float16, oracle.FP16)):
+        out = torch.zeros(L, 2, T, H, D, dtype=odt, device=DEV)
+        ctx.decode_chunks(dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out, "vllm"), 0, T)
+        torch.cuda.synchronize()
+        ctx.raise_on_status("decode of a CDF16 blob")
+        assert np.array_equal(bits_np(out).reshape(L, 2, T, H * D), oracle.decode_blob(old, ocode))

@@ -427,6 +427,8 @@ def test_scratch_of_the_hot_kernels_is_what_design_md_says():
     import json
     from lmcache_amd import native
     native.build()
+    if not os.path.exists(native.RESOURCES_PATH):
+        pytest.skip("the library was not compiled here (prebuilt): no kernel_resources.json to hold against DESIGN.md")
     res = json.load(open(native.RESOURCES_PATH))
 
     def one(prefix):
@@ -482,3 +484,29 @@ def test_prefix_hash_chain_kept_between_calls_gives_the_same_digests():
         assert e._prefix_hashes_of(t, skip) == plain(t, e.chunk_size)[skip:], trial
         if rnd.random() < 0.5:
             base = t.clone()
+
+
+@pytest.mark.parametrize("T", [2, 3, 5, 17, 32, 100, 128, 200, 255, 256])
+def test_pack_cap_covers_the_allocations_of_high_entropy_channels(oracle, T):
+    """pack_cap (the pinned region a pack is written into) is a Python formula, the streams' allocations are
+    the format's (lmc_counts_alloc_bytes over lmc_counts_lane_words of the lane's S).  Held against each other where the
+    allocation is largest -- channels that use every symbol the plane has, as evenly as the chunk length allows (the
+    bound is a sum of concave per-symbol terms) -- for every bins value a CacheGen table or a fuzz case can name."""
+    from lmcache_amd.storage_backend.serde.cachegen_device import pack_cap
+    H, D, L = 1, 128, 1
+    C = H * D
+    rng = np.random.default_rng(T)
+    for bins in (4, 5, 6, 8, 9, 16, 17, 22, 32, 33):
+        R = bins - 1
+        m = bins // 2 - 1
+        # symbols of token t in channel c: a permutation-shifted round robin over all R symbols (every count within 1 of
+        # T / R), realised as inputs x = (sym - m) / m * max with a row maximum of exactly 1 on a channel of its own
+        sym = (np.arange(T)[:, None] + rng.integers(0, R, size=C)[None, :]) % R
+        x = (sym.astype(np.float32) - m) / m
+        x[:, 0] = 1.0   # the row maximum (symbol 2m)
+        kv = np.stack([x, x])[None].astype(np.float32)        # [L, 2, T, C]
+        import torch
+        bits, code = oracle.torch_to_bits(torch.from_numpy(kv).to(torch.bfloat16))
+        blob = oracle.encode_blob(bits, code, H, D, np.array([bins, bins], np.int32))
+        pack = oracle.pack_from_blobs([blob], T)
+        assert len(pack) <= pack_cap(1, L, T, H, D, [bins, bins]), (T, bins, len(pack), pack_cap(1, L, T, H, D, [bins, bins]))

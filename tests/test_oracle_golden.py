@@ -350,3 +350,25 @@ def test_stream_head_is_the_bit_sliced_counts(oracle):
             assert np.array_equal(cnt, stored), (T, pg)
             assert np.array_equal(widths, [int(v).bit_length() for v in stored.max(axis=1)]), (T, pg)
             assert hb % 16 == 0 and gdir[pg, 1] - gdir[pg, 0] >= hb + 256
+
+
+@pytest.mark.parametrize("T", [2, 44, 100, 255, 256])
+def test_cdf16_blobs_of_short_chunks_still_decode(oracle, T):
+    """Rounds 3-4 coded every chunk other than 256 tokens on the 16-bit CDF (header model 0, format v6); round 5 moved
+    2 .. 255 tokens to the counts model WITHOUT a version bump.  A store that outlives a build still holds the old
+    blobs: the header's model word is what a decoder goes by (lmc_model_valid), not lmc_model_for(T)."""
+    g = np.random.default_rng(T)
+    import torch
+    L, H, D = 2, 2, 64
+    kv = torch.from_numpy(g.standard_normal((L, 2, T, H * D)).astype(np.float32)).to(torch.bfloat16)
+    bits, code = oracle.torch_to_bits(kv)
+    bins = np.array([32, 16, 16, 22], np.int32)
+    old = oracle.encode_blob(bits, code, H, D, bins, model=oracle.MODEL_CDF16)
+    new = oracle.encode_blob(bits, code, H, D, bins)
+    assert oracle.parse_header(old)["model"] == oracle.MODEL_CDF16
+    assert oracle.parse_header(new)["model"] == oracle.MODEL_COUNTS
+    assert old != new
+    for dt in (oracle.BF16, oracle.FP16):
+        assert np.array_equal(oracle.decode_blob(old, dt), oracle.decode_blob(new, dt))
+    assert np.array_equal(oracle.decode_blob_symbols(old), oracle.decode_blob_symbols(new))
+    assert np.array_equal(oracle.blob_cdf(old), oracle.blob_cdf(new))
