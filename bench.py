@@ -1317,7 +1317,7 @@ def ttft_hbm_tier(dev, kv, proxy, alone, meta):
         # the decode runs on a HIGH-priority side stream: its waves go first wherever the model's layers leave issue
         # slots, so a range is complete as early as the hardware allows (schedule the slack)
         side = torch.cuda.Stream(device=dev, priority=-1)
-        whole, host_ms = [], []
+        whole, host_ms = [], {}
         from lmcache_amd.storage_backend.serde.cachegen_device import layer_ranges
         # range size, or a schedule of range sizes (small ranges first, the last entry repeats)
         piped = {2: [], 4: [], 8: [], (2, 6, 24): [], (1, 3, 12, 16): [], (4, 28): [], 32: []}
@@ -1334,7 +1334,7 @@ def ttft_hbm_tier(dev, kv, proxy, alone, meta):
                 t0 = time.perf_counter()
                 with torch.cuda.stream(side):        # one decode launch per range of layers on a side stream ...
                     res = engine.retrieve_layerwise(toks, layers_per_launch=step)
-                host_ms.append((time.perf_counter() - t0) * 1e3)  # hashing, look-ups, launches: the GPU idles until the first launch
+                host_ms.setdefault(step, []).append((time.perf_counter() - t0) * 1e3)  # hashing, look-ups, launches: the GPU idles until the first launch
                 for l0, l1 in layer_ranges(L, step):  # ... the model's layers of a range wait for THAT range's KV only
                     res.wait_layer(l0)
                     for l in range(l0, l1):
@@ -1350,7 +1350,11 @@ def ttft_hbm_tier(dev, kv, proxy, alone, meta):
         return {"retrieve_then_step_ms": round(median(whole), 3), "ratio": round(median(whole) / alone, 3),
                 "layerwise_ms": round(med[best], 3), "layerwise_ratio": round(med[best] / alone, 3),
                 "layers_per_launch": best if isinstance(best, int) else list(best), "layerwise_ms_by_layers_per_launch": {str(k): round(v, 3) for k, v in med.items()},
-                "target": "<= 1.05", "reps": 5, "host_ms_before_the_model_can_start": round(median(host_ms), 3),
+                "target": "<= 1.05", "reps": 5,
+                # the host part of the BEST schedule (what a serving engine would configure), and of every schedule:
+                # one lmc_decode_chunks_schedule call issues all ranges, so it grows by ~7 us per range
+                "host_ms_before_the_model_can_start": round(median(host_ms[best][1:]), 3),
+                "host_ms_by_layers_per_launch": {str(k): round(median(v[1:]), 3) for k, v in host_ms.items()},
                 "hbm_floor_ratio": round((PROXY_BYTES + 2.66e9) / PROXY_BYTES, 3),
                 "note": "encoded chunks resident in HBM (4.2x more warm context than raw KV): retrieve = decode only; "
                         "layerwise = retrieve_layerwise on a side stream, one k_decode launch per range of layers, the "

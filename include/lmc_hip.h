@@ -221,6 +221,18 @@ int lmc_decode_chunks_layers(lmc_ctx* ctx, const void* const* blob_ptrs, uint64_
                              const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, int32_t layer_begin,
                              int32_t layer_count, uint32_t* job_status, lmc_stream_t stream);
 
+/*
+ * ... and a whole SCHEDULE of such launches in one call (round 6): range i covers layers
+ * [layer_ends[i - 1], layer_ends[i]) (layer_ends[-1] = 0, ascending, the last entry = num_layers), each launch is
+ * followed by hipEventRecord(events[i]) on `stream`.  What engine.retrieve_layerwise() issued as one C call and one
+ * event per range from Python (0.26 ms of host time in front of the first kernel of a warm 16 k prefix) -- the host
+ * side of cache_engine.py:293-381 for the HBM-resident tier.  events may be NULL (no events), or hold NULL entries.
+ */
+int lmc_decode_chunks_schedule(lmc_ctx* ctx, const void* const* blob_ptrs, uint64_t max_blob_bytes, int32_t nchunks,
+                               const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, int32_t nranges,
+                               const int32_t* layer_ends_h, const lmc_event_t* events_h, uint32_t* job_status,
+                               lmc_stream_t stream);
+
 /* Entropy-decode only (debug / parity): blob -> sym_out int8 [P][T][C].
  * Stands where torchac_cuda.decode_fast_prefsum stands (cachegen_decoder.py:65-66). */
 int lmc_decode_symbols(lmc_ctx* ctx, const void* blob, int32_t L, int32_t H, int32_t D, int8_t* sym_out,

@@ -142,7 +142,8 @@ class LMCacheEngine:
         return tuple((k.cuda(), v.cuda()) for k, v in kv)
 
     def _blob_to_tuple_kv(self, blob: torch.Tensor) -> KVCache:
-        return tuple((layer[0], layer[1]) for layer in torch.unbind(blob, dim=0))
+        # (one unbind per layer: layer[0], layer[1] are two indexing calls each -- 64 of them in front of a 32-layer model)
+        return tuple(tuple(layer.unbind(0)) for layer in blob.unbind(0))
 
     # ------------------------------------------------------------------ store
     @_lmcache_nvtx_annotate
@@ -293,7 +294,9 @@ class LMCacheEngine:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(blob.device))
             event_sets.append([(box["L"], ev)])
-        return LayerwiseRetrieval(self._blob_to_tuple_kv(blob), ret_mask, event_sets[-1], jobs, event_sets)
+        # (the per-layer (K, V) views are made when `kv` is first read: 33 tensor calls that need not stand between the
+        # launches above and the caller's first wait_layer)
+        return LayerwiseRetrieval(lambda: self._blob_to_tuple_kv(blob), ret_mask, event_sets[-1], jobs, event_sets)
 
     def _retrieve_into(self, tokens: torch.Tensor, mask: Optional[torch.Tensor], make_dst,
                        layers_per_launch: Optional[int] = None, jobs_out: Optional[list] = None) -> Tuple[int, torch.Tensor]:
@@ -308,9 +311,22 @@ class LMCacheEngine:
         if mask is not None:
             num_skip_tok = int(len(mask) - int(torch.sum(mask)))
         num_skip_chunk = num_skip_tok // cs
-        ret_mask[:num_skip_tok] = False
+        if num_skip_tok:
+            ret_mask[:num_skip_tok] = False
         chunk_hashes = self._prefix_hashes_of(tokens, num_skip_chunk)
-        keys = [self._make_key(h, fmt) for h in chunk_hashes]
+        # the key objects of the last few hash chains are kept (the chain's last digest names the whole chain): a warm
+        # prefix is looked up, retrieved and stored with the same 64 keys (round 6: host time in front of the first launch)
+        memo = getattr(self, "_key_memo", None)
+        if memo is None:
+            memo = self._key_memo = {}
+        mk = (fmt, chunk_hashes[-1], len(chunk_hashes)) if chunk_hashes else None
+        keys = memo.get(mk)
+        if keys is None:
+            keys = [self._make_key(h, fmt) for h in chunk_hashes]
+            if mk is not None:
+                if len(memo) >= 4:
+                    memo.pop(next(iter(memo)))
+                memo[mk] = keys
         dev = torch.device("cuda", torch.cuda.current_device())
 
         def miss():
@@ -318,11 +334,15 @@ class LMCacheEngine:
             return 0, ret_mask
 
         if getattr(self.engine_, "supports_kv_layout", False):
-            hits = 0
-            for k in keys:
-                if not self.engine_.contains(k):
-                    break
-                hits += 1
+            count = getattr(self.engine_, "contains_prefix", None)
+            if count is not None:
+                hits = count(keys)  # the same scan inside the backend: one call instead of one per key
+            else:
+                hits = 0
+                for k in keys:
+                    if not self.engine_.contains(k):
+                        break
+                    hits += 1
             _, extra, nret = self.plan_retrieve(len(tokens), cs, num_skip_tok, hits)
             if hits == 0 or nret <= 0:
                 return miss()
@@ -335,10 +355,10 @@ class LMCacheEngine:
             dst = make_dst(nret, L, H, D, dtype, dev)
             try:
                 if jobs_out is not None and getattr(self.engine_, "mode", None) in ("hbm-cachegen", "cachegen"):
-                    got = self.engine_.get_kv_range(keys[:hits], dst, fmt, -extra, cs,
+                    got = self.engine_.get_kv_range(keys if hits == len(keys) else keys[:hits], dst, fmt, -extra, cs,
                                                     layers_per_launch=layers_per_launch, jobs_out=jobs_out)
                 else:
-                    got = self.engine_.get_kv_range(keys[:hits], dst, fmt, -extra, cs)
+                    got = self.engine_.get_kv_range(keys if hits == len(keys) else keys[:hits], dst, fmt, -extra, cs)
             except native.NativeError:
                 # a stored blob that does not decode must never reach the model as KV: the whole lookup is a miss
                 logger.exception("retrieve: a cached chunk failed to decode; treated as a miss")
@@ -371,7 +391,8 @@ class LMCacheEngine:
                 if skip < T:
                     ctx.copy_kv(native.KVLayout.from_chunk(c, fmt), skip, T - skip, dst, pos + skip)
                 pos += T
-        ret_mask[num_skip_tok + nret:] = False
+        if num_skip_tok + nret < len(ret_mask):
+            ret_mask[num_skip_tok + nret:] = False
         logger.info("Retrieved %d chunks (%d tokens in total) -- elapsed time %.4f", hits, nret,
                     time.perf_counter() - t_start)
         return nret, ret_mask
@@ -386,8 +407,15 @@ class LayerwiseRetrieval:
     def __init__(self, kv, ret_mask, layer_events, jobs, event_sets=None):
         # `layer_events` is the LAST run's list only (kept for callers of rounds 2-4): a retrieve that spans several
         # stores has one list per run, and layer l is complete when every run's range that holds l is -- use wait_layer()
-        self.kv, self.ret_mask, self.layer_events, self._jobs = kv, ret_mask, layer_events, jobs
+        self._kv, self.ret_mask, self.layer_events, self._jobs = kv, ret_mask, layer_events, jobs
         self._event_sets = event_sets if event_sets is not None else ([layer_events] if layer_events else [])
+
+    @property
+    def kv(self):
+        """The per-layer (K, V) tuple (being filled layer by layer); () on a miss."""
+        if callable(self._kv):
+            self._kv = self._kv()
+        return self._kv
 
     def wait_layer(self, layer: int, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Make `stream` (default: the current one) wait until the KV of `layer` is complete.  No host wait."""

@@ -595,6 +595,9 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
       if constexpr (NIB) rans_put_nib(E, R.x, R.y);
       else rans_put_byte(E, R.x, R.y);
     }
+#ifdef LMC_EXP_SKIP_TOKEN_LOOP  // instruction-count experiments (tools/scripts/quick_pmc.sh): everything but pass 2's token loop
+    return;
+#endif
     if (NB == 0) return;
     // The table pipeline: the entry of a token is requested FOUR steps ahead, its reciprocal TWO (from an entry that
     // landed two steps earlier), so the wait in front of a step's block covers requests that are two steps old and

@@ -427,6 +427,7 @@ __device__ __forceinline__ void quantize_oct_hist(const KvAddr& src, const u16* 
         *reinterpret_cast<uint4*>(dst) = make_uint4(o[it][0], o[it][1], o[it][2], o[it][3]);
         *reinterpret_cast<uint4*>(dst + 4) = make_uint4(o[it][4], o[it][5], o[it][6], o[it][7]);
       }
+#ifndef LMC_EXP_SKIP_HIST  // (instruction-count experiments only: the blobs are garbage without the counters)
       static_for<NITER>([&](auto it_tag) {
         constexpr int it = decltype(it_tag)::value;
         if (FULL || cval[it]) {
@@ -437,6 +438,7 @@ __device__ __forceinline__ void quantize_oct_hist(const KvAddr& src, const u16* 
           });
         }
       });
+#endif
     }
   }
 }
@@ -526,6 +528,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       u32* const sym_pc = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.sym_stride;
       u16* const scl = reinterpret_cast<u16*>(scl0) + (long long)p * Tc;
       const u16* const pbase = lmc_plane_base(fa.src, p);
+#ifdef LMC_EXP_SKIP_PHASE_A
+      if (false)
+#endif
 #pragma unroll 1
       for (int oct = wave; oct < TO; oct += NW) {
         const bool q1valid = 2 * oct + 1 < a.TQ;

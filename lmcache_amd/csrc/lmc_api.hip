@@ -570,6 +570,31 @@ int lmc_decode_chunks_layers(lmc_ctx* c, const void* const* blob_ptrs, uint64_t 
   return decode_launch(c, a, dst, (hipStream_t)stream);
 }
 
+int lmc_decode_chunks_schedule(lmc_ctx* c, const void* const* blob_ptrs, uint64_t max_blob_bytes, int32_t nchunks,
+                               const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, int32_t nranges,
+                               const int32_t* layer_ends_h, const lmc_event_t* events_h, uint32_t* job_status,
+                               lmc_stream_t stream) {
+  if (!layout_ok(dst) || chunk_tokens < 1 || !blob_ptrs || nranges < 1 || !layer_ends_h) return LMC_ERR_INVALID;
+  for (int i = 0, prev = 0; i < nranges; prev = layer_ends_h[i], i++)  // the whole schedule is checked before anything is launched
+    if (layer_ends_h[i] <= prev || layer_ends_h[i] > dst->num_layers) return LMC_ERR_INVALID;
+  if (layer_ends_h[nranges - 1] != dst->num_layers) return LMC_ERR_INVALID;
+  DecodeArgs a;
+  memset(&a, 0, sizeof a);
+  int rc = decode_common(c, blob_ptrs, (max_blob_bytes + 15) & ~(uint64_t)15, nchunks, dst->num_layers, dst->num_heads,
+                         dst->head_size, job_status, a);
+  if (rc) return rc;
+  a.blob_ptrs = (const u8* const*)blob_ptrs;
+  a.dst = to_addr(dst); a.dst_tok0 = dst_tok0; a.chunk_tokens = chunk_tokens;
+  HIP_TRY(hipSetDevice(c->device));
+  for (int i = 0, prev = 0; i < nranges; prev = layer_ends_h[i], i++) {
+    a.layer_begin = prev; a.layer_count = layer_ends_h[i] - prev;
+    rc = decode_launch(c, a, dst, (hipStream_t)stream);
+    if (rc) return rc;
+    if (events_h && events_h[i]) HIP_TRY(hipEventRecord((hipEvent_t)events_h[i], (hipStream_t)stream));
+  }
+  return LMC_OK;
+}
+
 int lmc_decode_symbols(lmc_ctx* c, const void* blob, int32_t L, int32_t H, int32_t D, int8_t* sym_out,
                        lmc_stream_t stream) {
   if (!sym_out || L < 1 || H < 1 || D < 8) return LMC_ERR_INVALID;

@@ -129,6 +129,7 @@ SYMBOLS = {
     "lmc_encode_chunks": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp, _vp]),
     "lmc_decode_chunks": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _vp, _vp]),
     "lmc_decode_chunks_layers": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "lmc_decode_chunks_schedule": (ctypes.c_int, [_vp, _vp, _u64, _i32, _PL, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "lmc_decode_symbols": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "lmc_store_chunks": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     "lmc_load_chunks": (ctypes.c_int, [_vp, _vp, _vp, _i32, _PL, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -587,6 +588,26 @@ class Context:
         check(lib().lmc_decode_chunks_layers(self.handle, blob_ptrs, max_blob_bytes, nchunks, ctypes.byref(dst.struct),
                                              dst_tok0, chunk_tokens, layer_begin, layer_count, status_ptr, st),
               "lmc_decode_chunks_layers")
+
+    def decode_chunks_schedule(self, blob_ptrs: int, max_blob_bytes: int, nchunks: int, dst: KVLayout, dst_tok0: int,
+                               chunk_tokens: int, layer_ends, events, stream: Optional[int] = None,
+                               status_ptr: Optional[int] = None) -> None:
+        """lmc_decode_chunks_schedule: one launch per range of layers [layer_ends[i - 1], layer_ends[i]) and one event
+        record behind each (events: NativeEvent objects), in ONE call.  layer_ends / events may be prebuilt ctypes arrays
+        (a cached retrieval plan passes the same ones every time)."""
+        st = current_stream_ptr(dst.device) if stream is None else stream
+        if isinstance(layer_ends, ctypes.Array):
+            ends, n = layer_ends, len(layer_ends)
+        else:
+            n = len(layer_ends)
+            ends = (ctypes.c_int32 * n)(*layer_ends)
+        if events is None or isinstance(events, ctypes.Array):
+            evs = events
+        else:
+            evs = (ctypes.c_void_p * n)(*[e.handle for e in events])
+        check(lib().lmc_decode_chunks_schedule(self.handle, blob_ptrs, max_blob_bytes, nchunks, ctypes.byref(dst.struct),
+                                               dst_tok0, chunk_tokens, n, ends, evs, status_ptr, st),
+              "lmc_decode_chunks_schedule")
 
     def store_chunks(self, src: KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int, bins, host_arena_ptr: int,
                      host_cap: int, offsets_ptr: int, sizes_ptr: int, stream: Optional[int] = None,

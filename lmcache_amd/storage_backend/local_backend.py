@@ -126,6 +126,8 @@ class LMCLocalBackend(LMCBackendInterface):
         self._stage: Optional[torch.Tensor] = None   # device staging for raw gathers / scatters
         self._stage_free: Optional[torch.cuda.Event] = None
         self._cuda_device = torch.cuda.current_device()
+        self._gen = 0               # bumped by every _publish: what _prefix_entries' kept answer is valid for
+        self._prefix_memo = None
         self.put_queue: "queue.Queue" = queue.Queue()
         self.put_thread = threading.Thread(target=self.put_worker, daemon=True)
         self.put_thread.start()
@@ -134,9 +136,31 @@ class LMCLocalBackend(LMCBackendInterface):
     def contains(self, key: CacheEngineKey) -> bool:
         return key in self.dict
 
+    def _prefix_entries(self, keys: Sequence[CacheEngineKey]) -> list:
+        """The entries of the leading keys that are present (stop at the first miss).  The last answer is kept for the SAME
+        key list object while nothing has been published since (the engine keeps the key lists of its last hash chains:
+        the lookup -> retrieve of a warm prefix probes the same 64 keys twice, every call of a serving engine)."""
+        m = self._prefix_memo
+        if m is not None and m[0] is keys and m[1] == self._gen:
+            return m[2]
+        d, entries = self.dict, []
+        for k in keys:
+            e = d.get(k)
+            if e is None:
+                break
+            entries.append(e)
+        self._prefix_memo = (keys, self._gen, entries)
+        return entries
+
+    def contains_prefix(self, keys: Sequence[CacheEngineKey]) -> int:
+        """How many leading keys are present: the engine's prefix probe (cache_engine.py:323-345: stop at the first
+        miss) as one call."""
+        return len(self._prefix_entries(keys))
+
     def _publish(self, key: CacheEngineKey, entry) -> None:
         with self.update_lock:
             self.dict[key] = entry
+            self._gen += 1
 
     @_lmcache_nvtx_annotate
     def put_worker(self):
@@ -382,12 +406,7 @@ class LMCLocalBackend(LMCBackendInterface):
         below 0 are dropped (retrieve()'s first-chunk trim, cache_engine.py:360-365).  Returns the number of
         leading chunks written (a key that has gone since `contains` ends the run, like the reference's break on
         the first None chunk, cache_engine.py:339-345); raises NativeError if a stored blob does not decode."""
-        entries = []
-        for k in keys:
-            e = self.dict.get(k)
-            if e is None:
-                break
-            entries.append(e)
+        entries = self._prefix_entries(keys)
         if not entries:
             return 0
         ctx = native.get_context(self._cuda_device)
@@ -397,7 +416,10 @@ class LMCLocalBackend(LMCBackendInterface):
             # returns at once and the caller finishes the job (engine.retrieve_layerwise)
             codec = self._codec()
             with torch.cuda.device(dev):
-                job = codec.decode_device([e.blob for e in entries], dst, dst_tok0, chunk_tokens, layers_per_launch)
+                # (`entries` is the SAME list object for a repeated lookup of one prefix -- _prefix_entries -- and the codec
+                # keeps the uploaded address table of the last few lists it has seen)
+                job = codec.decode_device([e.blob for e in entries], dst, dst_tok0, chunk_tokens, layers_per_launch,
+                                          same_blobs_as=entries)
             if jobs_out is not None:
                 jobs_out.append((codec, job))
             else:

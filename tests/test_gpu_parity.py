@@ -926,3 +926,29 @@ def test_round4_cdf16_blobs_of_short_chunks_still_decode(nat, ctx, oracle, T):
         torch.cuda.synchronize()
         ctx.raise_on_status("decode of a CDF16 blob")
         assert np.array_equal(bits_np(out).reshape(L, 2, T, H * D), oracle.decode_blob(old, ocode))
+
+
+def test_decode_schedule_in_one_call_equals_the_oracle(nat, ctx, oracle):
+    """lmc_decode_chunks_schedule (round 6): every range of layers of a retrieve launched, and its event recorded, by ONE
+    C-ABI call -- the result is the oracle's decode, the events fire in order, a schedule that does not cover the layers
+    exactly is refused before anything is launched."""
+    L, T, H, D, n = 5, 256, 2, 128, 3
+    kv = make_kv(L, n * T, H, D, torch.bfloat16, "randn", seed=11)
+    bins = default_bins(L)
+    blobs, blob_dev, stride = encode(nat, ctx, nat.KVLayout.from_chunk(kv.to(DEV), "vllm"), 0, n * T, T, bins)
+    table = torch.tensor([blob_dev.data_ptr() + i * stride for i in range(n)], dtype=torch.int64, device=DEV)
+    out = torch.zeros(L, 2, n * T, H, D, dtype=torch.bfloat16, device=DEV)
+    lay = nat.KVLayout.from_chunk(out, "vllm")
+    evs = [nat.NativeEvent() for _ in range(3)]
+    ctx.decode_chunks_schedule(table.data_ptr(), stride, n, lay, 0, T, [1, 3, L], evs)
+    evs[-1].synchronize()
+    assert all(e.query() for e in evs)
+    ctx.raise_on_status("decode schedule")
+    for i in range(n):
+        b, code = oracle.torch_to_bits(kv[:, :, i * T:(i + 1) * T].reshape(L, 2, T, H * D))
+        want = oracle.decode_blob(oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)), oracle.BF16)
+        assert blobs[i] == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+        assert np.array_equal(bits_np(out[:, :, i * T:(i + 1) * T]).reshape(L, 2, T, H * D), want)
+    for bad in ([1, 3], [3, 1, L], [0, L], [2, 2, L], [1, L + 1]):
+        with pytest.raises(nat.NativeError):
+            ctx.decode_chunks_schedule(table.data_ptr(), stride, n, lay, 0, T, bad, None)

@@ -26,7 +26,8 @@ def main():
     toks = torch.randint(0, 32000, (bench.CTX,), generator=torch.Generator().manual_seed(7))
     engine.store(toks, kv)
     side = torch.cuda.Stream(device=dev, priority=-1)
-    scheds = [int(a) for a in sys.argv[1:]] or [1, 2, 32]
+    # a range size, or a schedule of range sizes "4,28"
+    scheds = [(int(a) if "," not in a else tuple(int(x) for x in a.split(","))) for a in sys.argv[1:]] or [1, 2, 32]
     for lpl in scheds:
         def once():
             with torch.cuda.stream(side):
@@ -35,6 +36,14 @@ def main():
         for _ in range(3):
             once().finish()
             torch.cuda.synchronize()
+        plain = []
+        for _ in range(30):  # without the profiler: what bench.py's host_ms_before_the_model_can_start measures
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = once()
+            plain.append((time.perf_counter() - t0) * 1e3)
+            res.finish()
+        print(f"== layers_per_launch {lpl}: median {sorted(plain)[15]:.3f} ms per call, min {min(plain):.3f} (no profiler)")
         ts = []
         pr = cProfile.Profile()
         for _ in range(30):
