@@ -1223,7 +1223,10 @@ def overlap_legs(dev, kv, raw_bytes):
             if engine.engine_.contains(last_key):
                 done_at = time.perf_counter() - t0
         hidden.append(median(steps))
-        store_ms.append(done_at * 1e3)
+        # (the loop above looks once per proxy step, i.e. every 3 ms: the backend's own time stamp of the publication of the
+        # store's last key is the completion time, the loop only decides how many steps to run)
+        stamp = getattr(engine.engine_, "last_publish_time", 0.0)
+        store_ms.append((stamp - t0 if stamp > t0 else done_at) * 1e3)
         last_toks = toks
     store_hidden = {"proxy_step_ms_alone": round(alone, 3), "proxy_step_ms_during_store": round(median(hidden), 3),
                     "ratio": round(median(hidden) / alone, 4), "target": "<= 1.05",

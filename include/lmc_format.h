@@ -309,24 +309,30 @@ static inline uint64_t lmc_blob_bound(uint32_t L, uint32_t T, uint32_t H, uint32
 }
 
 
-/* ---- pack: the blobs of ONE store call, laid out layer-major for the pinned host tier -------------------------
+/* ---- pack: the blobs of ONE store call, laid out plane-major for the pinned host tier -------------------------
  *
  * A chunk's blob is chunk-major: header, static sections, then the streams of plane 0, 1, ...  Retrieving a context
  * layer range by layer range from such blobs means one short copy per (chunk, K run, V run, range).  A pack holds the
- * same bytes transposed, so that the streams of a range of LAYERS of all chunks are one contiguous region:
+ * same bytes transposed, so that the streams of a range of LAYERS of all chunks are two contiguous regions (their K
+ * planes, their V planes):
  *
  *   [0, 256)        lmc_pack_header
- *   off_table       uint64 seg_off[2 L n + 1]: segment (layer, kv, chunk) -- index (2 layer + kv) n + chunk -- starts at
- *                   off_streams + seg_off[index]; the last entry is the size of the streams region
+ *   off_table       uint64 seg_off[2 L n + 1]: segment (plane, chunk) -- index p n + chunk, p = kv L + layer: the blob's
+ *                   plane order, K planes of every layer, then V planes -- starts at off_streams + seg_off[index]; the
+ *                   last entry is the size of the streams region
  *   off_static      n slots of static_stride bytes: bytes [0, off_streams) of chunk i's blob (header, bins, scales,
  *                   checksums, stream directory), unchanged
- *   off_streams     the segments, in table order; segment (layer, kv, chunk) = the streams of plane kv L + layer of
- *                   chunk `chunk`: bytes [S, E) of the blob's streams section, S = beg of stream (p, 0),
- *                   E = beg of stream (p + 1, 0) (the end of the section for the last plane)
+ *   off_streams     the segments, in table order; segment (p, chunk) = the streams of plane p of chunk `chunk`: bytes
+ *                   [S, E) of the blob's streams section, S = beg of stream (p, 0), E = beg of stream (p + 1, 0) (the end
+ *                   of the section for the last plane)
  * Every offset is a multiple of 16.  The blob of chunk i is recovered byte for byte from its static slot and its 2 L
- * segments (lmc_pack_extract, lmc_hip.h); the pack is written by the GPU (lmc_store_pack) and read by lmc_load_pack. */
+ * segments (lmc_pack_extract, lmc_hip.h); the pack is written by the GPU (lmc_store_pack) and read by lmc_load_pack.
+ * Version 3 (round 6): plane order.  Version 2 ordered the segments (layer, K/V, chunk) -- one region per range of
+ * layers, but a region that is complete only when the encoder has reached the layers' V planes, i.e. at the very end;
+ * in plane order the K half of a range is final after a fraction of the encode, and a store that launches its encode
+ * in plane ranges (lmc_store_pack_parts) sends each range over PCIe while the later planes are still being coded. */
 #define LMC_PACK_MAGIC 0x4b504d4cu /* "LMPK" */
-#define LMC_PACK_VERSION 2u
+#define LMC_PACK_VERSION 3u
 #define LMC_PACK_HEADER_BYTES 256u
 typedef struct lmc_pack_header {
   uint32_t magic;

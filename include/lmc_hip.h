@@ -307,7 +307,8 @@ int lmc_load_chunks(lmc_ctx* ctx, const void* const* host_blob_ptrs_h, const uin
 /*
  * Packs: the layer-major form of the pinned host tier (lmc_format.h, "pack").  lmc_store_pack is lmc_store_chunks with
  * the job's blobs written TRANSPOSED into one pinned region -- static sections of every chunk, then the streams ordered
- * (layer, K/V, chunk) -- so that lmc_load_pack moves the streams of a range of layers as ONE hipMemcpyAsync and the
+ * (plane, chunk): K planes of every layer, then V planes -- so that lmc_load_pack moves the streams of a range of layers
+ * as TWO hipMemcpyAsync (their K planes, their V planes) and the
  * model's first layers run while the later ranges are still crossing PCIe.  That is the order the consumer needs and
  * the reference cannot produce: its chunks arrive whole, one `.to("cuda")` each (local_backend.py:128-144), and
  * nothing can be decoded before the last one (cache_engine.py:339-381).
@@ -327,13 +328,29 @@ int lmc_load_chunks(lmc_ctx* ctx, const void* const* host_blob_ptrs_h, const uin
  *   one-chunk path of the backend, and how the tests pin a pack to the oracle).
  * lmc_load_pack: chunks [chunk_begin, chunk_begin + nchunks) of the pack (nchunks 0 = all that follow chunk_begin) ->
  *   decoded KV in `dst`, chunk chunk_begin + i at tokens dst_tok0 + i * chunk_tokens.  Offset table and static slots go first, then per range of `layers_per_range` layers
- *   (0 = all in one) the streams -- one copy per range for the whole pack, one per (layer, K/V) for a run of its
+ *   (0 = all in one) the streams -- two copies per range for the whole pack, one per (layer, K/V) for a run of its
  *   chunks -- each followed by the range's decode on `stream` and, if given, range_events[r].  The pack must stay where it
  *   is until `stream` has completed.  LMC_ERR_INVALID, with nothing queued, if the pack does not check out.
  */
 int lmc_store_pack(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
                    const int32_t* bins_h, void* pack_h, uint64_t pack_cap, uint32_t* sizes_h, uint32_t* job_status,
                    lmc_stream_t stream);
+/*
+ * lmc_store_pack with the encode launched in `nparts` ranges of planes, each range packed as soon as it is coded
+ * (round 6): after part r the streams region holds part r's segments at their final offsets, part_info_h[2 r] =
+ * the part's offset in the streams region, part_info_h[2 r + 1] = its bytes (0: the pack has failed), and
+ * part_events[r] is recorded on `stream` -- the caller moves [off_streams + offset, + bytes) to host memory with a
+ * DMA copy while the later planes are still being encoded (CacheGenDeviceCodec.store_pack / finish_pack: a 16 k
+ * store completes when its last PCIe byte lands, where lmc_store_pack + one copy of the finished pack waits for the
+ * whole encode first).  Header, offset table and static slots ([0, off_streams)) are final after the LAST part.
+ * pack_d must be DEVICE memory (a kernel that posts PCIe writes between the encode's parts would stall them);
+ * part_info_h: pinned uint64 [2 nparts]; part_events: [nparts] events or NULL.  A job that cannot be split (a ragged
+ * last chunk, a job too small for the fused encode) runs as ONE part: part_info_h[1 .. ) read {0, 0} and the
+ * events of the unused parts are recorded behind the only one.  nparts <= 16.
+ */
+int lmc_store_pack_parts(lmc_ctx* ctx, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
+                         const int32_t* bins_h, void* pack_d, uint64_t pack_cap, uint32_t* sizes_h, int32_t nparts,
+                         uint64_t* part_info_h, const lmc_event_t* part_events, uint32_t* job_status, lmc_stream_t stream);
 int lmc_pack_info(const void* pack_h, uint64_t nbytes, lmc_pack_header* out);
 int lmc_pack_extract(const void* pack_h, uint64_t nbytes, int32_t chunk, void* blob_out, uint64_t cap, uint32_t* size_out);
 int lmc_load_pack(lmc_ctx* ctx, const void* pack_h, uint64_t pack_bytes, int32_t chunk_begin, int32_t nchunks,

@@ -40,7 +40,7 @@ struct DecodeArgs {
   int P, C, G;
   u32* status;
   // pack (lmc_format.h): `blobs` / `blob_stride` are the static slots, the streams of plane (layer, kv) of chunk c lie at
-  // seg_streams + seg_off[(2 layer + kv) seg_n + c]
+  // seg_streams + seg_off[(kv L + layer) seg_n + c]
   const unsigned long long* seg_off;
   const u8* seg_streams;
   int seg_n;
@@ -114,8 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   const u8* sbytes = blob + bo.streams + start;
   bool seg_bad = false;
   if (a.seg_off) {  // pack: this plane's streams are a segment of their own, wave-uniform addresses
-    const int Lh = a.P >> 1, layer = p < Lh ? p : p - Lh;
-    const long long si = (long long)(2 * layer + (p >= Lh ? 1 : 0)) * a.seg_n + chunk;
+    const long long si = (long long)p * a.seg_n + chunk;  // pack v3: segments in plane order (K planes, then V planes)
     const unsigned long long so = uniform_ptr((const void*)a.seg_off[si]), se = uniform_ptr((const void*)a.seg_off[si + 1]);
     const u32 sbeg = (u32)__builtin_amdgcn_readfirstlane((int)gdir[2 * (p * a.G)]);  // the plane's first stream
     seg_bad = start < sbeg || se < so || (unsigned long long)end - sbeg > se - so;

@@ -58,6 +58,9 @@ struct FusedArgs {
   long long scale_stride;
   u32 epoch;  // 1 .. 2^30 - 1
   int pl, ipc;   // planes per work item, items per chunk = ceil(P / pl)
+  u32 item_base; // the first work item of THIS launch: a job may be launched in ranges of items (plane ranges of all its
+                 // chunks: lmc_store_pack_parts) -- same epoch, so a later range's look-back finds the earlier ranges'
+                 // granules published
 };
 
 __device__ __forceinline__ void aggE_store(unsigned long long* p, unsigned long long flag, u32 epoch, u32 v) {
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // consecutive work items are the same planes of consecutive chunks (see k_cdf_encode): an item's predecessors
   // in the look-back were taken at least nchunks workgroups earlier.  The item comes from a ticket, not from
   // blockIdx (EncodeArgs::ticket): a predecessor's workgroup has started, whatever order the hardware dispatches in.
-  const u32 item = (u32)__builtin_amdgcn_readfirstlane((int)draw_ticket(a.ticket, a.ticket_base));
+  const u32 item = fa.item_base + (u32)__builtin_amdgcn_readfirstlane((int)draw_ticket(a.ticket, a.ticket_base));
   const int chunk = (int)(item % (unsigned)a.nchunks), it = (int)(item / (unsigned)a.nchunks);
   const int p0 = it * fa.pl, np = min(fa.pl, a.P - p0);  // the item's planes
   const int NS = np * a.G;                               // ... and streams: j -> plane p0 + j / G, group j % G

@@ -78,84 +78,118 @@ __global__ __launch_bounds__(256) void k_offload(OffloadArgs a) {
 }
 
 
-// ---- pack: the blobs of one store call, transposed layer-major on their way to the pinned arena (lmc_format.h) ---
+// ---- pack: the blobs of one store call, transposed plane-major on their way to the pinned arena (lmc_format.h) ---
 //
-// k_pack_scan   one workgroup: the size of every (layer, kv, chunk) segment from the blobs' stream directories, their
-//               exclusive prefix sums in table order -> the pack's offset table (pinned, and a device copy for the
-//               copy kernel), the pack header with its total size.
-// k_pack_copy   a fixed number of workgroups walk the segments and the static slots and write them into the mapped
-//               pinned region (16-byte accesses, four loads in flight per thread; PCIe-bound like k_offload).
+// k_pack_scan   one workgroup: the size of every (plane, chunk) segment of planes [p_begin, p_end) from the blobs' stream
+//               directories, their exclusive prefix sums in table order on top of the running total of the parts in
+//               front -> the pack's offset table (in the pack, and a device copy for the copy kernel); the LAST part
+//               also writes the pack header with the total size.  (Round 6: a store whose encode is launched in plane
+//               ranges -- lmc_store_pack_parts -- packs each range as soon as it is coded, so that its bytes can leave
+//               over PCIe while the later planes are still being encoded.  Pack format v3 orders the segments by
+//               PLANE, K planes then V planes, which is the order the encoder finishes them in.)
+// k_pack_copy   a fixed number of workgroups walk the part's segments (the last part: the static slots as well) and
+//               write them into the pack region (16-byte accesses, four loads in flight per thread).
 struct PackArgs {
   const u8* blobs;              // device arena, blob i at blobs + i * stride (what lmc_encode_chunks wrote)
   long long stride;
-  const u32* sizes_d;           // [n] blob sizes (0: the chunk's encode failed)
+  const u32* sizes_d;           // [n] blob sizes (0: the chunk's encode failed); read by the LAST part only
   int n, L, G;
-  u8* host;                     // pinned, device-mapped: where the pack goes
+  u8* host;                     // where the pack goes: pinned device-mapped host memory, or device memory
   unsigned long long cap;
-  unsigned long long* table_d;  // device copy of the offset table, [2 L n + 1]
+  unsigned long long* table_d;  // device copy of the offset table, [2 L n + 1], + [2 L n + 1] = the running total of the parts so far
   lmc_pack_header hdr;          // filled in by the host but for total_bytes
   u32* status;
+  int p_begin, p_end, last;     // this part: planes [p_begin, p_end) of every chunk; last: p_end == 2 L
+  unsigned long long* part_h;   // NULL, or two words for the caller: {offset of the part in the streams region, its bytes}
 };
 
-// Bytes of segment idx = (layer, kv, chunk) -- the streams of one plane of one chunk: from the beginning of the plane's
+// Bytes of segment idx = (plane, chunk) -- the streams of one plane of one chunk: from the beginning of the plane's
 // first stream to the beginning of the next plane's (the end of the streams section for the last plane) -- and where
-// it begins in the blob.  Every header word is checked before it is used as an offset: a chunk whose encode did not
-// finish (size word 0: lmc_encode_chunks zeroes the words in front of the job) or whose header is not a v6 header of
-// this geometry gives 0 bytes, and k_pack_scan fails the pack.
-__device__ __forceinline__ u32 pack_seg_bytes(const PackArgs& a, int idx, u32* begin) {
-  const int lk = idx / a.n, chunk = idx - lk * a.n;
-  const int P = 2 * a.L, p = (lk & 1) * a.L + (lk >> 1);
+// it begins in the blob.  Every header word is checked before it is used as an offset.
+// check: the blob's header and size word are there -- they are written by the chunk's LAST work item, so only the last
+// part of a store can hold them against the geometry; a chunk whose encode did not finish (size word 0) or whose header
+// is not a v6 header of this geometry gives 0 bytes, and k_pack_scan fails the pack.  The earlier parts (!check) go by
+// the stream directory alone: the caller hands them planes whose SUCCESSOR has been coded too (the end of a plane is the
+// `beg` its successor's first stream wrote), of full chunks only (lmc_api.hip splits a store only when it has no ragged
+// chunk: every blob then has the layout of a chunk_tokens-token blob).
+__device__ __forceinline__ u32 pack_seg_bytes(const PackArgs& a, int idx, u32* begin, bool check) {
+  const int p = idx / a.n, chunk = idx - p * a.n;
+  const int P = 2 * a.L;
   const u8* blob = a.blobs + (long long)chunk * a.stride;
   const u32* hd = reinterpret_cast<const u32*>(blob);
   if (begin) *begin = 0u;
-  if (a.sizes_d[chunk] == 0u || hd[0] != LMC_BLOB_MAGIC || (hd[1] & 0xffffu) != LMC_BLOB_VERSION || hd[8] != (u32)P ||
-      hd[9] != (u32)a.G)
-    return 0u;
-  const BlobOff bo = lmc_blob_off((u32)P, hd[4], (u32)a.G);
-  if (hd[14] != bo.gdir || hd[15] != bo.streams || (unsigned long long)bo.streams + hd[16] > (unsigned long long)a.stride) return 0u;
+  BlobOff bo = lmc_blob_off((u32)P, (u32)a.hdr.chunk_tokens, (u32)a.G);
+  u32 stream_bytes = (u32)min((unsigned long long)a.stride - bo.streams, 0xfffffff0ull);
+  if (check) {
+    if (a.sizes_d[chunk] == 0u || hd[0] != LMC_BLOB_MAGIC || (hd[1] & 0xffffu) != LMC_BLOB_VERSION || hd[8] != (u32)P ||
+        hd[9] != (u32)a.G)
+      return 0u;
+    bo = lmc_blob_off((u32)P, hd[4], (u32)a.G);  // the chunk's own length (a ragged last chunk is shorter)
+    if (hd[14] != bo.gdir || hd[15] != bo.streams || (unsigned long long)bo.streams + hd[16] > (unsigned long long)a.stride) return 0u;
+    stream_bytes = hd[16];
+  } else if (p + 1 >= P) {
+    return 0u;  // (the last plane ends with the section: the last part's)
+  }
   const u32* gdir = reinterpret_cast<const u32*>(blob + bo.gdir);
   const u32 s = gdir[2 * (p * a.G)];
-  const u32 e = p + 1 < P ? gdir[2 * ((p + 1) * a.G)] : hd[16];
+  const u32 e = p + 1 < P ? gdir[2 * ((p + 1) * a.G)] : stream_bytes;
   if (begin) *begin = bo.streams + s;
-  return e >= s && e <= hd[16] && !(s & 15u) && !(e & 15u) ? e - s : 0u;
+  return e >= s && e <= stream_bytes && !(s & 15u) && !(e & 15u) ? e - s : 0u;
 }
 
+// One part of a pack: planes [p_begin, p_end).  table_d[N + 1] carries the running total from part to part (the host
+// zeroes it in front of the first part); table_d[N] == ~0 says "the pack has failed": later parts do nothing.
 __global__ __launch_bounds__(256) void k_pack_scan(PackArgs a) {
   __shared__ unsigned long long sums[256];
-  const int N = 2 * a.L * a.n, K = (N + 255) / 256;
-  const int t = (int)threadIdx.x, i0 = t * K, i1 = min(N, i0 + K);
+  const int N = 2 * a.L * a.n;
+  const int s0 = a.p_begin * a.n, M = (a.p_end - a.p_begin) * a.n, K = (M + 255) / 256;
+  const int t = (int)threadIdx.x, i0 = s0 + t * K, i1 = min(s0 + M, i0 + K);
+  const bool check = a.last != 0;
+  const bool failed = a.p_begin > 0 && a.table_d[N] == ~0ull;
   unsigned long long mine = 0;
   int empty = 0;  // a segment of no bytes: its chunk's encode did not finish, or its header does not check out
   for (int i = i0; i < i1; i++) {
-    const u32 b = pack_seg_bytes(a, i, nullptr);
+    const u32 b = pack_seg_bytes(a, i, nullptr, check);
     empty |= b == 0u;
     mine += b;
   }
   sums[t] = mine;
-  const bool bad = __syncthreads_or(empty) != 0;
+  const bool bad = __syncthreads_or(empty) != 0 || failed;
   unsigned long long off = 0, total = 0;
-  for (int j = 0; j < 256; j++) {  // 256 adds per thread: one launch per store
+  for (int j = 0; j < 256; j++) {  // 256 adds per thread: one launch per part
     off += j < t ? sums[j] : 0ull;
     total += sums[j];
   }
-  const bool fits = !bad && a.hdr.off_streams + total <= a.cap;
+  const unsigned long long base = a.p_begin > 0 ? a.table_d[N + 1] : 0ull;
+  const bool fits = !bad && a.hdr.off_streams + base + total <= a.cap;
   unsigned long long* table_h = reinterpret_cast<unsigned long long*>(a.host + a.hdr.off_table);
+  off += base;
   for (int i = i0; i < i1; i++) {
     a.table_d[i] = off;
     if (fits) table_h[i] = off;
-    off += pack_seg_bytes(a, i, nullptr);
+    off += pack_seg_bytes(a, i, nullptr, check);
   }
+  __syncthreads();  // (every thread has read table_d[N + 1] before thread 0 moves it on)
   if (t == 0) {
-    a.table_d[N] = fits ? total : ~0ull;  // all ones: nothing is copied
-    if (fits) {
-      table_h[N] = total;
-      if (a.hdr.off_static > a.hdr.off_table + 8ull * (unsigned long long)(N + 1)) table_h[N + 1] = 0ull;  // alignment pad
+    a.table_d[N + 1] = base + total;
+    if (!fits) a.table_d[N] = ~0ull;  // all ones: nothing more is copied
+    else if (a.p_begin == 0) a.table_d[N] = 0ull;  // (whatever an earlier job left there)
+    if (a.part_h) {
+      a.part_h[0] = base;
+      a.part_h[1] = fits ? total : 0ull;
     }
-    lmc_pack_header h = a.hdr;
-    h.total_bytes = fits ? a.hdr.off_streams + total : 0ull;  // 0: not a pack
-    if (!fits) h.magic = 0u;
-    *reinterpret_cast<lmc_pack_header*>(a.host) = h;
-    if (!fits) atomicOr(a.status, LMC_ST_HOST_ARENA_FULL);
+    if (a.last) {
+      if (fits) {
+        a.table_d[N] = base + total;
+        table_h[N] = base + total;
+        if (a.hdr.off_static > a.hdr.off_table + 8ull * (unsigned long long)(N + 1)) table_h[N + 1] = 0ull;  // alignment pad
+      }
+      lmc_pack_header h = a.hdr;
+      h.total_bytes = fits ? a.hdr.off_streams + base + total : 0ull;  // 0: not a pack
+      if (!fits) h.magic = 0u;
+      *reinterpret_cast<lmc_pack_header*>(a.host) = h;
+    }
+    if (!fits && !failed) atomicOr(a.status, LMC_ST_HOST_ARENA_FULL);
   }
 }
 
@@ -169,19 +203,22 @@ __device__ __forceinline__ void pack_copy16(uint4* dst, const uint4* src, u32 n1
   for (; i < n16; i += step) dst[i] = src[i];
 }
 
-// grid = (workgroups), 256 threads: workgroup w takes items w, w + gridDim.x, ... of the 2 L n segments + n static slots
+// grid = (workgroups), 256 threads: workgroup w takes items w, w + gridDim.x, ... of the part's segments (+ the n static
+// slots in the last part)
 __global__ __launch_bounds__(256) void k_pack_copy(PackArgs a) {
   const int N = 2 * a.L * a.n;
   if (a.table_d[N] == ~0ull) return;
-  for (int item = (int)blockIdx.x; item < N + a.n; item += (int)gridDim.x) {
-    if (item < N) {
+  const int s0 = a.p_begin * a.n, M = (a.p_end - a.p_begin) * a.n;
+  const bool check = a.last != 0;
+  for (int item = (int)blockIdx.x; item < M + (a.last ? a.n : 0); item += (int)gridDim.x) {
+    if (item < M) {
       u32 begin;
-      const u32 bytes = pack_seg_bytes(a, item, &begin);
-      const int chunk = item % a.n;
-      pack_copy16(reinterpret_cast<uint4*>(a.host + a.hdr.off_streams + a.table_d[item]),
+      const u32 bytes = pack_seg_bytes(a, s0 + item, &begin, check);
+      const int chunk = (s0 + item) % a.n;
+      pack_copy16(reinterpret_cast<uint4*>(a.host + a.hdr.off_streams + a.table_d[s0 + item]),
                   reinterpret_cast<const uint4*>(a.blobs + (long long)chunk * a.stride + begin), bytes >> 4);
     } else {
-      const int chunk = item - N;
+      const int chunk = item - M;
       const u8* blob = a.blobs + (long long)chunk * a.stride;
       const u32 bytes = min((reinterpret_cast<const u32*>(blob)[15] + 15u) & ~15u, a.hdr.static_stride);
       uint4* slot = reinterpret_cast<uint4*>(a.host + a.hdr.off_static + (unsigned long long)chunk * a.hdr.static_stride);

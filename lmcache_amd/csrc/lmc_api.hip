@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <stdlib.h>
@@ -336,9 +337,24 @@ int lmc_calculate_cdf(lmc_ctx* c, const int8_t* sym, int32_t P, int32_t T, int32
   return LMC_OK;
 }
 
+// lmc_encode_chunks, optionally launched in `nparts` ranges of PLANES (all chunks of the job): after part r,
+// after_part(r, planes coded so far, last part?) runs with the context lock held (lmc_store_pack_parts packs the range
+// there).  Only a job that takes the fused kernel for every chunk is split; any other job is one part.
+typedef std::function<int(int, int, bool)> AfterPart;
+static int encode_chunks_parts(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
+                               const int32_t* bins_h, void* blobs, uint64_t blob_stride, uint32_t* sizes, uint32_t* job_status,
+                               lmc_stream_t stream, int nparts, const AfterPart* after_part);
+
 int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
                       const int32_t* bins_h, void* blobs, uint64_t blob_stride, uint32_t* sizes, uint32_t* job_status,
                       lmc_stream_t stream) {
+  return encode_chunks_parts(c, src, tok_begin, tok_end, chunk_tokens, bins_h, blobs, blob_stride, sizes, job_status, stream, 1,
+                             nullptr);
+}
+
+static int encode_chunks_parts(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
+                               const int32_t* bins_h, void* blobs, uint64_t blob_stride, uint32_t* sizes, uint32_t* job_status,
+                               lmc_stream_t stream, int nparts, const AfterPart* after_part) {
   if (!c || !layout_ok(src) || tok_begin < 0 || tok_end <= tok_begin || chunk_tokens < 1 || chunk_tokens > 65535 ||
       !blobs || !sizes || ((uintptr_t)blobs & 15) || (blob_stride & 15))
     return LMC_ERR_INVALID;
@@ -354,6 +370,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
   hipStream_t s = (hipStream_t)stream;
 
   std::lock_guard<std::mutex> lk(c->mu);
+  bool split_done = false;  // the fused launch went out in plane ranges and after_part ran behind each
   // k_fused.h codes the 256-token chunks (the counts model) of every plane width: a work item is a run of whole planes
   // of one chunk -- 8 planes of <= 128 channels, 4 of <= 256, else one
   const int nfull = (tok_end - tok_begin) / chunk_tokens;  // chunks of exactly chunk_tokens tokens; a ragged one may follow
@@ -483,14 +500,24 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     if (!c->epoch) c->epoch = 1u;
     fa.epoch = c->epoch;
     fa.pl = pl; fa.ipc = ipc;
-    const dim3 grid((unsigned)((long long)nfull * ipc)), block(64 * FUSED_WAVES);
-    fa.e.ticket_base = w->tickets_drawn;
+    // items are plane-major across the chunks (item = it * nfull + chunk): a range of `it` is a range of planes of ALL
+    // chunks.  One launch, or -- a store that packs and ships the planes as they are coded -- `nparts` of them.
+    const int np = (after_part && nfull == nchunks && nparts > 1) ? std::min(nparts, ipc) : 1;
+    split_done = np > 1;
+    const dim3 block(64 * FUSED_WAVES);
     if ((rc = prof_mark(c, s))) return rc;
-    if (src->dtype == LMC_DTYPE_BF16) launch_fused<LMC_DTYPE_BF16>(C, grid, block, s, fa);
-    else launch_fused<LMC_DTYPE_FP16>(C, grid, block, s, fa);
-    const hipError_t le = hipGetLastError();
-    if (le != hipSuccess) { g_last_hip = (int)le; tickets_reset(); return LMC_ERR_HIP; }
-    w->tickets_drawn += grid.x;
+    for (int r = 0; r < np; r++) {
+      const int it0 = (int)((long long)ipc * r / np), it1 = (int)((long long)ipc * (r + 1) / np);
+      const dim3 grid((unsigned)((long long)nfull * (it1 - it0)));
+      fa.item_base = (u32)((long long)it0 * nfull);
+      fa.e.ticket_base = w->tickets_drawn;
+      if (src->dtype == LMC_DTYPE_BF16) launch_fused<LMC_DTYPE_BF16>(C, grid, block, s, fa);
+      else launch_fused<LMC_DTYPE_FP16>(C, grid, block, s, fa);
+      const hipError_t le = hipGetLastError();
+      if (le != hipSuccess) { g_last_hip = (int)le; tickets_reset(); return LMC_ERR_HIP; }
+      w->tickets_drawn += grid.x;
+      if (np > 1 && (rc = (*after_part)(r, std::min(P, it1 * pl), r == np - 1))) return rc;
+    }
     if ((rc = prof_mark(c, s))) return rc;
     if (nfull < nchunks && (rc = two_kernels(nfull, nchunks - nfull))) return rc;  // the ragged last chunk
   } else if (nfull > 0 && nfull < nchunks && !general_only && tail_general) {
@@ -500,6 +527,7 @@ int lmc_encode_chunks(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, i
     if ((rc = two_kernels(0, nchunks))) return rc;
   }
 
+  if (after_part && !split_done && (rc = (*after_part)(0, P, true))) return rc;  // one part: everything is coded
   HIP_TRY(hipEventRecord(w->ws_free, s));
   w->ws_used = true;
   w->last_stream = s;
@@ -832,11 +860,14 @@ int lmc_load_chunks(lmc_ctx* c, const void* const* host_blob_ptrs_h, const uint3
 }
 
 // ---- packs (lmc_format.h): the layer-major form of the pinned host tier ---------------------------------------------
-int lmc_store_pack(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
-                   const int32_t* bins_h, void* pack_h, uint64_t pack_cap, uint32_t* sizes_h, uint32_t* job_status,
-                   lmc_stream_t stream) {
+// lmc_store_pack and lmc_store_pack_parts.  nparts == 0: the pack kernels run on the context's copy stream behind the
+// whole encode (pack_h may be mapped host memory: their PCIe writes then stall nobody's encode); nparts >= 1: the
+// encode goes out in plane ranges and each range is packed on `stream` right behind the launch that coded it.
+static int store_pack_impl(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
+                           const int32_t* bins_h, void* pack_h, uint64_t pack_cap, uint32_t* sizes_h, int32_t nparts,
+                           uint64_t* part_info_h, const lmc_event_t* part_events, uint32_t* job_status, lmc_stream_t stream) {
   if (!c || !layout_ok(src) || tok_begin < 0 || tok_end <= tok_begin || chunk_tokens < 1 || chunk_tokens > 65535 || !bins_h ||
-      !pack_h || ((uintptr_t)pack_h & 15) || !sizes_h)
+      !pack_h || ((uintptr_t)pack_h & 15) || !sizes_h || nparts < 0 || nparts > 16 || (nparts > 0 && !part_info_h))
     return LMC_ERR_INVALID;
   const int nchunks = (tok_end - tok_begin + chunk_tokens - 1) / chunk_tokens;
   const int L = src->num_layers, P = 2 * L;
@@ -853,7 +884,7 @@ int lmc_store_pack(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int3
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  const size_t table_bytes = 8 * ((size_t)P * nchunks + 1);
+  const size_t table_bytes = 8 * ((size_t)P * nchunks + 2);  // the table, and the running total of the parts
   {
     std::lock_guard<std::mutex> lk(c->mu);
     if ((rc = legs_init(c))) return rc;
@@ -866,27 +897,75 @@ int lmc_store_pack(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int3
     }
     if (c->store_used) HIP_TRY(hipStreamWaitEvent(s, c->store_free, 0));  // the previous job's copies have read the arena
   }
-  // the segment offsets need every chunk's stream directory: the whole job is encoded (1 ms per 16 k tokens) before the
-  // first byte leaves (11 ms over PCIe) -- the part-wise overlap of lmc_store_chunks would save less than a tenth
-  if ((rc = lmc_encode_chunks(c, src, tok_begin, tok_end, chunk_tokens, bins_h, c->store_arena, stride, sizes_h, job_status, stream)))
-    return rc;
-  std::lock_guard<std::mutex> lk(c->mu);
-  hipEvent_t ev;
-  if ((rc = next_event(c, &ev))) return rc;
-  HIP_TRY(hipEventRecord(ev, s));
-  HIP_TRY(hipStreamWaitEvent(c->copy_stream, ev, 0));
   pa.blobs = c->store_arena; pa.stride = (long long)stride; pa.sizes_d = sizes_h;
   pa.n = nchunks; pa.L = L; pa.G = (int)pa.hdr.ngroups;
   pa.host = (u8*)pack_h; pa.cap = pack_cap; pa.table_d = c->pack_table;
   pa.status = job_status ? job_status : c->status_h;
-  hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(256), 0, c->copy_stream, pa);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_pack_copy, dim3(64), dim3(256), 0, c->copy_stream, pa);  // PCIe-bound: 64 workgroups fill the link
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(c->store_free, c->copy_stream));
+  if (nparts == 0) {
+    // the whole job is encoded (1 ms per 16 k tokens) before the first byte leaves: the pack kernels on the copy stream
+    if ((rc = lmc_encode_chunks(c, src, tok_begin, tok_end, chunk_tokens, bins_h, c->store_arena, stride, sizes_h, job_status, stream)))
+      return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipEvent_t ev;
+    if ((rc = next_event(c, &ev))) return rc;
+    HIP_TRY(hipEventRecord(ev, s));
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, ev, 0));
+    pa.p_begin = 0; pa.p_end = P; pa.last = 1; pa.part_h = nullptr;
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(256), 0, c->copy_stream, pa);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_pack_copy, dim3(64), dim3(256), 0, c->copy_stream, pa);  // PCIe-bound: 64 workgroups fill the link
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->store_free, c->copy_stream));
+    c->store_used = true;
+    HIP_TRY(hipStreamWaitEvent(s, c->store_free, 0));  // the caller's stream is done when the pack has landed
+    return LMC_OK;
+  }
+  // ---- in parts: plane range r is packed on `stream` behind the launch that coded it.  A plane's end is the `beg` its
+  // successor's first stream writes, so a part that is not the last packs the planes coded so far BUT the newest one,
+  // which rides with the next part (1 / 64 of the data at Llama-3-8B's 64 planes).
+  for (int r = 0; r < nparts; r++) part_info_h[2 * r] = part_info_h[2 * r + 1] = 0;  // (pinned host words: plain stores)
+  int packed = 0, parts_out = 0;
+  const AfterPart after = [&](int r, int coded, bool last) -> int {
+    (void)r;
+    const int upto = last ? P : coded - 1;
+    if (upto > packed || last) {
+      PackArgs q = pa;
+      q.p_begin = packed; q.p_end = upto; q.last = last ? 1 : 0;
+      q.part_h = (unsigned long long*)(part_info_h + 2 * parts_out);
+      hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(256), 0, s, q);
+      HIP_TRY(hipGetLastError());
+      hipLaunchKernelGGL(k_pack_copy, dim3(64), dim3(256), 0, s, q);
+      HIP_TRY(hipGetLastError());
+      packed = upto;
+    }
+    if (part_events && part_events[parts_out]) HIP_TRY(hipEventRecord((hipEvent_t)part_events[parts_out], s));
+    parts_out++;
+    return LMC_OK;
+  };
+  if ((rc = encode_chunks_parts(c, src, tok_begin, tok_end, chunk_tokens, bins_h, c->store_arena, stride, sizes_h, job_status,
+                                stream, nparts, &after)))
+    return rc;
+  std::lock_guard<std::mutex> lk(c->mu);
+  for (; parts_out < nparts; parts_out++)  // a job that could not be split: the unused parts' events fire behind the only one
+    if (part_events && part_events[parts_out]) HIP_TRY(hipEventRecord((hipEvent_t)part_events[parts_out], s));
+  HIP_TRY(hipEventRecord(c->store_free, s));
   c->store_used = true;
-  HIP_TRY(hipStreamWaitEvent(s, c->store_free, 0));  // the caller's stream is done when the pack has landed
   return LMC_OK;
+}
+
+int lmc_store_pack(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
+                   const int32_t* bins_h, void* pack_h, uint64_t pack_cap, uint32_t* sizes_h, uint32_t* job_status,
+                   lmc_stream_t stream) {
+  return store_pack_impl(c, src, tok_begin, tok_end, chunk_tokens, bins_h, pack_h, pack_cap, sizes_h, 0, nullptr, nullptr,
+                         job_status, stream);
+}
+
+int lmc_store_pack_parts(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t tok_end, int32_t chunk_tokens,
+                         const int32_t* bins_h, void* pack_d, uint64_t pack_cap, uint32_t* sizes_h, int32_t nparts,
+                         uint64_t* part_info_h, const lmc_event_t* part_events, uint32_t* job_status, lmc_stream_t stream) {
+  if (nparts < 1) return LMC_ERR_INVALID;
+  return store_pack_impl(c, src, tok_begin, tok_end, chunk_tokens, bins_h, pack_d, pack_cap, sizes_h, nparts, part_info_h,
+                         part_events, job_status, stream);
 }
 
 // Host-side check of a pack that lies in (pinned) host memory.
@@ -932,9 +1011,8 @@ int lmc_pack_extract(const void* pack_h, uint64_t nbytes, int32_t chunk, void* b
   const uint64_t* t = (const uint64_t*)(b + h.off_table);
   const uint32_t L = h.num_layers, n = h.nchunks;
   uint64_t at = bh.off_streams;
-  for (uint32_t p = 0; p < 2 * L; p++) {  // plane order of the blob: K planes of every layer, then V planes
-    const uint32_t layer = p < L ? p : p - L, kv = p < L ? 0u : 1u;
-    const uint64_t i = (uint64_t)(2 * layer + kv) * n + (uint32_t)chunk;
+  for (uint32_t p = 0; p < 2 * L; p++) {  // plane order of the blob and of the pack: K planes of every layer, then V planes
+    const uint64_t i = (uint64_t)p * n + (uint32_t)chunk;
     const uint64_t len = t[i + 1] - t[i];
     if (at + len > bh.total_bytes) return LMC_ERR_INVALID;
     memcpy((u8*)blob_out + at, b + h.off_streams + t[i], len);
@@ -987,13 +1065,17 @@ int lmc_load_pack(lmc_ctx* c, const void* pack_h, uint64_t pack_bytes, int32_t c
     const int nl = l0 + step <= L ? step : L - l0;
     // the streams of layers l0 .. l0 + nl: one contiguous region when the whole pack is wanted, else one run of the
     // m chunks per (layer, kv)
-    if (m == n) {
-      const uint64_t lo = t[(uint64_t)2 * l0 * n], hi = t[(uint64_t)2 * (l0 + nl) * n];
-      if (hi > lo) HIP_TRY(hipMemcpyAsync(dev + h.off_streams + lo, b + h.off_streams + lo, hi - lo, hipMemcpyHostToDevice, cs));
-    } else {
-      for (int lk = 2 * l0; lk < 2 * (l0 + nl); lk++) {
-        const uint64_t lo = t[(uint64_t)lk * n + c0], hi = t[(uint64_t)lk * n + c0 + m];
+    // (pack v3, plane order: the K planes of the range are one contiguous region, its V planes another)
+    for (int kv = 0; kv < 2; kv++) {
+      const int p0 = kv * L + l0;
+      if (m == n) {
+        const uint64_t lo = t[(uint64_t)p0 * n], hi = t[(uint64_t)(p0 + nl) * n];
         if (hi > lo) HIP_TRY(hipMemcpyAsync(dev + h.off_streams + lo, b + h.off_streams + lo, hi - lo, hipMemcpyHostToDevice, cs));
+      } else {
+        for (int p = p0; p < p0 + nl; p++) {
+          const uint64_t lo = t[(uint64_t)p * n + c0], hi = t[(uint64_t)p * n + c0 + m];
+          if (hi > lo) HIP_TRY(hipMemcpyAsync(dev + h.off_streams + lo, b + h.off_streams + lo, hi - lo, hipMemcpyHostToDevice, cs));
+        }
       }
     }
     hipEvent_t ev;

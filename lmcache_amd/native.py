@@ -134,6 +134,7 @@ SYMBOLS = {
     "lmc_store_chunks": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     "lmc_load_chunks": (ctypes.c_int, [_vp, _vp, _vp, _i32, _PL, _i32, _i32, _i32, _vp, _vp, _vp]),
     "lmc_store_pack": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _vp, _vp]),
+    "lmc_store_pack_parts": (ctypes.c_int, [_vp, _PL, _i32, _i32, _i32, _vp, _vp, _u64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "lmc_pack_info": (ctypes.c_int, [_vp, _u64, ctypes.POINTER(PackHeader)]),
     "lmc_pack_extract": (ctypes.c_int, [_vp, _u64, _i32, _vp, _u64, _vp]),
     "lmc_load_pack": (ctypes.c_int, [_vp, _vp, _u64, _i32, _i32, _PL, _i32, _i32, _vp, _vp, _vp]),
@@ -224,6 +225,11 @@ def pack_bound(n: int, L: int, chunk_tokens: int, H: int, D: int) -> int:
     G = (H * D + LANES - 1) // LANES
     static = r16(blob_static_bytes(L, chunk_tokens, H, D))
     return r16(256 + 8 * (2 * L * n + 1)) + n * static + n * 2 * L * G * group_cap_bytes(chunk_tokens)
+
+
+def pack_off_streams(n: int, L: int, chunk_tokens: int, H: int, D: int) -> int:
+    """lmc_pack_layout's off_streams: where the segments of a pack of n chunks begin (header, offset table, static slots in front)."""
+    return r16(256 + 8 * (2 * L * n + 1)) + n * r16(blob_static_bytes(L, chunk_tokens, H, D))
 
 
 def r16(x: int) -> int:
@@ -635,6 +641,20 @@ class Context:
         st = current_stream_ptr(src.device) if stream is None else stream
         check(lib().lmc_store_pack(self.handle, ctypes.byref(src.struct), tok_begin, tok_end, chunk_tokens, b, pack_ptr, pack_cap,
                                    sizes_ptr, status_ptr, st), "lmc_store_pack")
+        return (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
+
+    def store_pack_parts(self, src: KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int, bins, pack_ptr: int,
+                         pack_cap: int, sizes_ptr: int, nparts: int, part_info_ptr: int, part_events,
+                         stream: Optional[int] = None, status_ptr: Optional[int] = None) -> int:
+        """lmc_store_pack_parts: the encode in `nparts` plane ranges, each packed into the DEVICE region at pack_ptr as soon
+        as it is coded; part_info_ptr: pinned uint64 [2 nparts] ({offset in the streams region, bytes} per part);
+        part_events: NativeEvent per part (recorded behind the part's pack kernels)."""
+        b = self._bins(bins)
+        st = current_stream_ptr(src.device) if stream is None else stream
+        evs = None if part_events is None else (ctypes.c_void_p * nparts)(*[e.handle for e in part_events])
+        check(lib().lmc_store_pack_parts(self.handle, ctypes.byref(src.struct), tok_begin, tok_end, chunk_tokens, b, pack_ptr,
+                                         pack_cap, sizes_ptr, nparts, part_info_ptr, evs, status_ptr, st),
+              "lmc_store_pack_parts")
         return (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
 
     def load_pack(self, pack_ptr: int, pack_bytes: int, chunk_begin: int, nchunks: int, dst: KVLayout, dst_tok0: int,

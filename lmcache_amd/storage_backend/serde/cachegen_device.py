@@ -12,6 +12,7 @@ synchronisation: the reference itself flags torch.cuda.synchronize() as harmful
 here, local_backend.py:83-85).
 """
 import ctypes
+import os
 import threading
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
@@ -148,6 +149,12 @@ class PackJob:
     pool: Optional[native.StatusWords] = None
     dev: Optional[torch.Tensor] = None   # dma=True: the HBM region the pack is written to first
     d2h_issued: bool = True              # ... and whether its copies to pinned memory have been queued
+    # dma=True: the encode went out in plane ranges (lmc_store_pack_parts); part r's bytes may leave once part_events[r]
+    # has fired: part_info (pinned uint64 [2 nparts]) says where they lie
+    part_events: Optional[list] = None
+    part_info: Optional[native.PinnedBuffer] = None
+    cap: int = 0
+    geometry: tuple = ()                 # (L, H, D)
 
     def __del__(self):
         if _return_status_word is not None:
@@ -270,6 +277,10 @@ class CacheGenDeviceCodec:
         self._pack_dev_free: Optional[torch.cuda.Event] = None
         self._pack_prev: Optional[PackJob] = None
         self._hdr: Optional[native.PinnedBuffer] = None
+        # plane ranges a pack's encode is launched in (store_pack, dma): LMCACHE_AMD_PACK_PARTS=1 is the round-5 behaviour
+        # (the whole encode, then the pack, then its copies), for A/B
+        self.pack_parts = max(1, min(16, int(os.environ.get("LMCACHE_AMD_PACK_PARTS", "8"))))
+        self._part_info_pool: List[native.PinnedBuffer] = []
         self._same_blobs: dict = {}                          # id(caller's list) -> (the list, its blobs' address tuple)
         self._table_cache: dict = {}                         # blob-address tuple -> (device table, largest blob, upload stream)
 
@@ -560,17 +571,32 @@ class CacheGenDeviceCodec:
             if sizes is None:
                 sizes = native.PinnedBuffer(4 * max(n, 256))
             st = self._status.acquire()
+            part_events = part_info = None
             try:
-                self.ctx.store_pack(src, tok_begin, tok_end, chunk_tokens, bins, dev.data_ptr() if dma else region.ptr, cap,
-                                    sizes.ptr, stream=cur.cuda_stream, status_ptr=self._status.ptr(st))
+                if dma:
+                    # the encode in plane ranges, each packed as soon as it is coded (lmc_store_pack_parts): finish_pack
+                    # sends a range over PCIe while the later planes are still being encoded
+                    nparts = self.pack_parts if n * 2 * L >= 16 * self.pack_parts else 1
+                    part_events = [native.NativeEvent() for _ in range(nparts)]
+                    part_info = self._part_info_pool.pop() if self._part_info_pool else native.PinnedBuffer(16 * 16)
+                    self.ctx.store_pack_parts(src, tok_begin, tok_end, chunk_tokens, bins, dev.data_ptr(), cap, sizes.ptr,
+                                              nparts, part_info.ptr, part_events, stream=cur.cuda_stream,
+                                              status_ptr=self._status.ptr(st))
+                else:
+                    self.ctx.store_pack(src, tok_begin, tok_end, chunk_tokens, bins, region.ptr, cap,
+                                        sizes.ptr, stream=cur.cuda_stream, status_ptr=self._status.ptr(st))
                 done = torch.cuda.Event()
                 done.record(cur)
             except BaseException:
                 self._abandon_status(st, cur)
                 self._size_pool.append(sizes)
+                if part_info is not None:
+                    self._part_info_pool.append(part_info)
                 raise
             job = PackJob(region, n, chunk_tokens, sizes, done, st, pool=self._status)
             job.dev, job.d2h_issued = dev, not dma
+            job.geometry = (L, H, D)
+            job.part_events, job.part_info, job.cap = part_events, part_info, cap
             if dma and dev is self._pack_dev:
                 self._pack_prev = job
             return job
@@ -579,43 +605,71 @@ class CacheGenDeviceCodec:
         """Wait for THIS store (its event), raise NativeError if a kernel flagged it, return the pack in pinned host DRAM
         (dma=True: its size is read from the header the GPU wrote, the pinned region is allocated at that size and two
         DMA queues move one half each)."""
-        job.done.synchronize()
+        if job.dev is None:
+            job.done.synchronize()
+            st = self._release_pack_words(job)
+            if st:
+                raise native.NativeError("CacheGen store (pack): " + native.describe_status(st))
+            h = native.pack_info(job.region.ptr, job.region.nbytes)
+            return HostPack(arena.shrink(job.region, h.total_bytes), job.nchunks, job.chunk_tokens)
+        # dma: the pack is being built in HBM part by part.  Part r leaves as soon as its event has fired -- the host waits
+        # for that event only, reads where the part lies (two pinned words the GPU wrote) and queues ONE DMA copy, on
+        # alternating copy streams (two DMA queues) -- while the later plane ranges are still being encoded; behind the
+        # last part the static sections (header, offset table, static slots) follow.  The pinned region is taken at the
+        # pack's upper bound and cut to its size afterwards.
+        off_streams = native.pack_off_streams(job.nchunks, job.geometry[0], job.chunk_tokens, job.geometry[1], job.geometry[2])
+        region = arena.alloc(job.cap, slab_hint=min(4 * job.cap, 4 << 30))
+        info = job.part_info.tensor.view(torch.int64)
+        streams = [self.copy_stream, self.copy_stream2]
+        total, failed = off_streams, False
+        with torch.cuda.device(self.device):
+            for r, ev in enumerate(job.part_events):
+                ev.synchronize()  # this part only
+                off, nbytes = int(info[2 * r]), int(info[2 * r + 1])
+                if nbytes <= 0:
+                    failed = failed or (r == 0)  # (parts behind the only one of an unsplit job are empty by design)
+                    continue
+                if off_streams + off + nbytes > job.cap:
+                    failed = True
+                    break
+                native.memcpy_async(region.ptr + off_streams + off, job.dev.data_ptr() + off_streams + off, nbytes, "d2h",
+                                    streams[r % 2].cuda_stream)
+                total = off_streams + off + nbytes
+            # (the last part's event has fired: every kernel of the store is done)
+            st = self._release_pack_words(job)
+            with self._lock:
+                if st == 0 and not failed:
+                    native.memcpy_async(region.ptr, job.dev.data_ptr(), off_streams, "d2h", streams[0].cuda_stream)
+                ev2 = torch.cuda.Event()
+                ev2.record(self.copy_stream2)
+                self.copy_stream.wait_event(ev2)
+                evd = torch.cuda.Event()
+                evd.record(self.copy_stream)
+                job.d2h_issued = True
+                if job.dev is self._pack_dev:
+                    self._pack_dev_free = evd
+            evd.synchronize()
+        if st or failed:
+            arena.shrink(region, 0)
+            raise native.NativeError("CacheGen store (pack): " + (native.describe_status(st) if st else "the device left no pack"))
+        h = native.pack_info(region.ptr, total)  # the pack checks out where it lies now
+        if int(h.total_bytes) != total:
+            raise native.NativeError("CacheGen store (pack): the parts do not add up to the pack")
+        return HostPack(arena.shrink(region, total), job.nchunks, job.chunk_tokens)
+
+    def _release_pack_words(self, job: PackJob) -> int:
+        """The store's kernels are done: its status word (returned), its size words and part words go back to their pools."""
         with self._lock:
             st, job.status_idx = self._status.read_release(job.status_idx), -1
             if job.sizes is not None:
                 self._size_pool.append(job.sizes)
                 job.sizes = None
-        if st:
-            job.d2h_issued = True
-            raise native.NativeError("CacheGen store (pack): " + native.describe_status(st))
-        if job.dev is None:
-            h = native.pack_info(job.region.ptr, job.region.nbytes)
-            return HostPack(arena.shrink(job.region, h.total_bytes), job.nchunks, job.chunk_tokens)
-        with self._lock, torch.cuda.device(self.device):
-            if self._hdr is None:
-                self._hdr = native.PinnedBuffer(256)
-            cs = self.copy_stream
-            native.memcpy_async(self._hdr.ptr, job.dev.data_ptr(), 256, "d2h", cs.cuda_stream)
-            cs.synchronize()  # 256 bytes: the size of what follows
-            total = int(self._hdr.tensor[72:80].view(torch.int64)[0])  # lmc_pack_header.total_bytes
-            if total <= 0 or total > job.dev.numel():
+            if job.part_info is not None:
+                self._part_info_pool.append(job.part_info)
+                job.part_info = None
+            if st:
                 job.d2h_issued = True
-                raise native.NativeError("CacheGen store (pack): the device left no pack")
-            region = arena.alloc(total)
-            half = native.r16(total // 2)
-            native.memcpy_async(region.ptr, job.dev.data_ptr(), half, "d2h", cs.cuda_stream)
-            native.memcpy_async(region.ptr + half, job.dev.data_ptr() + half, total - half, "d2h", self.copy_stream2.cuda_stream)
-            ev2 = torch.cuda.Event()
-            ev2.record(self.copy_stream2)
-            cs.wait_event(ev2)
-            ev = torch.cuda.Event()
-            ev.record(cs)
-            job.d2h_issued = True
-            if job.dev is self._pack_dev:
-                self._pack_dev_free = ev
-        ev.synchronize()
-        h = native.pack_info(region.ptr, total)  # the pack checks out where it lies now
-        return HostPack(HostBlob(region.slab, region.offset, int(h.total_bytes)), job.nchunks, job.chunk_tokens)
+        return st
 
     def load_pack(self, pack: HostPack, chunk_begin: int, nchunks: int, dst: native.KVLayout, dst_tok0: int,
                   layers_per_range) -> DecodeJob:

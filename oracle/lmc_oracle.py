@@ -326,7 +326,7 @@ def bits_to_torch(a: np.ndarray, code: int):
 
 def pack_from_blobs(blobs, chunk_tokens: int) -> bytes:
     """CPU restatement of the pack layout (include/lmc_format.h, "pack"): the blobs of one store call -- all of the same
-    geometry, every chunk but possibly the last of `chunk_tokens` tokens -- transposed layer-major.  Test infrastructure:
+    geometry, every chunk but possibly the last of `chunk_tokens` tokens -- transposed plane-major.  Test infrastructure:
     what lmc_store_pack must produce byte for byte."""
     import struct
     hs = [parse_header(b) for b in blobs]
@@ -348,9 +348,8 @@ def pack_from_blobs(blobs, chunk_tokens: int) -> bytes:
     off_static = r16(off_table + 8 * (N + 1))
     off_streams = off_static + n * static_stride
     segs, table, at = [], [], 0
-    for layer in range(L):
-        for kv in range(2):
-            p = kv * L + layer
+    for p in range(P):  # pack v3: plane order -- K planes of every layer, then V planes (p = kv * L + layer)
+        if True:
             for c, (b, h) in enumerate(zip(blobs, hs)):
                 gdir = np.frombuffer(b, dtype=np.uint32, count=2 * P * G, offset=h["off_gdir"])
                 s0 = int(gdir[2 * p * G])  # beg of stream (p, 0) ... of stream (p + 1, 0), or the end of the section
@@ -360,7 +359,7 @@ def pack_from_blobs(blobs, chunk_tokens: int) -> bytes:
                 at += s1 - s0
     table.append(at)
     ntok = sum(h["ntokens"] for h in hs)
-    head = struct.pack("<12I4Q", 0x4b504d4c, 2, 256, n, L, H, D, chunk_tokens, G, static_stride, ntok, 0,
+    head = struct.pack("<12I4Q", 0x4b504d4c, 3, 256, n, L, H, D, chunk_tokens, G, static_stride, ntok, 0,
                        off_table, off_static, off_streams, off_streams + at)
     out = bytearray(off_streams + at)
     out[:len(head)] = head

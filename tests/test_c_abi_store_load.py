@@ -198,3 +198,83 @@ def test_pack_store_extract_load_through_the_c_abi_only(nat, oracle, shape):
         nat.pack_info(region.ptr, cap)
     region.free()
     meta.free()
+
+
+@pytest.mark.parametrize("shape", [(4, 2048, 8, 128, 256, 4, True), (3, 1024, 4, 128, 128, 3, True), (4, 2048, 8, 128, 256, 16, True),
+                                   (4, 2148, 8, 128, 256, 4, True), (2, 512, 8, 128, 256, 4, False)],
+                         ids=["8planes_4parts", "6planes_3parts_chunks_of_128", "more_parts_than_items", "ragged_tail_is_one_part",
+                              "small_job_two_kernels_is_one_part"])
+def test_pack_stored_in_parts_is_the_same_pack(nat, oracle, shape):
+    """lmc_store_pack_parts (round 6): the encode launched in plane ranges, each range packed into a DEVICE region as soon
+    as it is coded.  After part r its bytes lie at their final place (part_info: offset, bytes) and its event has been
+    recorded; [0, off_streams) is final after the last part.  Assembled from exactly those pieces, the pack is the
+    oracle's restatement of the layout byte for byte -- the same bytes lmc_store_pack writes in one piece."""
+    L, T, H, D, cs, nparts, fused = shape
+    n = (T + cs - 1) // cs
+    g = torch.Generator().manual_seed(T + L)
+    kv = torch.randn(L, 2, T, H, D, generator=g).to(torch.bfloat16)
+    kv_d = kv.to(DEV)
+    bins = [32 if l < max(1, L // 3) else 16 for l in range(L)] + [32 if l < 1 else 16 for l in range(L)]
+    ctx = nat.get_context(0)
+    cap = nat.pack_bound(n, L, cs, H, D)
+    dev = torch.zeros(cap, dtype=torch.uint8, device=DEV)
+    host = nat.PinnedBuffer(cap)
+    n4 = (4 * n + 7) & ~7  # (the part words are uint64)
+    meta = nat.PinnedBuffer(n4 + 64 + 16 * 16)
+    sizes = meta.tensor[:4 * n].view(torch.int32)
+    status = meta.tensor[n4:n4 + 4].view(torch.int32)
+    info = meta.tensor[n4 + 64:n4 + 64 + 16 * nparts].view(torch.int64)
+    status[0] = 0
+    st = torch.cuda.Stream(device=DEV)
+    cp = torch.cuda.Stream(device=DEV)
+    lay = nat.KVLayout.from_chunk(kv_d, "vllm")
+    events = [nat.NativeEvent() for _ in range(nparts)]
+    ctx.set_encode_path("fused" if fused else "auto")
+    try:
+        ctx.store_pack_parts(lay, 0, T, cs, bins, dev.data_ptr(), cap, meta.ptr, nparts, meta.ptr + n4 + 64, events,
+                             stream=st.cuda_stream, status_ptr=meta.ptr + n4)
+    finally:
+        ctx.set_encode_path("auto")
+    off_streams = nat.pack_off_streams(n, L, cs, H, D)
+    moved, nonempty = 0, 0
+    for r, ev in enumerate(events):  # what CacheGenDeviceCodec.finish_pack does: one DMA per part as its event fires
+        ev.synchronize()
+        off, nb = int(info[2 * r]), int(info[2 * r + 1])
+        assert nb == 0 or off == moved, "the parts are consecutive pieces of the streams region"
+        if nb:
+            nat.memcpy_async(host.ptr + off_streams + off, dev.data_ptr() + off_streams + off, nb, "d2h", cp.cuda_stream)
+            nonempty += 1
+        moved += nb
+    assert int(status[0]) == 0
+    nat.memcpy_async(host.ptr, dev.data_ptr(), off_streams, "d2h", cp.cuda_stream)
+    cp.synchronize()
+    st.synchronize()
+    split = fused and T % cs == 0
+    # (a part packs the planes coded so far but the newest one, whose end its successor writes: a first range of a single
+    # plane ships nothing, and ranges there are no items for stay empty)
+    assert (min(nparts, 2 * L) - 1 <= nonempty <= min(nparts, 2 * L)) if split else nonempty == 1
+    h = nat.pack_info(host.ptr, cap)
+    assert h.total_bytes == off_streams + moved
+    blobs = []
+    for i in range(n):
+        t0, t1 = i * cs, min(T, (i + 1) * cs)
+        b, code = oracle.torch_to_bits(kv[:, :, t0:t1].reshape(L, 2, t1 - t0, H * D))
+        blobs.append(oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)))
+        assert nat.pack_extract(host.ptr, h.total_bytes, i) == blobs[i], f"chunk {i}"
+        assert int(sizes[i]) == len(blobs[i])
+    assert ctypes.string_at(host.ptr, h.total_bytes) == oracle.pack_from_blobs(blobs, cs)
+    # a region that is too small: flagged, every part reads "no bytes" from the failing one on, and there is no pack header
+    status[0] = 0
+    ctx.set_encode_path("fused" if fused else "auto")
+    try:
+        ctx.store_pack_parts(lay, 0, T, cs, bins, dev.data_ptr(), int(h.total_bytes) - 16, meta.ptr, nparts,
+                             meta.ptr + n4 + 64, events, stream=st.cuda_stream, status_ptr=meta.ptr + n4)
+    finally:
+        ctx.set_encode_path("auto")
+    st.synchronize()
+    assert int(status[0]) & 32
+    assert int(info[2 * (len(events) - 1) + 1]) == 0 or not split
+    hdr = dev[:256].cpu().numpy().view(np.uint32)
+    assert hdr[0] == 0, "a failed pack must not look like one"
+    host.free()
+    meta.free()
