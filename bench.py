@@ -1085,9 +1085,10 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
                                "load_ms_per_context": round(loads[0], 3), "load_ms_per_context_8_layer_ranges": round(loads[8], 3),
                                "pcie_GBps_load": round(ph.total_bytes / loads[0] / 1e6, 1), "status": int(hstatus[0]),
                                "note": "lmc_store_pack: whole encode, then one device-side copy kernel writes the blobs "
-                                       "transposed (static sections, then streams ordered layer / K,V / chunk) into the "
-                                       "mapped pinned region; lmc_load_pack: table + static sections, then ONE "
-                                       "hipMemcpyAsync and one decode launch per range of layers"}
+                                       "transposed (static sections, then streams ordered plane / chunk: pack v3) into the "
+                                       "mapped pinned region -- the idle-GPU form; the engine's store (store_hidden) ships the "
+                                       "pack in parts by DMA; lmc_load_pack: table + static sections, then two "
+                                       "hipMemcpyAsync (K run, V run) and one decode launch per range of layers"}
         del out_p
         harena.free()
         hmeta.free()
