@@ -305,7 +305,7 @@ int lmc_load_chunks(lmc_ctx* ctx, const void* const* host_blob_ptrs_h, const uin
                     lmc_event_t* range_events, uint32_t* job_status, lmc_stream_t stream);
 
 /*
- * Packs: the layer-major form of the pinned host tier (lmc_format.h, "pack").  lmc_store_pack is lmc_store_chunks with
+ * Packs: the plane-major form of the pinned host tier (lmc_format.h, "pack").  lmc_store_pack is lmc_store_chunks with
  * the job's blobs written TRANSPOSED into one pinned region -- static sections of every chunk, then the streams ordered
  * (plane, chunk): K planes of every layer, then V planes -- so that lmc_load_pack moves the streams of a range of layers
  * as TWO hipMemcpyAsync (their K planes, their V planes) and the

@@ -636,7 +636,7 @@ class Context:
 
     def store_pack(self, src: KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int, bins, pack_ptr: int, pack_cap: int,
                    sizes_ptr: int, stream: Optional[int] = None, status_ptr: Optional[int] = None) -> int:
-        """lmc_store_pack: encode + the job's blobs transposed layer-major into one pinned region, no host wait."""
+        """lmc_store_pack: encode + the job's blobs transposed plane-major into one region, no host wait."""
         b = self._bins(bins)
         st = current_stream_ptr(src.device) if stream is None else stream
         check(lib().lmc_store_pack(self.handle, ctypes.byref(src.struct), tok_begin, tok_end, chunk_tokens, b, pack_ptr, pack_cap,

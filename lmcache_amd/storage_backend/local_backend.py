@@ -69,7 +69,7 @@ class _HostChunk:
 
 @dataclass
 class _PackChunk:
-    """Chunk `index` of a pack: the blobs of one put_kv_range() call, stored layer-major in pinned host DRAM."""
+    """Chunk `index` of a pack: the blobs of one put_kv_range() call, stored plane-major (pack v3) in pinned host DRAM."""
     pack: HostPack
     index: int
     shape: Tuple[int, ...]
@@ -119,7 +119,7 @@ class LMCLocalBackend(LMCBackendInterface):
         self.dict: Dict[CacheEngineKey, Union[torch.Tensor, _HostChunk]] = {}
         self.update_lock = threading.Lock()
         self.host_arena = PinnedArena() if self.mode in ("raw", "cachegen") else None
-        # pinned CacheGen tier: a put_kv_range() of several chunks is stored as ONE layer-major pack (lmc_store_pack), so
+        # pinned CacheGen tier: a put_kv_range() of several chunks is stored as ONE plane-major pack (lmc_store_pack_parts), so
         # that a retrieve of the same prefix moves a range of layers as one transfer (LMCACHE_AMD_PINNED_PACKS=0: one
         # blob per chunk, as the reference stores them)
         self.pack_stores = self.mode == "cachegen" and os.environ.get("LMCACHE_AMD_PINNED_PACKS", "1") != "0"

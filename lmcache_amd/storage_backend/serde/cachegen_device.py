@@ -127,7 +127,7 @@ class EncodeJob:
 
 @dataclass
 class HostPack:
-    """The blobs of one store call in pinned host DRAM, laid out layer-major (include/lmc_format.h, "pack")."""
+    """The blobs of one store call in pinned host DRAM, laid out plane-major (include/lmc_format.h, "pack" v3)."""
     blob: HostBlob
     nchunks: int
     chunk_tokens: int
@@ -534,7 +534,7 @@ class CacheGenDeviceCodec:
             job._meta, job._meta_pool = meta, self._meta_pool  # the kernels read the arrays: back in the pool at finish
             return job
 
-    # ---- packs: the layer-major pinned tier ---------------------------------------------------------------
+    # ---- packs: the plane-major pinned tier ---------------------------------------------------------------
     def store_pack(self, src: native.KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int, bins: Sequence[int],
                    arena: PinnedArena, dma: bool = True) -> PackJob:
         """lmc_store_pack on the CURRENT stream: encode every chunk of [tok_begin, tok_end), then a copy kernel writes
