@@ -133,6 +133,83 @@ def step_v6(i, salu="full", emit=True, valu=True, lds=True, nop=True, flush=True
 
 TAIL = []  # out-of-line blocks of the body being generated (behind the loop)
 
+# ---- round 6: a wave's TWO streams interleaved in one loop ------------------------------------------
+# Stream B = the shipped step (lean2) on a second register set; the emit blocks (exec = emitting lanes) and the flush
+# tests stay whole, everything between them alternates A / B instruction by instruction, so that the dependent chains of
+# one stream (v_mul_hi -> shift -> mad -> add of the state; address -> load of the entry) issue in the other's shadow.
+# Both streams read the wave's table and stage into the wave's ring region (timing only: the data are synthetic).
+B_MAP = {"v1": "v7", "v2": "v8", "v3": "v9", "v4": "v10", "v5": "v11", "v6": "v12",
+         "v17": "v13", "v18": "v14", "v19": "v15", "v20": "v16", "v21": "v52", "v22": "v53", "v23": "v54", "v24": "v55",
+         "s34": "s54", "s7": "s57", "s22": "s56"}
+for _k in range(5):
+    B_MAP["v%d" % (32 + 2 * _k)] = "v%d" % (42 + 2 * _k)
+    B_MAP["v%d" % (33 + 2 * _k)] = "v%d" % (43 + 2 * _k)
+
+
+def to_b(line):
+    import re
+
+    def sub(m):
+        tok = m.group(0)
+        return B_MAP.get(tok, tok)
+    line = re.sub(r"\bv\[(\d+):(\d+)\]", lambda m: "v[%s:%s]" % (B_MAP["v" + m.group(1)][1:], B_MAP["v" + m.group(2)][1:])
+                  if "v" + m.group(1) in B_MAP else m.group(0), line)
+    return re.sub(r"\b[vs]\d+\b", sub, line)
+
+
+def step_sections(i, tag):
+    """the shipped step (lean2, no s_nop) of token i as sections: pre | emit (atomic) | addr + loads | flush (atomic) | put"""
+    e0, e2, e4 = E[i % 5], E[(i + 2) % 5], E[(i + 4) % 5]
+    r0, r2 = R[i % 5], R[(i + 2) % 5]
+    pre = ["v_lshrrev_b32_e32 v22, 20, %s" % e2]
+    emit = ["v_cmpx_ge_u32_sdwa vcc, v1, %s src0_sel:WORD_1 src1_sel:WORD_1" % e0,
+            "s_bcnt1_i32_b64 s7, vcc",
+            "v_mbcnt_lo_u32_b32 v21, vcc_lo, 0", "v_mbcnt_hi_u32_b32 v21, vcc_hi, v21",
+            "v_lshl_add_u32 v21, v21, 1, s34",
+            "ds_write_b16 v21, v1",
+            "v_lshrrev_b32_e32 v1, 16, v1",
+            "s_mov_b64 exec, s[30:31]"]
+    loads = sym_addr(i) + ["ds_read_b64 v[%s:%s], v22 offset:%d" % (r2[0][1:], r2[1][1:], RTAB_OFF),
+                           "ds_read_b32 %s, v23" % e4]
+    flush = ["s_lshl1_add_u32 s34, s7, s34"]
+    if i % 2 == 1:
+        fl, back = "F%s%d_%%=" % (tag, i), "B%s%d_%%=" % (tag, i)
+        blk = ["%s:" % fl, "v_add_u32_e32 v27, s20, v26", "ds_read_b32 v29, v27", "ds_read_b32 v28, v27 offset:256",
+               "s_sub_u32 s6, s34, s35", "v_cmp_gt_u32_e32 vcc, s6, v26", "s_waitcnt lgkmcnt(0)",
+               "global_store_dword v26, v29, s[12:13]", "s_and_saveexec_b64 s[6:7], vcc", "ds_write_b32 v27, v28",
+               "s_or_b64 exec, exec, s[6:7]", "s_addk_i32 s34, 0xff00", "s_addk_i32 s22, 0x80", "s_branch %s" % back]
+        TAIL.extend(blk if tag == "A" else [to_b(x) if not x.endswith(":") and not x.startswith("s_branch") else x for x in blk])
+        flush += ["s_cmp_lt_u32 s34, s35", "s_cbranch_scc0 %s" % fl, "%s:" % back]
+    put = ["v_mul_hi_u32 v24, v1, %s" % r0[0],
+           "v_lshrrev_b32_sdwa v24, %s, v24 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" % r0[1],
+           "v_mad_u32_u24 v1, v24, %s, v1" % r0[1],
+           "v_add_u32_sdwa v1, v1, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" % e0]
+    secs = [pre, emit, loads, flush, put]
+    if tag == "B":
+        secs = [[(x if (x.endswith(":") or x.startswith("s_cbranch")) else to_b(x)) for x in sec] for sec in secs]
+        # (the flush test's compare reads B's cursor; its label lines and branch targets stay)
+        secs[3] = [to_b(x) if x.startswith("s_cmp") or x.startswith("s_lshl1") else x for x in secs[3]]
+    return secs
+
+
+def zipped(a, b):
+    out = []
+    for k in range(max(len(a), len(b))):
+        if k < len(a):
+            out.append(a[k])
+        if k < len(b):
+            out.append(b[k])
+    return out
+
+
+def step_two_streams(i, interleave=True):
+    A, Bs = step_sections(i, "A"), step_sections(i, "B")
+    if not interleave:  # the two streams one after the other inside the step (the control: same work, no interleaving)
+        return sum(A, []) + ["s_waitcnt lgkmcnt(2)"] + sum(Bs, []) + ["s_waitcnt lgkmcnt(2)"]
+    o = zipped(A[0], Bs[0]) + A[1] + Bs[1] + zipped(A[2], Bs[2]) + A[3] + Bs[3] + zipped(A[4], Bs[4])
+    o.append("s_waitcnt lgkmcnt(4)")
+    return o
+
 
 def lean2_check(i):
     """round-5 shipped form: linear 256-word buffer, the test every SECOND token, the flush out of line (the common
@@ -256,6 +333,10 @@ def body_steps(kind):
             o += step_v6(i, salu="none", lds=False)
         elif kind == "v6_salu_only":
             o += step_v6(i, valu=False, lds=False, flush=False)
+        elif kind == "two_streams":
+            o += step_two_streams(i)
+        elif kind == "two_streams_serial":
+            o += step_two_streams(i, interleave=False)
         else:
             raise ValueError(kind)
     return o
@@ -296,6 +377,8 @@ STEPS = [
     ("step v6, no emit block", "v6_noemit", 1),
     ("step v6, VALU only", "v6_valu_only", 1),
     ("step v6, SALU only", "v6_salu_only", 1),
+    ("TWO streams per wave, interleaved (per token step)", "two_streams", 2),
+    ("TWO streams per wave, one after the other (control)", "two_streams_serial", 2),
     ("pair v7 (per token)", "pair", 1),
     ("pair v7, lean scalar (per token)", "pair_lean", 1),
 ]
@@ -347,6 +430,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       "v_lshrrev_b32 v22, %%7, v2\n"
       "ds_read_b64 v[32:33], v22 offset:%(rtab)d\n ds_read_b64 v[34:35], v22 offset:%(rtab)d\n ds_read_b64 v[36:37], v22 offset:%(rtab)d\n"
       "ds_read_b64 v[38:39], v22 offset:%(rtab)d\n ds_read_b64 v[40:41], v22 offset:%(rtab)d\n"
+      // stream B (two-stream variants): its own state, entry and reciprocal pipelines, symbols, ring cursor
+      "v_mov_b32 v7, %%3\n v_mov_b32 v8, v2\n v_mov_b32 v9, v2\n v_mov_b32 v10, v2\n v_mov_b32 v11, v2\n v_mov_b32 v12, v2\n"
+      "v_mov_b32 v42, v32\n v_mov_b32 v43, v33\n v_mov_b32 v44, v32\n v_mov_b32 v45, v33\n v_mov_b32 v46, v32\n v_mov_b32 v47, v33\n"
+      "v_mov_b32 v48, v32\n v_mov_b32 v49, v33\n v_mov_b32 v50, v32\n v_mov_b32 v51, v33\n"
+      "v_mul_lo_u32 v13, v20, s51\n v_mul_lo_u32 v14, v13, s52\n v_mul_lo_u32 v15, v14, s53\n v_mul_lo_u32 v16, v15, s50\n"
+      "s_mov_b32 s54, s20\n s_mov_b32 s56, 0\n s_mov_b32 s57, 0\n"
       "s_waitcnt lgkmcnt(0)\n"
       "s_memtime s[24:25]\n"
       "s_movk_i32 s23, %(iters)d\n"
@@ -370,9 +459,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       : "=v"(ticks), "=v"(xout)
       : "v"(col), "v"(x0), "v"(h), "s"(ring), "s"(glo), "s"(shr), "s"(ghi)
       : "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20",
-        "v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v48","v49","v50","v51","v52","v53","v54","v55",
+        "v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55",
         "s6","s7","s12","s13","s20","s21","s22","s23","s24","s25","s26","s27","s30","s31","s33","s34","s35","s36","s37",
-        "s40","s41","s42","s43","s44","s45","s46","s47","s50","s51","s52","s53","vcc","scc","memory");
+        "s40","s41","s42","s43","s44","s45","s46","s47","s50","s51","s52","s53","s54","s55","s56","s57","vcc","scc","memory");
   if (lane == 0) gout[(gridDim.x * 8 + blockIdx.x * 8 + wave) * 64] = ticks;
   if (xout == 0x12345) sink[0] = xout;
 }
@@ -398,12 +487,12 @@ def main():
         n = "pure_" + ident(name)
         src.append(KERNEL % {"name": n, "iters": iters, "body": asm_lines(lines), "tail": '""', "rtab": RTAB_OFF})
         ents.append((name, n, 32, 0))
-    for name, kind, _ in STEPS:
+    for name, kind, _ in STEPS:  # _ = streams per wave (token steps per unrolled position)
         n = "step_" + ident(kind)
         del TAIL[:]
         body = asm_lines(body_steps(kind))
         src.append(KERNEL % {"name": n, "iters": iters, "body": body, "tail": asm_lines(TAIL) if TAIL else '""', "rtab": RTAB_OFF})
-        ents.append((name, n, UNROLL, 1 if kind.startswith("pair") else 0))
+        ents.append((name, n, UNROLL * _, 1 if kind.startswith("pair") else 0))
     src.append("typedef void (*kfn)(unsigned*, unsigned*, int);\n")
     src.append("struct Ent { const char* n; kfn f; int per_trip; int v7; };\nstatic Ent ents[] = {\n")
     for name, n, per, v7 in ents:
@@ -416,11 +505,11 @@ int main() {
   (void)hipMalloc(&out, 4ull * maxblocks * 8 * 64 * 2); (void)hipMalloc(&sink, 64);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   printf("ns per unit per SIMD = kernel wall time x 1024 SIMDs / (waves x units per wave); unit = one instruction (pure streams) or one TOKEN STEP (steps)\n");
-  printf("%-36s %10s %10s %10s | %12s\n", "stream", "ns@2w/SIMD", "ns@4w", "ns@8w", "cycles@8w(2.4GHz)");
+  printf("%-52s %10s %10s %10s %10s | %12s\n", "stream", "ns@2w/SIMD", "ns@4w", "ns@6w", "ns@8w", "cycles@8w(2.4GHz)");
   for (auto& e : ents) {
-    double r[3];
-    int ws[3] = {1, 2, 4};  // workgroups of 8 waves per CU -> 2, 4, 8 waves per SIMD
-    for (int k = 0; k < 3; k++) {
+    double r[4];
+    int ws[4] = {1, 2, 3, 4};  // workgroups of 8 waves per CU -> 2, 4, 6, 8 waves per SIMD
+    for (int k = 0; k < 4; k++) {
       int blocks = 256 * ws[k];
       float ms = 0, best = 1e9f;
       for (int rep = 0; rep < 3; rep++) {
@@ -433,7 +522,7 @@ int main() {
       }
       r[k] = (double)best * 1e6 * 1024.0 / ((double)blocks * 8.0 * @ITERS@.0 * e.per_trip);
     }
-    printf("%-36s %10.2f %10.2f %10.2f | %12.1f\n", e.n, r[0], r[1], r[2], r[2] * 2.4);
+    printf("%-52s %10.2f %10.2f %10.2f %10.2f | %12.1f\n", e.n, r[0], r[1], r[2], r[3], r[3] * 2.4);
   }
   hipError_t err = hipDeviceSynchronize();
   printf("status %d\n", (int)err);
