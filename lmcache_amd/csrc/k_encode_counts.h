@@ -257,7 +257,7 @@ __device__ __forceinline__ void counts_table_byte_pk(const u32 (&mp)[8], u16* ta
 template <bool ALIGNED = false, bool PLANE = false>
 __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const CountsStream& s, u32* tabmem,
                                                   const u32* bits,
-                                                  int lane, CountsState& cs) {
+                                                  int lane, CountsState& cs, u32 vq_base = 0) {
   typedef __attribute__((address_space(3))) u32* lds_u32w;
   typedef const __attribute__((address_space(3))) u16* lds_u16p;
   typedef const __attribute__((address_space(3))) u8* lds_u8p;
@@ -305,7 +305,10 @@ __device__ __forceinline__ u32 counts_hist_stream(const EncodeArgs& a, const Cou
   };
   // PLANE: the channel of this lane, c = 64 g + lane, was quantised by lane qx = (c % 512) / 8 as element e = c % 8 of
   // its channel run it = c / 512
-  const u32 qx = (((u32)s.g & 7u) << 3) + ((u32)lane >> 3), qe = (u32)lane & 7u, qit = (u32)s.g >> 3;
+  // (k_hist.h: virtual quantising lane vq = vq_base + c / 8 with c = 64 g + lane the channel within its plane; vq_base = 0
+  // for a plane of up to 1024 channels, pj * GL for plane pj of an item of narrow planes)
+  const u32 vq = vq_base + (((u32)s.g) << 3) + ((u32)lane >> 3);
+  const u32 qx = vq & 63u, qe = (u32)lane & 7u, qit = vq >> 6;
   u32 ph = 0;  // LDS byte address of this lane's counter of symbol 0 (rows of 256 B)
   if constexpr (PLANE) {
     if (s.nib) {

@@ -258,30 +258,9 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
 #ifndef LMC_FUSED_HIST_A_BYTE
 #define LMC_FUSED_HIST_A_BYTE 1  // ... for the planes with more than 16 symbols as well
 #endif
-#define PLANE_HIST_DWORDS 8192
-
-// one histogram add of the plane: counter row `sym` of the lane's column, `field` = the symbol moved to bits 8 .. 12
-template <int OFF>
-__device__ __forceinline__ void plane_hist_add(u32 ad, u32 val) {
-  typedef __attribute__((address_space(3))) u32* lds_u32w;
-  __hip_atomic_fetch_add((lds_u32w)(size_t)(ad + (u32)OFF), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// LDS byte address of a symbol's counter row in the lane's column: `ad` holds 4 * lane in byte 0 (the histogram starts
-// at LDS address 0 -- checked -- and rows are 256 B), and ONE SDWA instruction writes the symbol into byte 1 and keeps
-// the rest (dst_unused:UNUSED_PRESERVE): the low nibble of byte K of w (v_and 15), its high nibble (v_lshrrev 4), or
-// the whole byte (a byte plane's symbol is < 32).  (Shift + v_and_or_b32 takes two.)
-#define LMC_HIST_ROW_OP(NAME, OPSTR)                                                                                     \
-  template <int K>                                                                                                      \
-  __device__ __forceinline__ void NAME(u32& ad, u32 w) {                                                                \
-    if constexpr (K == 0) asm(OPSTR " dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0" : "+v"(ad) : "v"(w)); \
-    else if constexpr (K == 1) asm(OPSTR " dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_1" : "+v"(ad) : "v"(w)); \
-    else if constexpr (K == 2) asm(OPSTR " dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2" : "+v"(ad) : "v"(w)); \
-    else asm(OPSTR " dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3" : "+v"(ad) : "v"(w)); \
-  }
-LMC_HIST_ROW_OP(hist_row_lo, "v_and_b32_sdwa %0, 15, %1")      // byte 1 = byte K of w & 15
-LMC_HIST_ROW_OP(hist_row_hi, "v_lshrrev_b32_sdwa %0, 4, %1")   // byte 1 = byte K of w >> 4
-LMC_HIST_ROW_OP(hist_row_byte, "v_or_b32_sdwa %0, 0, %1")      // byte 1 = byte K of w
-
+#ifndef LMC_FUSED_HIST_A_NARROW
+#define LMC_FUSED_HIST_A_NARROW 1  // ... and for items of several narrow planes (C <= 256)
+#endif
 // quantize_oct_fused with the histogram: one row oct by one wave, symbols to the workspace AND into the plane's counters.
 // skip0: the oct holds token 0 of the chunk (byte planes leave it out of the counters).
 template <int NITER, int DT, bool NIB, bool FULL, bool ALLROWS>
@@ -304,30 +283,8 @@ __device__ __forceinline__ void quantize_oct_hist(const KvAddr& src, const u16* 
   u32 ad[2] = {lane4, lane4};  // two address registers in turn: a symbol's SDWA write does not wait for the previous ds_add's read
   auto hist_dword = [&](auto it_tag, auto e_tag, auto hq_tag, u32 od) {
     constexpr int it = decltype(it_tag)::value, e = decltype(e_tag)::value, hq = decltype(hq_tag)::value;
-    if constexpr (NIB) {
-      constexpr int OFF = (it * 4 + e / 2) * 4096;
-      const u32 val = (e & 1) ? 0x10000u : 1u;
-      static_for<8>([&](auto ktag) {
-        constexpr int row = decltype(ktag)::value;             // token of the oct: byte row & 3, high nibble from row 4 on
-        if (ALLROWS || t_first + row < Tc) {                   // (wave-uniform test)
-          if constexpr (row < 4) hist_row_lo<row & 3>(ad[row & 1], od);
-          else hist_row_hi<row & 3>(ad[row & 1], od);
-          plane_hist_add<OFF>(ad[row & 1], val);
-        }
-      });
-    } else {
-      constexpr int OFF = (it * 2 + e / 4) * 8192;
-      const u32 val = 1u << (8 * (e & 3));
-      static_for<4>([&](auto ktag) {
-        constexpr int k = decltype(ktag)::value;
-        constexpr int row = 4 * hq + k;
-        const bool count = (ALLROWS || t_first + row < Tc) && !(row == 0 && skip0);  // wave-uniform
-        if (count) {
-          hist_row_byte<k>(ad[k & 1], od);
-          plane_hist_add<OFF>(ad[k & 1], val);
-        }
-      });
-    }
+    // (wave-uniform tests: the rows of a partial last oct, token 0 of a byte plane)
+    plane_hist_dword<NIB, it, e, hq>(od, ad, [&](int row) { return (ALLROWS || t_first + row < Tc) && (NIB || !(row == 0 && skip0)); });
   };
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -455,6 +412,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // (GL == 64: the eight slices together are the plane's histogram during phase A and pass 1 -- PLANE_HIST_DWORDS, at LDS
   // address 0: plane_hist_row)
   constexpr bool HISTA = LMC_FUSED_HIST_A && GL == 64 && NW * CNT_TAB_DWORDS == PLANE_HIST_DWORDS;
+  // ... and narrow planes (GL < 64: several planes per item): the same 32 KiB hold the counters of ALL the item's planes,
+  // plane pj's lane group on the virtual quantising lanes pj * GL .. (k_hist.h) -- when the item's planes fit 128 of them
+  // GL == 32 only (planes of 129 .. 256 channels): a wave pass quantises 64 / GL row octs of one plane, whose lane groups add
+  // into the SAME columns -- the same LDS bank.  Two groups (GL = 32) cost a 2-way conflict and the histogram still wins
+  // 5 % (0.251 - 0.256 vs 0.262 - 0.270 ms, 32 layers x 2 heads x 128, 16 k tokens, five alternations); four groups
+  // (GL = 16) make every ds_add a 4-way conflict: level at C = 128, + 18 % at C = 64 (profiles/r06_experiments.md).
+  constexpr bool HISTN = LMC_FUSED_HIST_A && LMC_FUSED_HIST_A_NARROW && GL == 32 && NW * CNT_TAB_DWORDS == PLANE_HIST_DWORDS;
   __shared__ __attribute__((aligned(HISTA ? 32768 : 4096))) u32 lds_all[NW * (CNT_TAB_DWORDS + CNT_RING_DWORDS)];  // the tables, then the staging buffers
   __shared__ __attribute__((aligned(16))) u32 rtab_lds[RTAB_LDS_DWORDS];  // reciprocals of the counts model's frequencies, bound table
   __shared__ u32 st_alloc[FUSED_MAX_NS];  // allocation of the item's group streams
@@ -476,6 +440,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   rtab_to_lds(rtab_lds);  // visible to the coder waves behind the barrier that ends phase A
   // the item's plane takes its histogram while it is quantised (wave-uniform per item: GL == 64 items are one plane)
   bool hist_a = false;
+  if constexpr (HISTN) {
+    typedef __attribute__((address_space(3))) u32* lds_u32w;
+    if ((u32)(size_t)(lds_u32w)lds_all != 0u) __builtin_trap();
+    hist_a = np * GL <= 128;  // (wave-uniform; false only with an LMC_FUSED_PL override that packs more planes into an item)
+    if (hist_a) {
+      uint4* z = reinterpret_cast<uint4*>(lds_all);
+#pragma unroll
+      for (int i = 0; i < PLANE_HIST_DWORDS / 4 / (64 * NW); i++) z[i * 64 * NW + threadIdx.x] = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+    }
+  }
   if constexpr (HISTA) {
     typedef __attribute__((address_space(3))) u32* lds_u32w;
     if ((u32)(size_t)(lds_u32w)lds_all != 0u) __builtin_trap();  // (static layout: plane_hist_row builds addresses from 0)
@@ -519,7 +494,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         u32* const sym_out = const_cast<u32*>(a.sym4) + ((long long)chunk * a.P + p) * a.sym_stride + (long long)oct * (nib ? 1 : 2) * a.C;
         u16* const scale_out = reinterpret_cast<u16*>(scl0) + (long long)p * Tc + oct * 8;
         const bool q1valid = 2 * oct + 1 < a.TQ;
-        if (nib) quantize_task<GL, 1, DT, true, true, 4, 2>(fa.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out, nullptr, scale_out, sl);
+        if (HISTN && hist_a) {
+          const u32 vq = (u32)((task / OG) * GL + sl);  // the lane's virtual quantising lane within the item (k_hist.h)
+          const u32 hl4 = 4u * (vq & 63u);
+          const int hit = __builtin_amdgcn_readfirstlane((int)(((u32)(task / OG) * GL) >> 6));  // (GL lanes never straddle 64)
+          if (nib) quantize_task<GL, 1, DT, true, true, 4, 2, 1, true>(fa.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out, nullptr, scale_out, sl, 0, nullptr, hl4, hit);
+          else quantize_task<GL, 1, DT, true, false, 4, 2, 1, true>(fa.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out, nullptr, scale_out, sl, 0, nullptr, hl4, hit);
+        } else if (nib) quantize_task<GL, 1, DT, true, true, 4, 2>(fa.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out, nullptr, scale_out, sl);
         else quantize_task<GL, 1, DT, true, false, 4, 2>(fa.src, p, tok0, Tc, oct * 8, ovalid, q1valid, a.C, maxf, sym_out, nullptr, scale_out, sl);
       }
     } else {
@@ -588,7 +569,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if (j < NS) {  // wave-uniform
       const CountsStream s = stream_of(j);
       u32 alloc;
-      if (HISTA && (LMC_FUSED_HIST_A_BYTE || hist_a)) alloc = counts_hist_stream<true, true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);  // the counters are there
+      // (the counters are there; vq_base = the plane's first virtual quantising lane within the item)
+      if (HISTA && (LMC_FUSED_HIST_A_BYTE || hist_a)) alloc = counts_hist_stream<true, true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
+      else if (HISTN && hist_a) alloc = counts_hist_stream<true, true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs, (u32)(s.p - p0) * GL);
       else alloc = counts_hist_stream<true>(a, s, hist, rtab_lds + RTAB_DWORDS, lane, cs);
       if (lane == 0) st_alloc[j] = alloc;
     }

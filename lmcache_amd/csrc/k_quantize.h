@@ -21,6 +21,7 @@
 // Output, QUAD=false (lmc_quantize parity entry): int8 [P][T][C].
 #pragma once
 #include "lmc_device.h"
+#include "k_hist.h"
 
 struct QuantArgs {
   KvAddr src;
@@ -76,10 +77,15 @@ __device__ __forceinline__ u32 quant_special(float x, float factor, float maxf) 
 // `slice` takes channels [slice, slice + 1) * NITER * 512, and the row maxima meet in `xmax` (LDS, [8][SPLIT]) behind
 // ONE workgroup barrier per task -- a wave then holds 8 rows x 1024 channels (98 VGPRs, 4 waves per SIMD) where a
 // whole 4096-channel row per wave costs 241 VGPRs and 2 waves per SIMD (C = 4096: 3.5 -> 4.3 TB/s).
-template <int G, int NITER, int DT, bool QUAD, bool NIB, int ROWS = 4, int NQ = NIB ? 2 : 1, int SPLIT = 1>
+// HIST (the fused encode's narrow planes, round 6): the task's symbols also go into the work item's histogram (k_hist.h)
+// -- hist_lane4 = 4 * the task's virtual quantising lane, hist_it its virtual channel run (wave-uniform: a wave pass
+// quantises row octs of ONE plane).
+template <int G, int NITER, int DT, bool QUAD, bool NIB, int ROWS = 4, int NQ = NIB ? 2 : 1, int SPLIT = 1, bool HIST = false>
 __device__ __forceinline__ void quantize_task(const KvAddr& src, int p, int tok0, int Tc, int t_first, bool qvalid,
                                               bool q1valid, int C, float maxf, u32* sym_out, int8_t* sym8_plane,
-                                              u16* scale_out, int sl, int slice = 0, u32* xmax = nullptr) {
+                                              u16* scale_out, int sl, int slice = 0, u32* xmax = nullptr,
+                                              u32 hist_lane4 = 0, int hist_it = 0) {
+  static_assert(!HIST || (QUAD && NITER == 1 && NQ == 2 && SPLIT == 1), "the histogram rides on the fused kernel's narrow tasks");
   static_assert(SPLIT == 1 || (QUAD && ROWS == 4 * NQ), "a split task exchanges all its rows' maxima at once");
   static_assert(ROWS == 2 || ROWS == 4 || (ROWS == 8 && NQ == 2), "rows in flight: a power of two within the task");
   static_assert(QUAD || (!NIB && NQ == 1), "nibble packing and two-quad tasks are workspace formats");
@@ -234,6 +240,10 @@ __device__ __forceinline__ void quantize_task(const KvAddr& src, int p, int tok0
         for (int e = 0; e < 8; e++) w[e] = o[0][it][e] | (o[NQ - 1][it][e] << 4);
         *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
         *reinterpret_cast<uint4*>(dst + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+        if constexpr (HIST) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) o[0][it][e] = w[e];  // the histogram below counts the merged dwords
+        }
       } else {
 #pragma unroll
         for (int hq = 0; hq < NQ; hq++) {  // byte format: the task's row quads are adjacent [quad][channel] rows
@@ -244,6 +254,36 @@ __device__ __forceinline__ void quantize_task(const KvAddr& src, int p, int tok0
         }
       }
     }
+  }
+  if constexpr (HIST) {
+    // rows of the oct that are tokens of the chunk (per lane group: the groups of a wave pass hold different octs); a byte
+    // plane leaves token 0 out (its u8 counters must not reach 256: k_hist.h)
+    const int nrow = (qvalid && cval[0]) ? min(8, Tc - t_first) : 0;
+    const bool all8 = __ballot(nrow != 8) == 0;           // wave-uniform: every group holds a full oct (the usual case)
+    const bool tok0_here = !NIB && __ballot(nrow > 0 && t_first == 0) != 0;  // wave-uniform: some group holds token 0
+    u32 ad[2] = {hist_lane4, hist_lane4};
+    auto add_all = [&](auto it_tag) {
+      constexpr int IT = decltype(it_tag)::value;
+      static_for<8>([&](auto e_tag) {
+        constexpr int E = decltype(e_tag)::value;
+        if (all8 && !tok0_here) {
+          if constexpr (NIB) plane_hist_dword<true, IT, E, 0>(o[0][0][E], ad, [](int) { return true; });
+          else {
+            plane_hist_dword<false, IT, E, 0>(o[0][0][E], ad, [](int) { return true; });
+            plane_hist_dword<false, IT, E, 1>(o[1][0][E], ad, [](int) { return true; });
+          }
+        } else {  // a partial or absent oct in some group, or token 0 of a byte plane: per-lane tests (exec-masked adds)
+          auto counted = [&](int row) { return row < nrow && (NIB || t_first + row != 0); };
+          if constexpr (NIB) plane_hist_dword<true, IT, E, 0>(o[0][0][E], ad, counted);
+          else {
+            plane_hist_dword<false, IT, E, 0>(o[0][0][E], ad, counted);
+            plane_hist_dword<false, IT, E, 1>(o[1][0][E], ad, counted);
+          }
+        }
+      });
+    };
+    if (hist_it) add_all(IntTag<1>{});  // (wave-uniform)
+    else add_all(IntTag<0>{});
   }
 }
 
