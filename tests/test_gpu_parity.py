@@ -698,6 +698,11 @@ FUSED_SHAPES = [
     (1, 300, 300, 8, 128, torch.bfloat16, "randn"),   # T > 256 in one chunk (two-byte counts): CDF16, not a fused geometry
     (2, 9, 4, 3, 128, torch.bfloat16, "randn"),       # chunks shorter than a row oct (counts-only launch); the 1-token tail is CDF16
     (1, 67, 33, 1, 72, torch.bfloat16, "randn"),      # P G = 4: streams do not fill 8-wave workgroups -> general launch, counts model per stream
+    # round 6: the histogram taken in phase A -- items of TWO narrow planes (C = 256 / 192: GL = 32) with different counter
+    # formats side by side (default_bins: a 32-bin and a 16-bin plane per item), and a partial last oct
+    (3, 768, 256, 2, 128, torch.bfloat16, "rand"),
+    (2, 512, 256, 3, 64, torch.float16, "outlier"),
+    (2, 300, 100, 2, 128, torch.bfloat16, "randn"),
 ]
 
 
@@ -806,13 +811,14 @@ def test_fused_encode_special_rows_and_repeated_jobs(nat, ctx, oracle):
             assert blob == oracle.encode_blob(b, code, H, D, np.array(bins, np.int32)), f"job {rep}, chunk {i}"
 
 
+@pytest.mark.parametrize("H", [3, 2], ids=["C384", "C256_two_planes_per_item"])
 @pytest.mark.parametrize("path", ["fused", "two_kernels"])
-def test_counts_model_constant_and_sparse_channels(nat, ctx, oracle, path):
+def test_counts_model_constant_and_sparse_channels(nat, ctx, oracle, path, H):
     """LMC_MODEL_COUNTS (256-token chunks) on the channels that stress its table: channels whose 256 symbols are all
     equal (count 256 -> 255 + 1 on a neighbour, lmc_counts_model: symbol 0 and another one), channels with a symbol
     that occurs once (frequency 2, the smallest the reciprocal table serves), two-symbol channels; on 32-bin and
     16-bin planes, both launch paths; blob and decode bit-exact against the oracle."""
-    L, T, H, D = 2, 512, 3, 128
+    L, T, D = 2, 512, 128
     g = torch.Generator().manual_seed(5)
     x = torch.randn(L, 2, T, H, D, generator=g)
     big = x.abs().amax(dim=(-1, -2), keepdim=True)
@@ -821,7 +827,7 @@ def test_counts_model_constant_and_sparse_channels(nat, ctx, oracle, path):
     x[:, :, :, 0, 16:24] = -big[..., 0]                       # symbol 0, every token
     x[:, :, :, 1, 0:8] = 0.0
     x[:, :, 100, 1, 0:8] = big[:, :, 100, 0]                  # one outlier token in a constant channel
-    x[:, :, ::2, 2, 5] = 0.0                                  # two-symbol-ish channel
+    x[:, :, ::2, H - 1, 5] = 0.0                              # two-symbol-ish channel
     kv = x.to(torch.bfloat16)
     bins = [32, 16, 16, 32]
     lay = nat.KVLayout.from_chunk(kv.to(DEV), "vllm")
