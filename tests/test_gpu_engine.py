@@ -1041,3 +1041,43 @@ def test_disk_tier_stores_the_flat_blob_and_decodes_from_the_file(fmt, tmp_path,
         assert mask3.all()
     finally:
         engine.close()
+
+
+@pytest.mark.parametrize("tier", ["cachegen-hbm", "cachegen-host"])
+def test_kept_lookup_plans_follow_the_store(oracle, tier):
+    """Round 6 keeps, between calls, the key objects of the engine's last hash chains, the backend's entry list of the last
+    probed prefix and the codec's uploaded blob-address tables (the host time in front of a warm retrieve).  None of it may
+    outlive a change of the store: a prompt that was half cached is seen whole once the rest has been stored, a repeated
+    retrieve returns the same KV, and a second engine's store of other prompts in between changes nothing."""
+    fmt, cs, nl = "vllm", 128, 4
+    engine = LMCacheEngine(make_cfg(tier, cs), dumb_metadata(fmt, MODEL))
+    try:
+        toks = generate_tokens(512, "cuda")
+        kv = generate_kv_cache(512, fmt, "cuda", num_layers=nl)
+        half = tuple((k[:256], v[:256]) for k, v in kv)
+        engine.store(toks[:256], half)
+        r1 = engine.retrieve_layerwise(toks, layers_per_launch=2)  # the plan of `toks` is made with 2 of 4 chunks present
+        r1.finish()
+        assert int(r1.ret_mask.sum()) == 256
+        first = [(k.clone(), v.clone()) for k, v in r1.kv]
+        engine.store(toks, kv)                                     # ... and must not survive this
+        for _ in range(3):                                         # the third call runs entirely on kept plans
+            r2 = engine.retrieve_layerwise(toks, layers_per_launch=2)
+            r2.finish()
+            assert int(r2.ret_mask.sum()) == 512
+            for l in range(nl):
+                assert torch.equal(r2.kv[l][0][:256], first[l][0]) and torch.equal(r2.kv[l][1][:256], first[l][1])
+        want, m = engine.retrieve(toks)
+        assert int(m.sum()) == 512
+        for l in range(nl):
+            assert torch.equal(r2.kv[l][0], want[l][0]) and torch.equal(r2.kv[l][1], want[l][1])
+        other = generate_tokens(300, "cuda")
+        engine.store(other, generate_kv_cache(300, fmt, "cuda", num_layers=nl))  # publishes: the kept entry list is stale now
+        r3 = engine.retrieve_layerwise(toks, layers_per_launch=4)
+        r3.finish()
+        assert int(r3.ret_mask.sum()) == 512
+        for l in range(nl):
+            assert torch.equal(r3.kv[l][0], want[l][0])
+        assert int(engine.retrieve(other)[1].sum()) == 300          # (the short last chunk is a chunk too: cache_engine.py:77-81)
+    finally:
+        engine.close()
