@@ -334,6 +334,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   }
   const int tdst0 = a.dst_tok0 + chunk * a.chunk_tokens;
 
+  // the ring bookkeeping is wave-uniform (SGPRs: its tests are scalar branches); runs when e <= trig
+  auto ring_event = [&]() {
+    if (pending == 0u) {
+      pend = block_load(top_blk - 2);
+      pending = 1u;
+      trig = 128 * top_blk;
+    } else {
+      wave_lds_fence();  // every lane's reads of the upper block are done
+      block_commit(top_blk - 2, pend);
+      top_blk = __builtin_amdgcn_readfirstlane(top_blk - 1);
+      pending = 0u;
+      trig = 128 * top_blk + 64;
+      wave_lds_fence();
+    }
+  };
   // The word pop of one token (after the state update): renormalising lanes take this step's words.  Branch
   // free: every lane reads a slot (rank < 64 keeps it inside ring + mirror), the renormalising ones keep it.
   auto decode_pop = [&](u64 mask) {  // mask = lanes with x < L
@@ -357,21 +372,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
                  : [m] "s"(mask), [mlo] "s"((u32)mask), [mhi] "s"((u32)(mask >> 32)), [sb] "s"(sbase),
                    [sel] "s"(0x01000504u), [full] "s"(full_exec)
                  : "memory");
-    // the ring bookkeeping is wave-uniform: pin it to SGPRs so its tests are scalar branches
-    if (__builtin_expect(e <= trig, 0)) {
-      if (pending == 0u) {
-        pend = block_load(top_blk - 2);
-        pending = 1u;
-        trig = 128 * top_blk;
-      } else {
-        wave_lds_fence();  // every lane's reads of the upper block are done
-        block_commit(top_blk - 2, pend);
-        top_blk = __builtin_amdgcn_readfirstlane(top_blk - 1);
-        pending = 0u;
-        trig = 128 * top_blk + 64;
-        wave_lds_fence();
-      }
-    }
+    if (__builtin_expect(e <= trig, 0)) ring_event();
   };
   // One token: search, state update, word pop.  Returns the symbol as an LDS address: of its dequantisation LUT
   // entry (wide) or of its CDF entry (narrow); `lv` receives the LUT value.
@@ -390,6 +391,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
       // compare of the whole entry with slot << 16 | 0xffff.  Levels 1-2 on the register pivots pick a quarter,
       // ONE ds_read_b128 brings its four entries, levels 3-4 select among them in registers: a single LDS round
       // trip per token in the search, and `r` follows the symbol as the address of its LUT entry.
+      if constexpr (COUNTS) {
+        // Round 6.  All four levels are exec-predicated moves (levels 1-2 on the register pivots pick the quarter, 3-4
+        // pick the entry among the four the ds_read_b128 brought): the replica of this step (tools/probes/decode_step.py)
+        // runs 3 - 5 ns per token faster with v_cmpx + v_mov than with the unsigned-minimum selection round 5 used for
+        // levels 3-4 (4 v_sub + v_min3 + v_min) -- same instruction count, but moves under a mask cost about half a
+        // subtraction.  d = key - entry = slot - start (bits 23 ..), the symbol's LUT address (bits 10 .. 19) and freq
+        // (bits 0 .. 9); x = freq * (x >> 9) + (slot - start).  The LUT value is read before the renormalising lanes take
+        // over exec (v_cmpx writes exec AND vcc: no scalar exec write, the count and the ranks come from vcc); the word
+        // pop follows in the same block, its s_waitcnt covers the LUT read too.  Four scalar instructions stand between
+        // the v_cmpx and the v_mbcnt that reads vcc (gfx940 family: two wait states between a VALU write of an SGPR and
+        // a VALU read of it).
+        u32 sl, q, pm, r, d, f, t, cnt;
+        asm("v_lshl_or_b32 %[sl], %[x], 23, %[ffff]\n\t"
+            "v_mov_b32_e32 %[q], %[colA]\n\t"
+            "v_mov_b32_e32 %[pm], %[pA]\n\t"
+            "v_cmpx_le_u32_e32 vcc, %[pB], %[sl]\n\t"
+            "v_mov_b32_e32 %[q], %[colB]\n\t"
+            "v_mov_b32_e32 %[pm], %[pC]\n\t"
+            "s_mov_b64 exec, %[full]\n\t"
+            "v_cmpx_le_u32_e32 vcc, %[pm], %[sl]\n\t"
+            "v_add_u32_e32 %[q], 0x400, %[q]\n\t"
+            "s_mov_b64 exec, %[full]"
+            : [sl] "=&v"(sl), [q] "=&v"(q), [pm] "=&v"(pm)
+            : [x] "v"(x), [ffff] "v"(c_ffff), [pA] "v"(pA), [pB] "v"(pB), [pC] "v"(pC), [colA] "v"(col_addr),
+              [colB] "v"(colB_addr), [full] "s"(full_exec)
+            : "vcc");
+        const u32x4_t e4 = *(const __attribute__((address_space(3))) u32x4_t*)(size_t)q;
+        u32 e0 = e4.x, e1 = e4.y;
+        asm volatile("v_cmpx_le_u32_e32 vcc, %[e2], %[sl]\n\t"
+                     "v_mov_b32_e32 %[e0], %[e2]\n\t"
+                     "v_mov_b32_e32 %[e1], %[e3]\n\t"
+                     "s_mov_b64 exec, %[full]\n\t"
+                     "v_cmpx_le_u32_e32 vcc, %[e1], %[sl]\n\t"
+                     "v_mov_b32_e32 %[e0], %[e1]\n\t"
+                     "s_mov_b64 exec, %[full]\n\t"
+                     "v_lshrrev_b32_e32 %[x], 9, %[x]\n\t"
+                     "v_sub_u32_e32 %[d], %[sl], %[e0]\n\t"
+                     "v_bfe_u32 %[r], %[d], 10, 10\n\t"
+                     "ds_read_b32 %[lv], %[r]\n\t"
+                     "v_and_b32_e32 %[f], 0x3ff, %[d]\n\t"
+                     "v_lshrrev_b32_e32 %[d], 23, %[d]\n\t"
+                     "v_mad_u32_u24 %[x], %[x], %[f], %[d]\n\t"
+                     "v_cmpx_lt_u32_e32 vcc, %[x], %[L]\n\t"
+                     "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+                     "s_sub_i32 %[e], %[e], %[cnt]\n\t"
+                     "s_and_b32 %[cnt], %[e], 0xff\n\t"
+                     "s_lshl1_add_u32 %[cnt], %[cnt], %[ring]\n\t"
+                     "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+                     "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+                     "v_lshl_add_u32 %[t], %[t], 1, %[cnt]\n\t"
+                     "ds_read_u16 %[t], %[t]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_perm_b32 %[x], %[t], %[x], %[sel]\n\t"
+                     "s_mov_b64 exec, %[full]"
+                     : [x] "+v"(x), [e] "+s"(e), [e0] "+v"(e0), [e1] "+v"(e1), [r] "=&v"(r), [lv] "=&v"(lv), [d] "=&v"(d),
+                       [f] "=&v"(f), [t] "=&v"(t), [cnt] "=&s"(cnt)
+                     : [sl] "v"(sl), [e2] "v"(e4.z), [e3] "v"(e4.w), [L] "v"(Lv), [ring] "s"(ring_addr),
+                       [sel] "s"(0x01000504u), [full] "s"(full_exec)
+                     : "vcc", "scc", "memory");
+        if (__builtin_expect(e <= trig, 0)) ring_event();
+        return r;
+      } else {
       u32 sl, q, r, pm;
       u64 mask;
       // levels 1-2 as one block, both exec-predicated (no back-to-back v_cndmask on one vcc, which the issue probe
@@ -409,48 +472,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
             [colB] "v"(colB_addr), [full] "s"(full_exec), [ksh] "n"(KSH)
           : "vcc");
       const u32x4_t e4 = *(const __attribute__((address_space(3))) u32x4_t*)(size_t)q;
-      if constexpr (!COUNTS) r = (q - lut_qbias) >> 6;  // LUT entry of the quarter's first symbol: quarter * 1024 -> quarter * 16 bytes
+      r = (q - lut_qbias) >> 6;  // LUT entry of the quarter's first symbol: quarter * 1024 -> quarter * 16 bytes
       u32 e0 = e4.x, e1 = e4.y, d;
       // levels 3-4 among the quarter's entries, then x = freq * (x >> 16) + (slot - start) (start is the entry's
       // upper half, freq its lower half) and the renormalisation test, as one block: no hazard padding in between
-      if constexpr (!COUNTS) {
-        asm("v_cmpx_le_u32_e32 vcc, %[e2], %[sl]\n\t"
-            "v_mov_b32_e32 %[e0], %[e2]\n\t"
-            "v_mov_b32_e32 %[e1], %[e3]\n\t"
-            "v_add_u32_e32 %[r], 8, %[r]\n\t"
-            "s_mov_b64 exec, %[full]\n\t"
-            "v_cmpx_le_u32_e32 vcc, %[e1], %[sl]\n\t"
-            "v_mov_b32_e32 %[e0], %[e1]\n\t"
-            "v_add_u32_e32 %[r], 4, %[r]\n\t"
-            "s_mov_b64 exec, %[full]\n\t"
-            "v_sub_u32_sdwa %[d], %[x], %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
-            "v_mad_u32_u16 %[x], %[x], %[e0], %[d] op_sel:[1,0,0,0]\n\t"
-            "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
-            : [e0] "+v"(e0), [e1] "+v"(e1), [r] "+v"(r), [x] "+v"(x), [d] "=&v"(d), [m] "=&s"(mask)
-            : [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [full] "s"(full_exec), [lv] "v"(Lv)
-            : "vcc");
-      } else {
-        // no selection: d = the smallest of key - entry over the quarter (see the table above) = slot - start (bits
-        // 23 ..), the symbol's LUT address (bits 10 .. 19) and freq (bits 0 .. 9) of the entry found; x = freq * (x >> 9)
-        // + (slot - start)
-        u32 f, d0, d1, d2;
-        asm("v_sub_u32_e32 %[d0], %[sl], %[e0]\n\t"
-            "v_sub_u32_e32 %[d1], %[sl], %[e1]\n\t"
-            "v_sub_u32_e32 %[d2], %[sl], %[e2]\n\t"
-            "v_sub_u32_e32 %[d], %[sl], %[e3]\n\t"
-            "v_min3_u32 %[d0], %[d0], %[d1], %[d2]\n\t"
-            "v_lshrrev_b32_e32 %[x], 9, %[x]\n\t"
-            "v_min_u32_e32 %[d], %[d], %[d0]\n\t"
-            "v_and_b32_e32 %[f], 0x3ff, %[d]\n\t"
-            "v_bfe_u32 %[r], %[d], 10, 10\n\t"
-            "v_lshrrev_b32_e32 %[d], 23, %[d]\n\t"
-            "v_mad_u32_u24 %[x], %[x], %[f], %[d]\n\t"
-            "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
-            : [r] "=&v"(r), [x] "+v"(x), [d] "=&v"(d), [f] "=&v"(f), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [m] "=&s"(mask)
-            : [e0] "v"(e4.x), [e1] "v"(e4.y), [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [lv] "v"(Lv));
-      }
+      asm("v_cmpx_le_u32_e32 vcc, %[e2], %[sl]\n\t"
+          "v_mov_b32_e32 %[e0], %[e2]\n\t"
+          "v_mov_b32_e32 %[e1], %[e3]\n\t"
+          "v_add_u32_e32 %[r], 8, %[r]\n\t"
+          "s_mov_b64 exec, %[full]\n\t"
+          "v_cmpx_le_u32_e32 vcc, %[e1], %[sl]\n\t"
+          "v_mov_b32_e32 %[e0], %[e1]\n\t"
+          "v_add_u32_e32 %[r], 4, %[r]\n\t"
+          "s_mov_b64 exec, %[full]\n\t"
+          "v_sub_u32_sdwa %[d], %[x], %[e0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+          "v_mad_u32_u16 %[x], %[x], %[e0], %[d] op_sel:[1,0,0,0]\n\t"
+          "v_cmp_lt_u32_e64 %[m], %[x], %[lv]"
+          : [e0] "+v"(e0), [e1] "+v"(e1), [r] "+v"(r), [x] "+v"(x), [d] "=&v"(d), [m] "=&s"(mask)
+          : [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [full] "s"(full_exec), [lv] "v"(Lv)
+          : "vcc");
       if (!SYMOUT) lv = *(lds_f32p)(size_t)r;  // issued here: back by the time the word pop below has its word
       return decode_pop(mask), r;
+      }
     } else {
       constexpr u32 ESTRIDE = 128u;  // bytes between entries of a lane's column
       u32 slot = x & (COUNTS ? 0x1ffu : 0xffffu);
@@ -551,8 +594,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
     auto scale_f32 = [&](u32 sb) -> float {
       return SRC_BF16 ? __uint_as_float(sb << 16) : (float)__builtin_bit_cast(_Float16, (unsigned short)sb);
     };
-    u32 sc_next = scale_bits(nskip);
-    for (u32 t0 = nskip; t0 < T; t0 += 64) {
+    // Round 6, bf16 -> bf16 contiguous rows of the counts model: blocks of EIGHT tokens.  The eight scales are one
+    // s_load_dwordx4 a block ahead (bf16 pairs: a scalar shift / mask makes each an fp32 SGPR operand of the multiply:
+    // no v_readlane), two tokens share one v_cvt_pk_bf16_f32 and leave as buffer_store_short + buffer_store_short_d16_hi,
+    // and the trip count, scale index and row offset cost three scalar instructions per eight tokens instead of per
+    // token.  Needs the first scale on a dword boundary (T even, or an even plane; an even trim); whatever is left --
+    // the last T % 8 tokens, every other combination -- takes the one-token loop below.
+    u32 tgen = nskip;
+    if constexpr (!SYMOUT && !PAGED && SRC_BF16 && DT_OUT == LMC_DTYPE_BF16 && decltype(model_tag)::value) {
+      typedef u32x4_t __attribute__((aligned(4))) u32x4_a4;
+      const u64 sc_addr = uniform_ptr(scl) + 2ull * nskip;
+      if ((sc_addr & 2ull) == 0ull && nskip + 8u <= T) {
+        const u32 nblk = (u32)__builtin_amdgcn_readfirstlane((int)((T - nskip) >> 3));
+        const __attribute__((address_space(4))) u32x4_a4* sp = (const __attribute__((address_space(4))) u32x4_a4*)sc_addr;
+        u32x4_t cur = sp[0];
+        const u64 rbase = ubase + (u64)((long long)(tdst0 + (int)nskip) * row_step);
+        const u32x4_t desc = {(u32)rbase, (u32)(rbase >> 32) & 0xffffu, 0xfffffff0u, 0x00020000u};
+        auto pair = [&](u32 s2) {
+          float lva = 0.0f, lvb = 0.0f;
+          (void)decode_token(top_tag, model_tag, lva);
+          (void)decode_token(top_tag, model_tag, lvb);
+          const float va = lva * __uint_as_float(s2 << 16), vb = lvb * __uint_as_float(s2 & 0xffff0000u);
+          u32 w;
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(va), "v"(vb));
+          asm volatile("buffer_store_short %0, %1, %2, %3 offen nt\n\t"
+                       "buffer_store_short_d16_hi %0, %1, %2, %4 offen nt"
+                       :: "v"(w), "v"(voff), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
+          soff += 2u * (u32)row_step;
+        };
+        for (u32 b = 0; b < nblk; b++) {
+          u32x4_t nxt = cur;
+          if (b + 1u < nblk) nxt = sp[b + 1u];
+          pair(cur.x);
+          pair(cur.y);
+          pair(cur.z);
+          pair(cur.w);
+          cur = nxt;
+        }
+        tgen += 8u * nblk;
+      }
+    }
+    u32 sc_next = scale_bits(tgen);
+    for (u32 t0 = tgen; t0 < T; t0 += 64) {
       const u32 nt = (u32)__builtin_amdgcn_readfirstlane((int)min(T - t0, 64u));
       const float sc = scale_f32(sc_next);
       sc_next = scale_bits(t0 + nt);

@@ -1,0 +1,163 @@
+// lib_ab.hip -- same-process A/B of builds of liblmc_hip.so: every library encodes and decodes THE SAME buffers
+// (one allocation: no placement difference between the builds), alternating, several rounds.
+//
+//   hipcc --offload-arch=gfx950 -O2 -o tools/probes/lib_ab tools/probes/lib_ab.hip -Iinclude -ldl
+//   tools/probes/lib_ab rounds reps dtype(0 bf16 / 1 fp16) name=path/to/liblmc_hip.so [name=path ...]
+//
+// Prints per library the minimum and the median over the rounds of: fused encode ms, decode ms (HIP events over `reps`
+// back-to-back jobs of the Llama-3-8B 16 k context), and checks that every library's blobs equal the first one's.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "lmc_hip.h"
+
+#define CK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e__), __FILE__, __LINE__); exit(2); } } while (0)
+#define LK(x) do { int r__ = (x); if (r__ != 0) { fprintf(stderr, "lmc error %d at %s:%d\n", r__, __FILE__, __LINE__); exit(3); } } while (0)
+
+__device__ inline unsigned hash32(unsigned long long i) {
+  unsigned long long z = i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned)(z >> 32);
+}
+__global__ void fill(unsigned short* kv, long long n, int dtype) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    unsigned h = hash32((unsigned long long)i);
+    float f = (float)(h >> 8) * (1.0f / 16777216.0f);
+    unsigned short b;
+    if (dtype == 0) { unsigned u = __float_as_uint(f); b = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
+    else b = __builtin_bit_cast(unsigned short, (_Float16)f);
+    kv[i] = b;
+  }
+}
+__global__ void diff16(const uint4* a, const uint4* b, unsigned long long n16, unsigned long long* bad) {
+  unsigned long long c = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * blockDim.x) {
+    uint4 x = a[i], y = b[i];
+    if (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) c++;
+  }
+  if (c) atomicAdd(bad, c);
+}
+
+struct Lib {
+  std::string name;
+  void* h;
+  decltype(&lmc_ctx_create) ctx_create;
+  decltype(&lmc_encode_chunks) encode;
+  decltype(&lmc_decode_chunks) decode;
+  decltype(&lmc_ctx_set_encode_path) set_path;
+  lmc_ctx* ctx;
+  std::vector<double> enc, dec;
+};
+
+static int plane_bins(int p, int L) { const int kv = p >= L, l = p - kv * L; return !kv ? (l < 10 ? 32 : 16) : (l < 2 ? 32 : 16); }
+
+int main(int argc, char** argv) {
+  if (argc < 5) { fprintf(stderr, "usage: lib_ab rounds reps dtype name=path ...\n"); return 1; }
+  const int rounds = atoi(argv[1]), reps = atoi(argv[2]), dtype = atoi(argv[3]);
+  const int L = 32, H = 8, D = 128, ctx_tok = 16384, chunk = 256, C = H * D, P = 2 * L, nchunks = ctx_tok / chunk;
+  const long long nelem = (long long)P * ctx_tok * C;
+  std::vector<Lib> libs;
+  for (int i = 4; i < argc; i++) {
+    Lib l;
+    const char* eq = strchr(argv[i], '=');
+    l.name = std::string(argv[i], eq - argv[i]);
+    l.h = dlopen(eq + 1, RTLD_NOW | RTLD_LOCAL);
+    if (!l.h) { fprintf(stderr, "dlopen %s: %s\n", eq + 1, dlerror()); return 1; }
+    l.ctx_create = (decltype(l.ctx_create))dlsym(l.h, "lmc_ctx_create");
+    l.encode = (decltype(l.encode))dlsym(l.h, "lmc_encode_chunks");
+    l.decode = (decltype(l.decode))dlsym(l.h, "lmc_decode_chunks");
+    l.set_path = (decltype(l.set_path))dlsym(l.h, "lmc_ctx_set_encode_path");
+    LK(l.ctx_create(0, &l.ctx));
+    LK(l.set_path(l.ctx, LMC_ENCODE_PATH_FUSED));
+    libs.push_back(l);
+  }
+  unsigned short *kv, *out;
+  CK(hipMalloc(&kv, nelem * 2));
+  CK(hipMalloc(&out, nelem * 2));
+  fill<<<4096, 256>>>(kv, nelem, dtype);
+  std::vector<int32_t> bins(P);
+  for (int p = 0; p < P; p++) bins[p] = plane_bins(p, L);
+  lmc_kv_layout lay;
+  memset(&lay, 0, sizeof lay);
+  lay.dtype = dtype == 0 ? LMC_DTYPE_BF16 : LMC_DTYPE_FP16;
+  lay.num_layers = L; lay.num_heads = H; lay.head_size = D; lay.base = kv;
+  lay.stride_layer = 2ll * ctx_tok * C; lay.stride_kv = (long long)ctx_tok * C; lay.stride_token = C; lay.stride_head = D;
+  lmc_kv_layout dl = lay;
+  dl.base = out;
+  const uint64_t stride = (lmc_blob_bound(L, chunk, H, D) + 15) & ~15ull;
+  unsigned char *blob, *blob0;
+  unsigned* sizes;
+  CK(hipMalloc(&blob, stride * nchunks));
+  CK(hipMalloc(&blob0, stride * nchunks));
+  CK(hipMalloc(&sizes, 4 * nchunks));
+  unsigned* status;
+  CK(hipHostMalloc((void**)&status, 64, hipHostMallocMapped));
+  memset(status, 0, 64);
+  unsigned long long* bad;
+  CK(hipHostMalloc((void**)&bad, 8, hipHostMallocMapped));
+  hipStream_t s;
+  CK(hipStreamCreate(&s));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  // reference blobs and decoded KV from the first library
+  CK(hipMemset(blob0, 0, stride * nchunks));
+  LK(libs[0].encode(libs[0].ctx, &lay, 0, ctx_tok, chunk, bins.data(), blob0, stride, sizes, status, s));
+  CK(hipStreamSynchronize(s));
+  unsigned short* out0;
+  CK(hipMalloc(&out0, nelem * 2));
+  { lmc_kv_layout d0 = lay; d0.base = out0; LK(libs[0].decode(libs[0].ctx, blob0, stride, nchunks, &d0, 0, chunk, status + 1, s)); CK(hipStreamSynchronize(s)); }
+  for (size_t k = 0; k < libs.size(); k++) {
+    Lib& l = libs[k];
+    CK(hipMemset(blob, 0, stride * nchunks));
+    CK(hipMemset(out, 0xff, nelem * 2));
+    LK(l.encode(l.ctx, &lay, 0, ctx_tok, chunk, bins.data(), blob, stride, sizes, status, s));
+    LK(l.decode(l.ctx, blob, stride, nchunks, &dl, 0, chunk, status + 1, s));
+    CK(hipStreamSynchronize(s));
+    *bad = 0;
+    // (the blob arena between the blobs is never written: zero in both)
+    diff16<<<2048, 256, 0, s>>>((const uint4*)blob, (const uint4*)blob0, stride * nchunks / 16, bad);
+    CK(hipStreamSynchronize(s));
+    const unsigned long long bb = *bad;
+    *bad = 0;
+    diff16<<<2048, 256, 0, s>>>((const uint4*)out, (const uint4*)out0, nelem * 2 / 16, bad);
+    CK(hipStreamSynchronize(s));
+    printf("%-8s blobs differ from %s's in %llu 16-byte words, decoded KV in %llu; status %u %u\n", l.name.c_str(), libs[0].name.c_str(), bb, *bad, status[0], status[1]);
+  }
+  for (int r = 0; r < rounds; r++) {
+    for (size_t kk = 0; kk < libs.size(); kk++) {
+      Lib& l = libs[(kk + r) % libs.size()];
+      float ms;
+      for (int w = 0; w < 2; w++) LK(l.encode(l.ctx, &lay, 0, ctx_tok, chunk, bins.data(), blob, stride, sizes, status, s));
+      CK(hipEventRecord(e0, s));
+      for (int i = 0; i < reps; i++) LK(l.encode(l.ctx, &lay, 0, ctx_tok, chunk, bins.data(), blob, stride, sizes, status, s));
+      CK(hipEventRecord(e1, s));
+      CK(hipStreamSynchronize(s));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      l.enc.push_back(ms / reps);
+      for (int w = 0; w < 2; w++) LK(l.decode(l.ctx, blob, stride, nchunks, &dl, 0, chunk, status + 1, s));
+      CK(hipEventRecord(e0, s));
+      for (int i = 0; i < reps; i++) LK(l.decode(l.ctx, blob, stride, nchunks, &dl, 0, chunk, status + 1, s));
+      CK(hipEventRecord(e1, s));
+      CK(hipStreamSynchronize(s));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      l.dec.push_back(ms / reps);
+    }
+  }
+  printf("%-8s %10s %10s %10s %10s   (ms per 16 k context, %d rounds x %d jobs)\n", "library", "enc min", "enc med", "dec min", "dec med", rounds, reps);
+  for (Lib& l : libs) {
+    std::sort(l.enc.begin(), l.enc.end());
+    std::sort(l.dec.begin(), l.dec.end());
+    printf("%-8s %10.4f %10.4f %10.4f %10.4f\n", l.name.c_str(), l.enc[0], l.enc[l.enc.size() / 2], l.dec[0], l.dec[l.dec.size() / 2]);
+  }
+  return 0;
+}
