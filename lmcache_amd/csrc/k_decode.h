@@ -52,6 +52,9 @@ struct DecodeArgs {
 #ifndef LMC_DEC_NT_IN
 #define LMC_DEC_NT_IN 1  // the stream words are read once: non-temporal loads (decode 0.963 -> 0.950 ms, same box)
 #endif
+#ifndef DEC_WAVES
+#define DEC_WAVES 1  // waves (= group streams) per workgroup: ONE (round 6) -- a slot is free again the moment its stream is done, not when the slowest of four is (resident waves 89 -> 97 %, decode -3 %: profiles/r06_timelines.md)
+#endif
 #define DEC_CDF_BYTES 4224
 #define DEC_RING_WORDS 256
 #define DEC_RING_BYTES (2 * (DEC_RING_WORDS + 64))
@@ -66,17 +69,24 @@ __device__ __forceinline__ u64 uniform_ptr(const void* p) {  // a pointer every 
   return ((u64)hi << 32) | (u64)lo;
 }
 
+#ifdef LMC_EXP_TIMELINE  // experiments only: time stamps of every stream's wave (tools/probes/decode_timeline.hip / .py)
+__device__ unsigned long long g_decode_timeline[65536 * 4];
+#define LMC_DTL(k, v) do { if (lane == 0 && gid < 65536u) g_decode_timeline[gid * 4u + (k)] = (v); } while (0)
+#else
+#define LMC_DTL(k, v) do { } while (0)
+#endif
 template <bool SYMOUT, int DT_OUT, bool PAGED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k_decode(DecodeArgs a) {
-  __shared__ __attribute__((aligned(16))) u8 lds_all[4 * (DEC_LUT_BYTES + DEC_WAVE_BYTES)];
+__global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(8))) void k_decode(DecodeArgs a) {
+  __shared__ __attribute__((aligned(16))) u8 lds_all[DEC_WAVES * (DEC_LUT_BYTES + DEC_WAVE_BYTES)];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform -> SGPRs
   // (32-bit work-item arithmetic: lmc_api.hip rejects a launch of 2^31 streams or more, and a 64-bit division costs
   // more than a hundred instructions per stream)
-  const u32 gid = blockIdx.x * 4u + (u32)wave;
+  const u32 gid = blockIdx.x * (u32)DEC_WAVES + (u32)wave;
   const int n = 2 * a.layer_count * a.G;  // streams of a chunk in this launch
   if (gid >= (u32)a.nchunks * (u32)n) return;
-  u8* wl = lds_all + 4 * DEC_LUT_BYTES + wave * DEC_WAVE_BYTES;
+  LMC_DTL(0, (unsigned long long)wall_clock64());
+  u8* wl = lds_all + DEC_WAVES * DEC_LUT_BYTES + wave * DEC_WAVE_BYTES;
   u16* cdfT = reinterpret_cast<u16*>(wl);                           // [33][64]: entry-major, bank = lane/2
   u16* ring = reinterpret_cast<u16*>(wl + DEC_CDF_BYTES);           // stream words, word j at slot j % 256; slots 256..319 mirror 0..63
   float* lut = reinterpret_cast<float*>(lds_all + wave * DEC_LUT_BYTES);  // (q - C) / C
@@ -88,9 +98,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   const int p = pidx < a.layer_count ? a.layer_begin + pidx : (a.P >> 1) + a.layer_begin + pidx - a.layer_count;
   const int pg = p * a.G + g;
   const u8* blob = a.blob_ptrs ? (const u8*)uniform_ptr(a.blob_ptrs[chunk]) : a.blobs + (long long)chunk * a.blob_stride;
-  const u32* hd = reinterpret_cast<const u32*>(blob);
-  // header words are the same for every lane: read them through SGPRs so all control flow below is scalar
-  auto hdw = [&](int i) { return (u32)__builtin_amdgcn_readfirstlane((int)hd[i]); };
+  // The header's 32 words with ONE coalesced load (lane i holds word i), handed out by v_readlane: all control flow
+  // below is scalar, and the validity test -- a chain of || over nine header words -- no longer walks through nine
+  // dependent round trips to memory (round 6: the prologue was 15 us of a wave's 95, most of it this chain).
+  const u32 hv = ((const LMC_GLOBAL u32*)blob)[lane & 31];
+  // Issued with it, before anything waits: the plane's bin count (at a fixed offset) and -- blobs in an arena or a
+  // pack's static slots, where a full-length chunk's directory offset lies inside the slot whatever this chunk's
+  // length turns out to be -- the directory entry at the offset a chunk of chunk_tokens tokens has it at.  A shorter
+  // chunk (a ragged last one) reads its entry again below.  (Blobs behind a pointer table end where they end: no
+  // speculative read there.)
+  const u32 bins_p = (u32)((const LMC_GLOBAL u8*)blob)[LMC_HEADER_BYTES + p];
+  const BlobOff bo_spec = lmc_blob_off((u32)a.P, (u32)a.chunk_tokens, (u32)a.G);
+  const bool spec = !SYMOUT && !a.blob_ptrs && (unsigned long long)bo_spec.streams <= (unsigned long long)a.blob_stride;
+  u32x2_t gd_spec = {0u, 0u};
+  u32 sbeg_spec = 0;
+  if (spec) {
+    gd_spec = *(const LMC_GLOBAL u32x2_t*)(blob + bo_spec.gdir + 8u * (u32)pg);
+    if (a.seg_off) sbeg_spec = *(const LMC_GLOBAL u32*)(blob + bo_spec.gdir + 8u * (u32)(p * a.G));
+  }
+  auto hdw = [&](int i) { return (u32)__builtin_amdgcn_readlane((int)hv, i); };
   const u32 T = hdw(4);
   const u32 src_dtype = hdw(2);
   const bool counts_model = hdw(22) == LMC_MODEL_COUNTS;  // wave-uniform: the coder ran on the symbol counts (2 <= T <= 256)
@@ -109,14 +135,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
 
   // ---- where the stream lies (directory entry {beg, end}, lmc_format.h v6) ------------------------------------------
   const u32* gdir = reinterpret_cast<const u32*>(blob + bo.gdir);
-  const u32 start = (u32)__builtin_amdgcn_readfirstlane((int)gdir[2 * pg]);
-  const u32 end = (u32)__builtin_amdgcn_readfirstlane((int)gdir[2 * pg + 1]);
+  const bool spec_ok = spec && bo.gdir == bo_spec.gdir;  // wave-uniform
+  u32x2_t gd = gd_spec;
+  if (!spec_ok) gd = *(const LMC_GLOBAL u32x2_t*)(const LMC_GLOBAL u32*)(gdir + 2 * pg);
+  const u32 start = (u32)__builtin_amdgcn_readfirstlane((int)gd.x);
+  const u32 end = (u32)__builtin_amdgcn_readfirstlane((int)gd.y);
   const u8* sbytes = blob + bo.streams + start;
   bool seg_bad = false;
   if (a.seg_off) {  // pack: this plane's streams are a segment of their own, wave-uniform addresses
     const long long si = (long long)p * a.seg_n + chunk;  // pack v3: segments in plane order (K planes, then V planes)
     const unsigned long long so = uniform_ptr((const void*)a.seg_off[si]), se = uniform_ptr((const void*)a.seg_off[si + 1]);
-    const u32 sbeg = (u32)__builtin_amdgcn_readfirstlane((int)gdir[2 * (p * a.G)]);  // the plane's first stream
+    const u32 sbeg = (u32)__builtin_amdgcn_readfirstlane((int)(spec_ok ? sbeg_spec : gdir[2 * (p * a.G)]));  // the plane's first stream
     seg_bad = start < sbeg || se < so || (unsigned long long)end - sbeg > se - so;
     sbytes = a.seg_streams + so + (start - sbeg);
   }
@@ -130,7 +159,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   // ---- the stream's head: symbol counts of this group -> the CDF table in LDS, [entry][lane] u16 ---------------------
   // The head stores the counts of every channel's symbols 0 .. nsym-1 (nsym = bins - 1) bit-sliced (k_head.h); a lane
   // takes its own channel's counts and turns them into its column of the table with the encoder's integer arithmetic.
-  const u32 nsym = min(31u, max(3u, (u32)__builtin_amdgcn_readfirstlane((int)blob[bo.bins + p]) - 1u));
+  const u32 nsym = min(31u, max(3u, (u32)__builtin_amdgcn_readfirstlane((int)bins_p) - 1u));
+  // the lanes' final states (the stream's last 256 bytes: their place does not depend on the head's size): requested
+  // here, together with the head
+  const LMC_GLOBAL u16* const xw = (const LMC_GLOBAL u16*)sbytes + ((end - start) >> 1) - 128u + 2u * (u32)lane;
+  const u32 x_lo = xw[0], x_hi = xw[1];
   u32 head_bytes;
   {
     u32 cv[32];
@@ -251,15 +284,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
     }
   }
   if (!SYMOUT && lane < 32) {
-    const float Cf = (float)((int)blob[bo.bins + p] / 2 - 1);
+    const float Cf = (float)((int)bins_p / 2 - 1);
     const float v = (float)lane - Cf;
     lut[lane] = v / Cf;
   }
 
+  LMC_DTL(1, (unsigned long long)wall_clock64());
   // ---- stream ----------------------------------------------------------------
   const u16* words = reinterpret_cast<const u16*>(sbytes + head_bytes);
   const u32 nwords = ((end - start - head_bytes) >> 1) - 128u;  // 16-bit words in front of the 64 states
-  u32 x = (u32)words[nwords + 2 * lane] | ((u32)words[nwords + 2 * lane + 1] << 16);
+  u32 x = x_lo | (x_hi << 16);
   // The decoder consumes the stream from its end: after `e` = number of words not yet consumed, a token whose
   // cnt lanes renormalise takes words [e - cnt, e), ascending with the lane (the encoder's append order).  The
   // words are staged in STREAM ORDER in a 256-word LDS ring, word j at slot j % 256, in blocks of 128 words
@@ -694,6 +728,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k
   if (src_dtype == (u32)LMC_DTYPE_BF16) run_src(BoolTag<true>{});
   else run_src(BoolTag<false>{});
 
+#ifdef LMC_EXP_TIMELINE
+  LMC_DTL(2, (unsigned long long)wall_clock64());
+  {
+    u32 hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    LMC_DTL(3, ((unsigned long long)nsym << 48) | ((unsigned long long)xcc << 32) | hwid);
+  }
+#endif
   const bool state_bad = active && x != rans_l;
   if (e != 0 || __ballot(state_bad)) {
     if (lane == 0) atomicOr(a.status, LMC_ST_BAD_STREAM);

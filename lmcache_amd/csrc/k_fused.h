@@ -51,6 +51,12 @@
 #define LMC_FUSED_PRIO_A 3  // wave priority while a wave fetches / quantises (phase A): its few instructions go first
 #endif
 
+#ifdef LMC_EXP_TIMELINE  // experiments only: phase time stamps of every work item (tools/probes/fused_timeline.hip / .py)
+__device__ unsigned long long g_fused_timeline[8192 * 8];
+#define LMC_TL(k) do { if (threadIdx.x == 0 && tick < 8192u) g_fused_timeline[tick * 8u + (k)] = wall_clock64(); } while (0)
+#else
+#define LMC_TL(k) do { } while (0)
+#endif
 struct FusedArgs {
   KvAddr src;
   EncodeArgs e;  // e.sym4 = workspace (written in phase A), e.agg = epoch-tagged plane granules [nchunks][P]
@@ -428,7 +434,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // consecutive work items are the same planes of consecutive chunks (see k_cdf_encode): an item's predecessors
   // in the look-back were taken at least nchunks workgroups earlier.  The item comes from a ticket, not from
   // blockIdx (EncodeArgs::ticket): a predecessor's workgroup has started, whatever order the hardware dispatches in.
-  const u32 item = fa.item_base + (u32)__builtin_amdgcn_readfirstlane((int)draw_ticket(a.ticket, a.ticket_base));
+  const u32 tick = (u32)__builtin_amdgcn_readfirstlane((int)draw_ticket(a.ticket, a.ticket_base));
+  const u32 item = fa.item_base + tick;
+  LMC_TL(0);
+#ifdef LMC_EXP_TIMELINE
+  if (threadIdx.x == 0 && tick < 8192u) {
+    u32 hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_fused_timeline[tick * 8u + 6u] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
   const int chunk = (int)(item % (unsigned)a.nchunks), it = (int)(item / (unsigned)a.nchunks);
   const int p0 = it * fa.pl, np = min(fa.pl, a.P - p0);  // the item's planes
   const int NS = np * a.G;                               // ... and streams: j -> plane p0 + j / G, group j % G
@@ -557,6 +573,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     __builtin_amdgcn_s_setprio(0);
   }
   __syncthreads();  // symbols and scales of the item are visible to the workgroup
+  LMC_TL(1);
 
   // ---- pass 1: the counts of this wave's group streams, and from them the streams' allocations ----------------
   // stream j of the item = group j % G of plane p0 + j / G
@@ -579,6 +596,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   pass1(wave, cs0);
   pass1(wave + NW, cs1);
   __syncthreads();
+  LMC_TL(2);
 
   // ---- placement: one look-back per item, BEFORE the streams are coded ------------------------------------------
   u32 wg_total = 0;
@@ -593,6 +611,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
   }
   __syncthreads();
+  LMC_TL(3);
 
   // ---- pass 2: every stream is coded at its final place -----------------------------------------------------------
   const BlobOff bo = lmc_blob_off((u32)a.P, (u32)Tc, (u32)a.G);
@@ -619,6 +638,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   };
   pass2(wave, cs0);
   pass2(wave + NW, cs1);
+#ifdef LMC_EXP_TIMELINE
+  LMC_TL(4);   // wave 0 is through
+  __syncthreads();
+  LMC_TL(5);   // ... every wave is
+#endif
   // The chunk's last item knows the chunk's size: header, static sections, size word.
   if (p0 + np == a.P && wave == NW - 1) {
     write_blob_static(blob, bo, a, (u32)Tc, wg_excl + wg_total, lane);

@@ -122,7 +122,22 @@ __device__ __forceinline__ u32 head_read(const u8* head_v, u32 limit, u32 R, u32
   typedef __attribute__((address_space(3))) u32x2_t* lds_u64w;
   const u8* const head = reinterpret_cast<const u8*>(uniform_ptr64(head_v));
   const u32 R8 = (R + 7u) & ~7u;
-  const u32 wv = ((u32)lane < R8 && R8 <= limit) ? (u32)((const LMC_GLOBAL u8*)head)[lane] : 0u;
+  // (loads below are unconditional, out-of-range lanes read the head's first bytes -- a stream is at least 256 bytes long --
+  // and drop them: a load under a lane condition joins with a constant, and the register's other write waits for vmcnt(0))
+  const u32 wv_raw = (u32)((const LMC_GLOBAL u8*)head)[lane];
+  const u32 wv = ((u32)lane < R8 && R8 <= limit) ? wv_raw : 0u;
+  // (round 6) the first PRE blocks of 64 planes are requested together with the widths -- W, the number of planes, is
+  // only known from the widths, but where plane p lies is not a function of them, and every plane below W lies inside
+  // `limit` (checked below): one round trip to memory instead of two for every head of up to 64 PRE planes
+  constexpr int PRE = 3;
+  const LMC_GLOBAL u32x2_t* const planes = (const LMC_GLOBAL u32x2_t*)(head + R8);
+  u32x2_t pre[PRE];
+#pragma unroll
+  for (int b = 0; b < PRE; b++) {
+    const u32 p = 64u * (u32)b + 63u - (u32)lane;
+    const bool in = (unsigned long long)R8 + 8ull * p + 8ull <= (unsigned long long)limit;
+    pre[b] = *(const LMC_GLOBAL u32x2_t*)(head + (in ? R8 + 8u * p : 0u));
+  }
   u32 W = 0;
   bool bad = R8 > limit || R > (u32)NSYM;
   u32 w[NSYM];
@@ -138,15 +153,23 @@ __device__ __forceinline__ u32 head_read(const u8* head_v, u32 limit, u32 R, u32
     for (int i = 0; i < NSYM; i++) cv[i] = 0u;
     return 0u;
   }
-  const LMC_GLOBAL u32x2_t* const planes = (const LMC_GLOBAL u32x2_t*)(head + R8);
   const lds_u64w slot = (lds_u64w)reinterpret_cast<u32x2_t*>(stage) + lane;  // row b of this lane: slot[64 b]
   wave_lds_fence();
-  for (u32 b = 0; 64u * b < W; b++) {
+#pragma unroll
+  for (int b = 0; b < PRE; b++) {
+    if (64u * (u32)b < W) {  // (wave-uniform)
+      const u32 p = 64u * (u32)b + 63u - (u32)lane;
+      u32 lo = p < W ? pre[b].x : 0u, hi = p < W ? pre[b].y : 0u;
+      transpose64(lo, hi, lane);  // lane l: its bits of planes 64 b .. 64 b + 63, the first plane on top
+      slot[64u * (u32)b] = u32x2_t{lo, hi};
+    }
+  }
+  for (u32 b = PRE; 64u * b < W; b++) {
     const u32 p = 64u * b + 63u - (u32)lane;
     u32x2_t v = {0u, 0u};
     if (p < W) v = planes[p];
     u32 lo = v.x, hi = v.y;
-    transpose64(lo, hi, lane);  // lane l: its bits of planes 64 b .. 64 b + 63, the first plane on top
+    transpose64(lo, hi, lane);
     slot[64u * b] = u32x2_t{lo, hi};
   }
   u64 cur = 0;   // the row being cut up

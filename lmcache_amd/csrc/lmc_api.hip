@@ -83,6 +83,14 @@ static int prof_mark(lmc_ctx* c, hipStream_t s) {
 }
 
 extern "C" {
+#ifdef LMC_EXP_TIMELINE  // experiments only (not in include/lmc_hip.h): the fused kernel's phase time stamps
+int lmc_debug_fused_timeline(void* host_out, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fused_timeline), bytes < sizeof(g_fused_timeline) ? bytes : sizeof(g_fused_timeline));
+}
+int lmc_debug_decode_timeline(void* host_out, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_decode_timeline), bytes < sizeof(g_decode_timeline) ? bytes : sizeof(g_decode_timeline));
+}
+#endif
 
 const char* lmc_strerror(int code) {
   switch (code) {
@@ -550,17 +558,17 @@ static int decode_common(lmc_ctx* c, const void* blobs, uint64_t blob_stride, in
 static int decode_launch(lmc_ctx* c, DecodeArgs& a, const lmc_kv_layout* dst, hipStream_t hs) {
   int rc;
   const long long n = (long long)a.nchunks * 2 * a.layer_count * a.G;
-  dim3 grid((unsigned)((n + 3) / 4));
+  dim3 grid((unsigned)((n + DEC_WAVES - 1) / DEC_WAVES));
   std::lock_guard<std::mutex> lk(c->mu);
   c->pn = 0;
   if ((rc = prof_mark(c, hs))) return rc;
   const bool paged = dst->slot_mapping != nullptr;
   if (dst->dtype == LMC_DTYPE_BF16) {
-    if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, true>), grid, dim3(256), 0, hs, a);
-    else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, false>), grid, dim3(256), 0, hs, a);
+    if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, true>), grid, dim3(64 * DEC_WAVES), 0, hs, a);
+    else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, false>), grid, dim3(64 * DEC_WAVES), 0, hs, a);
   } else {
-    if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, true>), grid, dim3(256), 0, hs, a);
-    else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, false>), grid, dim3(256), 0, hs, a);
+    if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, true>), grid, dim3(64 * DEC_WAVES), 0, hs, a);
+    else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, false>), grid, dim3(64 * DEC_WAVES), 0, hs, a);
   }
   HIP_TRY(hipGetLastError());
   if ((rc = prof_mark(c, hs))) return rc;
@@ -633,7 +641,7 @@ int lmc_decode_symbols(lmc_ctx* c, const void* blob, int32_t L, int32_t H, int32
   a.sym_out = sym_out;
   HIP_TRY(hipSetDevice(c->device));
   const long long n = (long long)a.P * a.G;  // every layer (decode_common set the full range)
-  hipLaunchKernelGGL((k_decode<true, LMC_DTYPE_BF16, false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_decode<true, LMC_DTYPE_BF16, false>), dim3((unsigned)((n + DEC_WAVES - 1) / DEC_WAVES)), dim3(64 * DEC_WAVES), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return LMC_OK;
 }
@@ -842,14 +850,14 @@ int lmc_load_chunks(lmc_ctx* c, const void* const* host_blob_ptrs_h, const uint3
     const int n = l0 + step <= L ? step : L - l0;
     da.layer_begin = l0; da.layer_count = n;
     const long long nstreams = (long long)nchunks * 2 * n * da.G;
-    const dim3 grid((unsigned)((nstreams + 3) / 4));
+    const dim3 grid((unsigned)((nstreams + DEC_WAVES - 1) / DEC_WAVES));
     const bool paged = dst->slot_mapping != nullptr;
     if (dst->dtype == LMC_DTYPE_BF16) {
-      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, true>), grid, dim3(256), 0, s, da);
-      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, false>), grid, dim3(256), 0, s, da);
+      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, true>), grid, dim3(64 * DEC_WAVES), 0, s, da);
+      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, false>), grid, dim3(64 * DEC_WAVES), 0, s, da);
     } else {
-      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, true>), grid, dim3(256), 0, s, da);
-      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, false>), grid, dim3(256), 0, s, da);
+      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, true>), grid, dim3(64 * DEC_WAVES), 0, s, da);
+      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, false>), grid, dim3(64 * DEC_WAVES), 0, s, da);
     }
     HIP_TRY(hipGetLastError());
     if (range_events && range_events[r]) HIP_TRY(hipEventRecord((hipEvent_t)range_events[r], s));
@@ -1084,14 +1092,14 @@ int lmc_load_pack(lmc_ctx* c, const void* pack_h, uint64_t pack_bytes, int32_t c
     HIP_TRY(hipStreamWaitEvent(s, ev, 0));
     da.layer_begin = l0; da.layer_count = nl;
     const long long nstreams = (long long)m * 2 * nl * da.G;
-    const dim3 grid((unsigned)((nstreams + 3) / 4));
+    const dim3 grid((unsigned)((nstreams + DEC_WAVES - 1) / DEC_WAVES));
     const bool paged = dst->slot_mapping != nullptr;
     if (dst->dtype == LMC_DTYPE_BF16) {
-      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, true>), grid, dim3(256), 0, s, da);
-      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, false>), grid, dim3(256), 0, s, da);
+      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, true>), grid, dim3(64 * DEC_WAVES), 0, s, da);
+      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_BF16, false>), grid, dim3(64 * DEC_WAVES), 0, s, da);
     } else {
-      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, true>), grid, dim3(256), 0, s, da);
-      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, false>), grid, dim3(256), 0, s, da);
+      if (paged) hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, true>), grid, dim3(64 * DEC_WAVES), 0, s, da);
+      else hipLaunchKernelGGL((k_decode<false, LMC_DTYPE_FP16, false>), grid, dim3(64 * DEC_WAVES), 0, s, da);
     }
     HIP_TRY(hipGetLastError());
     if (range_events && range_events[r]) HIP_TRY(hipEventRecord((hipEvent_t)range_events[r], s));

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <vector>
 #include "lmc_hip.h"
 #define CK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e__), __FILE__, __LINE__); exit(2); } } while (0)
@@ -76,5 +77,27 @@ int main(int argc, char** argv) {
   fwrite(tl.data(), 8, tl.size(), f);
   fclose(f);
   printf("%d items, last launch %.4f ms, status %u -> %s\n", items, ms, status[0], outp);
+  auto decode = (decltype(&lmc_decode_chunks))dlsym(h, "lmc_decode_chunks");
+  auto dtimeline = (int (*)(void*, size_t))dlsym(h, "lmc_debug_decode_timeline");
+  if (decode && dtimeline) {
+    unsigned short* out;
+    CK(hipMalloc(&out, nelem * 2));
+    lmc_kv_layout dl = lay;
+    dl.base = out;
+    for (int i = 0; i < 10; i++) LK(decode(ctx, blob, stride, nchunks, &dl, 0, chunk, status + 1, s));
+    CK(hipEventRecord(e0, s));
+    LK(decode(ctx, blob, stride, nchunks, &dl, 0, chunk, status + 1, s));
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const size_t nw = (size_t)nchunks * P * ((C + 63) / 64);
+    std::vector<unsigned long long> dt((nw < 65536 ? nw : 65536) * 4);
+    if (dtimeline(dt.data(), dt.size() * 8)) { fprintf(stderr, "decode timeline copy failed\n"); return 1; }
+    std::string dp = std::string(outp) + ".decode";
+    f = fopen(dp.c_str(), "wb");
+    fwrite(dt.data(), 8, dt.size(), f);
+    fclose(f);
+    printf("%zu decode waves, last launch %.4f ms, status %u -> %s\n", dt.size() / 4, ms, status[1], dp.c_str());
+  }
   return 0;
 }
