@@ -754,7 +754,7 @@ def test_random_paged_caches_through_the_engine_equal_the_dense_path(oracle):
     rnd = np.random.default_rng(int(os.environ.get("LMC_FUZZ_SEED", "31")))
     for case in range(int(os.environ.get("LMC_FUZZ_CASES", "8"))):
         layout = ["NHBD", "NBHD"][int(rnd.integers(0, 2))]
-        bs = int(rnd.choice([8, 16, 32]))
+        bs = int(rnd.choice([8, 16, 32, 12, 48]))  # (a block size that is no power of two decodes through the one-token loop)
         cs = int(rnd.choice([256, 128, 100, 236]))
         nl, H, D = int(rnd.integers(1, 5)), int(rnd.choice([1, 2, 8])), int(rnd.choice([64, 128]))
         seg = int(rnd.integers(1, 3 * cs + 20))
