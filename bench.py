@@ -464,12 +464,17 @@ def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=Fal
     while time.perf_counter() - t_r < 0.1:
         time_encode(ctx, lay, ntok, cs, bins, blobs, stride, sizes, st.cuda_stream, st, 10)
     tenc = time_encode(ctx, lay, ntok, cs, bins, blobs, stride, sizes, st.cuda_stream, st, 20)
-    if paged:  # decode + scatter into a paged cache at random, non-contiguous slots (north-star NHBD layout)
+    ol_token = None
+    if paged:  # decode + scatter into a paged cache, non-contiguous (north-star NHBD layout): the mapping a vLLM block
+        # manager produces -- blocks anywhere, a block's tokens in order -- and, as the worst case, every token at a random
+        # slot of its own (the first decodes in blocks of eight rows, the second token by token: k_decode.h)
         bs = 16
         nblocks = (ntok + bs - 1) // bs + 5
         caches = [torch.zeros((2, nblocks, nh, bs, hd), dtype=dtype, device=dev) for _ in range(nl)]
-        slots = torch.randperm(nblocks * bs, device=dev)[:ntok]
+        pos = torch.arange(ntok, device=dev)
+        slots = torch.randperm(nblocks, device=dev)[pos // bs] * bs + pos % bs
         ol = native.KVLayout.paged(caches, slots, bs, "NHBD")
+        ol_token = native.KVLayout.paged(caches, torch.randperm(nblocks * bs, device=dev)[:ntok], bs, "NHBD")
     else:
         out = tuple((torch.empty_like(k), torch.empty_like(v)) for k, v in kv)
         ol = native.KVLayout.from_kv_tuple(out, "vllm")
@@ -485,10 +490,24 @@ def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=Fal
     e1.record()
     torch.cuda.synchronize()
     tdec = e0.elapsed_time(e1) / 20
+    tdec_token = None
+    if ol_token is not None:
+        for _ in range(20):
+            ctx.decode_chunks(blobs.data_ptr(), stride, n, ol_token, 0, cs)
+        e0.record()
+        for _ in range(20):
+            ctx.decode_chunks(blobs.data_ptr(), stride, n, ol_token, 0, cs)
+        e1.record()
+        torch.cuda.synchronize()
+        ctx.raise_on_status(name)
+        tdec_token = e0.elapsed_time(e1) / 20
     row = {"workload": name, "raw_kv_MB": round(raw / 1e6, 1), "chunks": n, "chunk_tokens": cs,
            "encode_ms": round(tenc, 3), "encode_GBps_raw": round(raw / tenc / 1e6, 1),
            "decode_ms": round(tdec, 3), "decode_GBps_raw": round(raw / tdec / 1e6, 1),
            "compression": round(raw / int(sizes.sum()), 3)}
+    if tdec_token is not None:
+        row["slot_mapping"] = "blocks at random, a block's 16 tokens in order (vLLM)"
+        row["decode_ms_every_token_at_a_random_slot"] = round(tdec_token, 3)
     if roundtrip and not paged:
         # size-independent property at full size: decode(encode(x)) reproduces x within the quantisation bound,
         # |x^ - x| <= max1 / (2 M) + 1 ulp16(max1), per token row and plane -- checked on every plane
@@ -1168,7 +1187,7 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
                   shape_rate(native, ctx, dev, "configs[3] rank shape: Llama-3-70B TP=8, 32k context (80 L, C = 128)",
                              80, 1, 128, torch.bfloat16, 32768, "Llama-3-70B"),
                   shape_rate(native, ctx, dev, "configs[4]: Mistral-7B, 8 x 2048 tokens, decode + scatter into paged "
-                                               "NHBD blocks at random slots", 32, 8, 128, torch.bfloat16, 16384,
+                                               "NHBD blocks", 32, 8, 128, torch.bfloat16, 16384,
                              "mistralai/Mistral-7B-Instruct-v0.2", paged=True),
                   # chunk lengths other than 256 (the reference's encode_function takes any, its
                   # tests/test_serde.py:87-107 uses 236): the counts model scaled to a sum of 256 + the fused kernel

@@ -28,6 +28,23 @@
 #pragma once
 #include "k_head.h"
 
+// lmc_tok_off for the decoder's scatter: a block size that is a power of two (every one vLLM offers) costs a shift and a
+// mask instead of a 32-bit division per lane and 64 tokens (wave-uniform branch).  Kept apart from lmc_tok_off: the same
+// lines there cost k_encode_fused ten more spilled SGPRs.
+__device__ __forceinline__ long long dec_tok_off(const KvAddr& a, int t) {
+  if (!a.slot_mapping) return (long long)t * a.stride_token;
+  const u32 s = (u32)a.slot_mapping[t], bs = (u32)a.block_size;
+  u32 b, w;
+  if ((bs & (bs - 1u)) == 0u) {
+    b = s >> (u32)__builtin_ctz(bs);
+    w = s & (bs - 1u);
+  } else {
+    b = s / bs;
+    w = s - b * bs;
+  }
+  return (long long)b * a.stride_block + (long long)w * a.stride_token;
+}
+
 struct DecodeArgs {
   const u8* blobs;
   long long blob_stride;
@@ -628,44 +645,90 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
     auto scale_f32 = [&](u32 sb) -> float {
       return SRC_BF16 ? __uint_as_float(sb << 16) : (float)__builtin_bit_cast(_Float16, (unsigned short)sb);
     };
-    // Round 6, bf16 -> bf16 contiguous rows of the counts model: blocks of EIGHT tokens.  The eight scales are one
-    // s_load_dwordx4 a block ahead (bf16 pairs: a scalar shift / mask makes each an fp32 SGPR operand of the multiply:
-    // no v_readlane), two tokens share one v_cvt_pk_bf16_f32 and leave as buffer_store_short + buffer_store_short_d16_hi,
-    // and the trip count, scale index and row offset cost three scalar instructions per eight tokens instead of per
-    // token.  Needs the first scale on a dword boundary (T even, or an even plane; an even trim); whatever is left --
-    // the last T % 8 tokens, every other combination -- takes the one-token loop below.
+    // Round 6, bf16 -> bf16 rows of the counts model: blocks of EIGHT tokens.  The eight scales are one s_load_dwordx4 a
+    // block ahead (bf16 pairs: a scalar shift / mask makes each an fp32 SGPR operand of the multiply: no v_readlane), two
+    // tokens share one v_cvt_pk_bf16_f32 and leave as buffer_store_short + buffer_store_short_d16_hi, and the trip count,
+    // scale index and row offset cost three scalar instructions per eight tokens instead of per token.  Needs the first
+    // scale on a dword boundary (T even, or an even plane; an even trim); whatever is left -- the last T % 8 tokens, every
+    // other combination -- takes the one-token loop below.
+    // PAGED: a vLLM slot mapping fills a block with consecutive tokens, so a block of eight tokens normally lands on eight
+    // rows one stride_token apart.  Before the first token the wave works out every token's row (four coalesced loads of
+    // slot_mapping in flight together, lane = token), checks each block of eight against its first row (ds_bpermute + one
+    // ballot per 64 tokens) and leaves block b's first row in lane b of two registers; if every block is such a run the
+    // stream decodes as contiguous rows do, with a descriptor at the block's row (two v_readlane per EIGHT tokens).  One
+    // block that is not (slots in any order, a first token in the middle of a group of eight of its block) sends the
+    // whole stream through the one-token loop.
     u32 tgen = nskip;
-    if constexpr (!SYMOUT && !PAGED && SRC_BF16 && DT_OUT == LMC_DTYPE_BF16 && decltype(model_tag)::value) {
+    if constexpr (!SYMOUT && SRC_BF16 && DT_OUT == LMC_DTYPE_BF16 && decltype(model_tag)::value) {
       typedef u32x4_t __attribute__((aligned(4))) u32x4_a4;
       const u64 sc_addr = uniform_ptr(scl) + 2ull * nskip;
       if ((sc_addr & 2ull) == 0ull && nskip + 8u <= T) {
         const u32 nblk = (u32)__builtin_amdgcn_readfirstlane((int)((T - nskip) >> 3));
-        const __attribute__((address_space(4))) u32x4_a4* sp = (const __attribute__((address_space(4))) u32x4_a4*)sc_addr;
-        u32x4_t cur = sp[0];
-        const u64 rbase = ubase + (u64)((long long)(tdst0 + (int)nskip) * row_step);
-        const u32x4_t desc = {(u32)rbase, (u32)(rbase >> 32) & 0xffffu, 0xfffffff0u, 0x00020000u};
-        auto pair = [&](u32 s2) {
-          float lva = 0.0f, lvb = 0.0f;
-          (void)decode_token(top_tag, model_tag, lva);
-          (void)decode_token(top_tag, model_tag, lvb);
-          const float va = lva * __uint_as_float(s2 << 16), vb = lvb * __uint_as_float(s2 & 0xffff0000u);
-          u32 w;
-          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(va), "v"(vb));
-          asm volatile("buffer_store_short %0, %1, %2, %3 offen nt\n\t"
-                       "buffer_store_short_d16_hi %0, %1, %2, %4 offen nt"
-                       :: "v"(w), "v"(voff), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
-          soff += 2u * (u32)row_step;
-        };
-        for (u32 b = 0; b < nblk; b++) {
-          u32x4_t nxt = cur;
-          if (b + 1u < nblk) nxt = sp[b + 1u];
-          pair(cur.x);
-          pair(cur.y);
-          pair(cur.z);
-          pair(cur.w);
-          cur = nxt;
+        bool all_runs = true;
+        u32 glo = 0, ghi = 0;  // PAGED: lane b = byte offset of block b's first row from the plane's base
+        if constexpr (PAGED) {
+          all_runs = row_step > 0 && row_step < (1ll << 28) && nblk <= 32u;
+          const int tfirst = tdst0 + (int)nskip;
+          u32 slot[4];  // (the low halves: lmc_tok_off reads a slot as 32 bits too)
+          const u32* const sm32 = (const u32*)(a.dst.slot_mapping + tfirst);
+#pragma unroll
+          for (u32 r = 0; r < 4u; r++)
+            slot[r] = (a.dst.slot_mapping && 64u * r + (u32)lane < 8u * nblk) ? sm32[2u * (64u * r + (u32)lane)] : 0u;
+          const u32 bs = (u32)a.dst.block_size;
+          const bool pow2 = (bs & (bs - 1u)) == 0u;  // (every block size vLLM offers: a shift and a mask, no division)
+          const u32 bsh = (u32)__builtin_ctz(bs | 0x80000000u);
+          const int first = (lane & ~7) << 2, mine = (lane & 7) << 5;
+#pragma unroll
+          for (u32 r = 0; r < 4u; r++) {
+            if (all_runs && 64u * r < 8u * nblk) {  // (a mapping that fails in its first 64 tokens costs one round)
+              const u32 sl = slot[r];
+              const u32 blk = pow2 ? sl >> bsh : sl / bs, w = sl - blk * bs;
+              const long long off = a.dst.slot_mapping ? ((long long)blk * a.dst.stride_block + (long long)w * a.dst.stride_token) * 2
+                                                       : (long long)(tfirst + (int)(64u * r) + lane) * row_step;
+              const u32 olo = (u32)(unsigned long long)off, ohi = (u32)((unsigned long long)off >> 32);
+              const u32 blo = (u32)__builtin_amdgcn_ds_bpermute(first, (int)olo), bhi = (u32)__builtin_amdgcn_ds_bpermute(first, (int)ohi);
+              const long long rel = off - (long long)(((u64)bhi << 32) | (u64)blo);
+              all_runs = all_runs && __ballot(64u * r + (u32)lane >= 8u * nblk || rel == (long long)(lane & 7) * row_step) == ~0ull;
+              const u32 tlo = (u32)__builtin_amdgcn_ds_bpermute(mine, (int)olo), thi = (u32)__builtin_amdgcn_ds_bpermute(mine, (int)ohi);
+              if ((u32)(lane >> 3) == r) { glo = tlo; ghi = thi; }
+            }
+          }
         }
-        tgen += 8u * nblk;
+        if (all_runs) {
+          const __attribute__((address_space(4))) u32x4_a4* sp = (const __attribute__((address_space(4))) u32x4_a4*)sc_addr;
+          u32x4_t cur = sp[0];
+          const u64 rbase = ubase + (PAGED ? 0ull : (u64)((long long)(tdst0 + (int)nskip) * row_step));
+          u32x4_t desc = {(u32)rbase, (u32)(rbase >> 32) & 0xffffu, 0xfffffff0u, 0x00020000u};
+          auto pair = [&](u32 s2) {
+            float lva = 0.0f, lvb = 0.0f;
+            (void)decode_token(top_tag, model_tag, lva);
+            (void)decode_token(top_tag, model_tag, lvb);
+            const float va = lva * __uint_as_float(s2 << 16), vb = lvb * __uint_as_float(s2 & 0xffff0000u);
+            u32 w;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(va), "v"(vb));
+            asm volatile("buffer_store_short %0, %1, %2, %3 offen nt\n\t"
+                         "buffer_store_short_d16_hi %0, %1, %2, %4 offen nt"
+                         :: "v"(w), "v"(voff), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
+            soff += 2u * (u32)row_step;
+          };
+          for (u32 b = 0; b < nblk; b++) {
+            u32x4_t nxt = cur;
+            if (b + 1u < nblk) nxt = sp[b + 1u];
+            if constexpr (PAGED) {
+              const u32 rlo = (u32)__builtin_amdgcn_readlane((int)glo, (int)b), rhi = (u32)__builtin_amdgcn_readlane((int)ghi, (int)b);
+              const u64 rb = ubase + (((u64)rhi << 32) | (u64)rlo);
+              desc.x = (u32)rb;
+              desc.y = (u32)(rb >> 32) & 0xffffu;
+              soff = 0;
+            }
+            pair(cur.x);
+            pair(cur.y);
+            pair(cur.z);
+            pair(cur.w);
+            cur = nxt;
+          }
+          tgen += 8u * nblk;
+        }
       }
     }
     u32 sc_next = scale_bits(tgen);
@@ -676,7 +739,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
       // PAGED: lane i works out the block row of token t0 + i once (slot_mapping load + division); every token
       // then takes its row with two v_readlane and the store goes through a descriptor based at that row
       long long tok_off2 = 0;
-      if (PAGED && !SYMOUT) tok_off2 = (t0 + (u32)lane < T) ? lmc_tok_off(a.dst, tdst0 + (int)(t0 + (u32)lane)) * 2 : 0ll;
+      if (PAGED && !SYMOUT) tok_off2 = (t0 + (u32)lane < T) ? dec_tok_off(a.dst, tdst0 + (int)(t0 + (u32)lane)) * 2 : 0ll;
       auto one_token = [&](u32 i) {
         float lv = 0.0f;
         const u32 sa = decode_token(top_tag, model_tag, lv);

@@ -746,20 +746,40 @@ def test_paged_store_and_scatter_retrieve_of_independent_segments(layout, backen
         engine.close()
 
 
+def _slot_mapping(style, n, nblocks, bs, g):
+    """Slots of n tokens in a cache of nblocks blocks.  "token": every token at a random slot of its own.  "vllm": what a
+    block manager hands out -- blocks anywhere, a block's tokens in order, the first block entered at a random offset
+    (a prefix that continues a partly filled block).  "mixed": the vllm mapping with a few tokens swapped, so that runs
+    of eight break in odd places."""
+    if style == "token":
+        return torch.randperm(nblocks * bs, generator=g)[:n]
+    start = int(torch.randint(0, bs, (1,), generator=g))
+    need = (start + n + bs - 1) // bs
+    blocks = torch.randperm(nblocks, generator=g)[:need]
+    pos = torch.arange(start, start + n)
+    slots = blocks[pos // bs] * bs + pos % bs
+    if style == "mixed" and n >= 2:
+        for _ in range(max(1, n // 37)):
+            i, j = (int(x) for x in torch.randint(0, n, (2,), generator=g))
+            slots[[i, j]] = slots[[j, i]]
+    return slots
+
+
 def test_random_paged_caches_through_the_engine_equal_the_dense_path(oracle):
     """A seeded sweep over the paged entry points (LMC_FUZZ_CASES, default 8): block size, block layout, chunk size,
     segment length, heads -- store_paged from random slots of one cache, retrieve_into_paged into random slots of another,
     and what lands there equals the dense retrieve() and, chunk by chunk, the oracle."""
     import os
     rnd = np.random.default_rng(int(os.environ.get("LMC_FUZZ_SEED", "31")))
-    for case in range(int(os.environ.get("LMC_FUZZ_CASES", "8"))):
+    for case in range(int(os.environ.get("LMC_FUZZ_CASES", "12"))):
         layout = ["NHBD", "NBHD"][int(rnd.integers(0, 2))]
-        bs = int(rnd.choice([8, 16, 32, 12, 48]))  # (a block size that is no power of two decodes through the one-token loop)
+        bs = int(rnd.choice([8, 16, 32, 12, 48]))
+        style = ["token", "vllm", "mixed"][case % 3]  # (runs of eight tokens on consecutive rows decode in blocks: k_decode.h)
         cs = int(rnd.choice([256, 128, 100, 236]))
         nl, H, D = int(rnd.integers(1, 5)), int(rnd.choice([1, 2, 8])), int(rnd.choice([64, 128]))
         seg = int(rnd.integers(1, 3 * cs + 20))
         backend = ["cachegen-host", "cachegen-hbm"][int(rnd.integers(0, 2))]
-        tag = f"case {case}: {layout} bs{bs} cs{cs} L{nl} H{H} D{D} T{seg} {backend}"
+        tag = f"case {case}: {layout} bs{bs} cs{cs} L{nl} H{H} D{D} T{seg} {backend} slots:{style}"
         engine = LMCacheEngine(make_cfg(backend, cs), dumb_metadata("vllm", MODEL))
         try:
             g = torch.Generator().manual_seed(100 + case)
@@ -767,8 +787,8 @@ def test_random_paged_caches_through_the_engine_equal_the_dense_path(oracle):
             shape = (2, nblocks, bs, H, D) if layout == "NBHD" else (2, nblocks, H, bs, D)
             src = [torch.zeros(shape, dtype=torch.bfloat16, device="cuda") for _ in range(nl)]
             dst = [torch.zeros(shape, dtype=torch.bfloat16, device="cuda") for _ in range(nl)]
-            slots_src = torch.randperm(nblocks * bs, generator=g)[:seg].to("cuda")
-            slots_dst = torch.randperm(nblocks * bs, generator=g)[:seg].to("cuda")
+            slots_src = _slot_mapping(style, seg, nblocks, bs, g).to("cuda")
+            slots_dst = _slot_mapping(style, seg, nblocks, bs, g).to("cuda")
             toks = generate_tokens(seg, "cuda")
             kv = generate_kv_cache(seg, "vllm", "cuda", num_layers=nl, num_heads=H, head_size=D)
             _paged_scatter(src, kv, slots_src, bs, layout)

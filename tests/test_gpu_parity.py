@@ -256,6 +256,43 @@ def test_paged_gather_encode_and_scatter_decode(nat, ctx, oracle, layout):
         assert (flat[:, ~touched] == 0).all()  # nothing written outside slot_mapping
 
 
+@pytest.mark.parametrize("layout", ["NBHD", "NHBD"])
+@pytest.mark.parametrize("bs,start,skip,swaps", [(16, 0, 0, 0), (16, 5, 0, 0), (8, 3, 6, 0), (12, 7, 0, 0), (32, 9, 3, 0),
+                                                 (16, 2, 8, 5), (4, 1, 0, 0)])
+def test_scatter_decode_into_block_ordered_slots(nat, ctx, oracle, layout, bs, start, skip, swaps):
+    """The slot mapping a vLLM block manager produces: blocks anywhere, a block's tokens in order, the first block entered
+    at `start`.  Runs of eight tokens on consecutive rows of one block take the decoder's block path (k_decode.h), a run
+    that crosses a block boundary, swapped tokens, the trimmed first tokens (`skip`) and the last T % 8 tokens the
+    one-token path -- whichever path a token takes, what lands in its slot is the oracle's value and nothing else is
+    written.  Two chunks of 256 / 203 tokens (counts model)."""
+    L, H, D, cs, T = 2, 2, 64, 256, 459
+    g = torch.Generator().manual_seed(1000 + 17 * bs + start + skip)
+    kv = torch.randn((L, 2, T, H, D), generator=g).to(torch.bfloat16)
+    bins = default_bins(L)
+    blobs, blob_dev, stride = encode(nat, ctx, nat.KVLayout.from_chunk(kv.to(DEV), "vllm"), 0, T, cs, bins)
+    n = T - skip
+    nb = (start + n + bs - 1) // bs + 4
+    blocks = torch.randperm(nb, generator=g)
+    pos = torch.arange(start, start + n)
+    slots = blocks[pos // bs] * bs + pos % bs
+    for _ in range(swaps):
+        i, j = (int(x) for x in torch.randint(0, n, (2,), generator=g))
+        slots[[i, j]] = slots[[j, i]]
+    shape = (2, nb, bs, H, D) if layout == "NBHD" else (2, nb, H, bs, D)
+    caches = [torch.zeros(shape, dtype=torch.bfloat16, device=DEV) for _ in range(L)]
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, len(blobs), nat.KVLayout.paged(caches, slots, bs, layout), -skip, cs)
+    torch.cuda.synchronize()
+    ctx.raise_on_status("decode")
+    want = np.concatenate([oracle.decode_blob(b, oracle.BF16).reshape(L, 2, -1, H, D) for b in blobs], axis=2)[:, :, skip:]
+    touched = torch.zeros(nb * bs, dtype=torch.bool)
+    touched[slots] = True
+    for l in range(L):
+        c = caches[l].cpu()
+        flat = c.reshape(2, nb * bs, H, D) if layout == "NBHD" else c.permute(0, 1, 3, 2, 4).reshape(2, nb * bs, H, D)
+        assert np.array_equal(bits_np(flat[:, slots]), want[l])
+        assert (flat[:, ~touched] == 0).all()
+
+
 @pytest.mark.parametrize("case", ["T2048", "T768_fp16", "tiny_values"])
 def test_long_chunks_and_denormal_scales(nat, ctx, oracle, case):
     """Chunks longer than the decoder's 512-token scale window and 512-word ring (many refills);
