@@ -55,7 +55,7 @@ struct Lib {
   decltype(&lmc_decode_chunks) decode;
   decltype(&lmc_ctx_set_encode_path) set_path;
   lmc_ctx* ctx;
-  std::vector<double> enc, dec, pdec, bdec;
+  std::vector<double> enc, dec, pdec, bdec, benc, penc;
 };
 
 static int plane_bins(int p, int L) { const int kv = p >= L, l = p - kv * L; return !kv ? (l < 10 ? 32 : 16) : (l < 2 ? 32 : 16); }
@@ -189,15 +189,30 @@ int main(int argc, char** argv) {
       CK(hipStreamSynchronize(s));
       CK(hipEventElapsedTime(&ms, e0, e1));
       l.bdec.push_back(ms / reps);
+      // the encode with the paged cache as its SOURCE (store_paged: the gather is part of phase A), both mappings
+      for (int which = 0; which < 2; which++) {
+        lmc_kv_layout src = which ? pl : bl;
+        src.base = kv;
+        for (int w = 0; w < 2; w++) LK(l.encode(l.ctx, &src, 0, ctx_tok, chunk, bins.data(), blob, stride, sizes, status, s));
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < reps; i++) LK(l.encode(l.ctx, &src, 0, ctx_tok, chunk, bins.data(), blob, stride, sizes, status, s));
+        CK(hipEventRecord(e1, s));
+        CK(hipStreamSynchronize(s));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        (which ? l.penc : l.benc).push_back(ms / reps);
+      }
+      LK(l.encode(l.ctx, &lay, 0, ctx_tok, chunk, bins.data(), blob, stride, sizes, status, s));  // the blobs the decode legs read
     }
   }
-  printf("%-8s %10s %10s %10s %10s %10s %10s %10s %10s   (ms per 16 k context, %d rounds x %d jobs; pdec = decode + scatter into a paged cache, every token at a slot of its own; bdec = the same with vLLM's mapping: blocks anywhere, a block's tokens in order)\n", "library", "enc min", "enc med", "dec min", "dec med", "pdec min", "pdec med", "bdec min", "bdec med", rounds, reps);
+  printf("%-8s %9s %9s %9s %9s %9s %9s %9s %9s %9s %9s %9s %9s  (ms per 16 k context, %d rounds x %d jobs; pdec = decode + scatter into a paged cache, every token at a slot of its own; bdec = the same with vLLM's mapping: blocks anywhere, a block's tokens in order; benc / penc = encode reading the paged cache through those two mappings)\n", "library", "enc min", "enc med", "dec min", "dec med", "pdec min", "pdec med", "bdec min", "bdec med", "benc min", "benc med", "penc min", "penc med", rounds, reps);
   for (Lib& l : libs) {
-    std::sort(l.enc.begin(), l.enc.end());
-    std::sort(l.dec.begin(), l.dec.end());
-    std::sort(l.pdec.begin(), l.pdec.end());
-    std::sort(l.bdec.begin(), l.bdec.end());
-    printf("%-8s %10.4f %10.4f %10.4f %10.4f %10.4f %10.4f %10.4f %10.4f\n", l.name.c_str(), l.enc[0], l.enc[l.enc.size() / 2], l.dec[0], l.dec[l.dec.size() / 2], l.pdec[0], l.pdec[l.pdec.size() / 2], l.bdec[0], l.bdec[l.bdec.size() / 2]);
+    std::vector<double>* v[6] = {&l.enc, &l.dec, &l.pdec, &l.bdec, &l.benc, &l.penc};
+    printf("%-8s", l.name.c_str());
+    for (auto* x : v) {
+      std::sort(x->begin(), x->end());
+      printf(" %9.4f %9.4f", (*x)[0], (*x)[x->size() / 2]);
+    }
+    printf("\n");
   }
   return 0;
 }
