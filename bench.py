@@ -508,6 +508,11 @@ def shape_rate(native, ctx, dev, name, nl, nh, hd, dtype, ntok, model, paged=Fal
     if tdec_token is not None:
         row["slot_mapping"] = "blocks at random, a block's 16 tokens in order (vLLM)"
         row["decode_ms_every_token_at_a_random_slot"] = round(tdec_token, 3)
+        # ... and the store side of the connector: the fused encode reading the paged cache itself (slot_mapping gather in
+        # phase A; the cache holds what the decode above scattered into it)
+        time_encode(ctx, ol, ntok, cs, bins, blobs, stride, sizes, st.cuda_stream, st, 10)
+        row["encode_ms_from_the_paged_cache"] = round(time_encode(ctx, ol, ntok, cs, bins, blobs, stride, sizes, st.cuda_stream, st, 20), 3)
+        ctx.raise_on_status(name)
     if roundtrip and not paged:
         # size-independent property at full size: decode(encode(x)) reproduces x within the quantisation bound,
         # |x^ - x| <= max1 / (2 M) + 1 ulp16(max1), per token row and plane -- checked on every plane

@@ -66,7 +66,13 @@ int lmc_abi_version(void);
  *   tok_off(t) = slot_mapping ? (s / block_size)*stride_block + (s % block_size)*stride_token,
  *                               s = slot_mapping[t]
  *                             : t*stride_token
- * d is contiguous; head_size must be a multiple of 8 (16-byte vectors).
+ * d is contiguous.  A plane has a multiple of 8 channels (num_heads * head_size % 8 == 0).  Layouts the ENCODERS read
+ * (lmc_quantize, lmc_encode_chunks, lmc_store_*) are read with 16-byte vectors of 8 channels: base 16-byte aligned,
+ * stride_layer / stride_kv / stride_token / stride_block multiples of 8 elements, and either head_size % 8 == 0 with
+ * stride_head % 8 == 0, or stride_head == head_size (the heads of a token row back to back -- the vllm chunk, the
+ * per-layer [T,H,D] tensors, NBHD blocks -- where any head_size will do).  The DECODERS' destination and both sides of
+ * lmc_copy_kv take any strides and any head_size (lmc_copy_kv copies element-wise when a side is not vector-readable:
+ * the way to bring such a range into a chunk the encoders take; lmcache_amd's codec does that by itself).
  */
 typedef struct lmc_kv_layout {
   int32_t dtype;      /* LMC_DTYPE_BF16 / LMC_DTYPE_FP16 */
@@ -115,7 +121,7 @@ int lmc_ctx_reserve(lmc_ctx* ctx, int L, int H, int D, int chunk_tokens, int max
 int lmc_device_status(lmc_ctx* ctx, int clear);
 
 /* Geometry limits of this build: 2L <= LMC_MAX_PLANES planes, C = H*D <= LMC_MAX_CHANNELS channels per
- * plane (4096 = a 32-head x 128 MHA model; every BASELINE.json config fits), head_size a multiple of 8,
+ * plane (4096 = a 32-head x 128 MHA model; every BASELINE.json config fits), C a multiple of 8,
  * chunks of 1 .. 65535 tokens.  Outside them the entry points return LMC_ERR_INVALID. */
 #define LMC_MAX_PLANES 256
 #define LMC_MAX_CHANNELS 4096

@@ -13,7 +13,7 @@ struct CopyArgs {
   KvAddr src, dst;
   int tok_begin, ntok, dst_tok0;
   int P, C;
-  long long nvec;  // P * ntok * C/8
+  long long nvec;  // P * ntok * C/8 (k_copy_kv) or P * ntok * C (k_copy_kv_elem)
 };
 
 __global__ __launch_bounds__(256) void k_copy_kv(CopyArgs a) {
@@ -29,5 +29,23 @@ __global__ __launch_bounds__(256) void k_copy_kv(CopyArgs a) {
     u16* dp = const_cast<u16*>(lmc_plane_base(a.dst, p)) + lmc_tok_off(a.dst, a.dst_tok0 + t) +
               (long long)hs * a.dst.stride_head + ds;
     st_global_u4(dp, ld_global_u4(sp));
+  }
+}
+
+// The same copy one ELEMENT per thread: layouts whose rows are not on 16-byte boundaries, or whose head_size is no
+// multiple of 8 while the heads of a token row are apart (the reference's serde takes any shape:
+// cachegen_encoder.py:40-61, 76-91).  Not a fast path: the Python side uses it to bring such a range into a contiguous
+// chunk the encoders can read.
+__global__ __launch_bounds__(256) void k_copy_kv_elem(CopyArgs a) {
+  for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < a.nvec; id += (long long)gridDim.x * 256) {
+    const int ch = (int)(id % a.C);
+    const long long r = id / a.C;
+    const int t = (int)(r % a.ntok);
+    const int p = (int)(r / a.ntok);
+    const int hs = ch / a.src.D, ds = ch - hs * a.src.D;
+    const u16* sp = lmc_plane_base(a.src, p) + lmc_tok_off(a.src, a.tok_begin + t) + (long long)hs * a.src.stride_head + ds;
+    u16* dp = const_cast<u16*>(lmc_plane_base(a.dst, p)) + lmc_tok_off(a.dst, a.dst_tok0 + t) +
+              (long long)hs * a.dst.stride_head + ds;
+    *dp = *sp;
   }
 }

@@ -186,16 +186,27 @@ int lmc_device_status(lmc_ctx* c, int clear) {
 }  // extern "C"
 
 // ---------------------------------------------------------------------------
-static bool layout_ok(const lmc_kv_layout* l) {
+// `vec`: the layout is READ or WRITTEN with 16-byte vectors of 8 channels (the encoders, k_copy_kv): rows on 16-byte
+// boundaries, and a vector must not leave its head -- head_size a multiple of 8, or the heads of a token row back to back
+// (stride_head == head_size: the vllm chunk, the per-layer [T,H,D] tensors, NBHD paged blocks), where a vector that
+// crosses a head boundary is still 8 consecutive elements.  !vec: element-wise access (the decoder's scatter, the
+// element-wise copy): any strides.  Either way a plane has a multiple of 8 channels (the blob's geometry).
+static bool layout_ok(const lmc_kv_layout* l, bool vec = true) {
   if (!l) return false;
   if (l->dtype != LMC_DTYPE_BF16 && l->dtype != LMC_DTYPE_FP16) return false;
   if (l->num_layers < 1 || 2 * l->num_layers > LMC_MAX_PLANES) return false;
-  if (l->num_heads < 1 || l->head_size < 8 || (l->head_size & 7)) return false;
+  if (l->num_heads < 1 || l->head_size < 1) return false;
+  const long long C = (long long)l->num_heads * l->head_size;
+  if (C < 8 || (C & 7) || C > LMC_MAX_CHANNELS) return false;
   if (!l->base && !l->plane_ptrs) return false;
-  // 16-byte vectors: every stride a multiple of 8 elements, base 16-byte aligned
-  if ((l->stride_token & 7) || (l->stride_head & 7)) return false;
+  if (l->slot_mapping && l->block_size < 1) return false;
+  if (!vec) return true;
+  if (l->head_size & 7) {
+    if (l->stride_head != l->head_size) return false;
+  } else if (l->stride_head & 7) return false;
+  if (l->stride_token & 7) return false;
   if (!l->plane_ptrs && ((l->stride_layer & 7) || (l->stride_kv & 7) || ((uintptr_t)l->base & 15))) return false;
-  if (l->slot_mapping && (l->block_size < 1 || (l->stride_block & 7))) return false;
+  if (l->slot_mapping && (l->stride_block & 7)) return false;
   return true;
 }
 
@@ -303,7 +314,7 @@ static int reserve_locked(lmc_ctx::Workspace* c, int L, int H, int D, int chunk_
 extern "C" {
 
 int lmc_ctx_reserve(lmc_ctx* c, int L, int H, int D, int chunk_tokens, int max_chunks) {
-  if (!c || L < 1 || H < 1 || D < 8 || chunk_tokens < 1 || max_chunks < 1) return LMC_ERR_INVALID;
+  if (!c || L < 1 || H < 1 || D < 1 || (H * (long long)D) % 8 || chunk_tokens < 1 || max_chunks < 1) return LMC_ERR_INVALID;
   HIP_TRY(hipSetDevice(c->device));
   std::lock_guard<std::mutex> lk(c->mu);
   return reserve_locked(&c->ws[0], L, H, D, chunk_tokens, max_chunks, max_chunks);
@@ -577,7 +588,7 @@ static int decode_launch(lmc_ctx* c, DecodeArgs& a, const lmc_kv_layout* dst, hi
 
 int lmc_decode_chunks(lmc_ctx* c, const void* blobs, uint64_t blob_stride, int32_t nchunks, const lmc_kv_layout* dst,
                       int32_t dst_tok0, int32_t chunk_tokens, uint32_t* job_status, lmc_stream_t stream) {
-  if (!layout_ok(dst) || chunk_tokens < 1) return LMC_ERR_INVALID;
+  if (!layout_ok(dst, false) || chunk_tokens < 1) return LMC_ERR_INVALID;
   DecodeArgs a;
   memset(&a, 0, sizeof a);
   int rc = decode_common(c, blobs, blob_stride, nchunks, dst->num_layers, dst->num_heads, dst->head_size, job_status, a);
@@ -590,7 +601,7 @@ int lmc_decode_chunks(lmc_ctx* c, const void* blobs, uint64_t blob_stride, int32
 int lmc_decode_chunks_layers(lmc_ctx* c, const void* const* blob_ptrs, uint64_t max_blob_bytes, int32_t nchunks,
                              const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, int32_t layer_begin,
                              int32_t layer_count, uint32_t* job_status, lmc_stream_t stream) {
-  if (!layout_ok(dst) || chunk_tokens < 1 || !blob_ptrs || layer_begin < 0 || layer_count < 1 ||
+  if (!layout_ok(dst, false) || chunk_tokens < 1 || !blob_ptrs || layer_begin < 0 || layer_count < 1 ||
       layer_begin + layer_count > dst->num_layers)
     return LMC_ERR_INVALID;
   DecodeArgs a;
@@ -610,7 +621,7 @@ int lmc_decode_chunks_schedule(lmc_ctx* c, const void* const* blob_ptrs, uint64_
                                const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, int32_t nranges,
                                const int32_t* layer_ends_h, const lmc_event_t* events_h, uint32_t* job_status,
                                lmc_stream_t stream) {
-  if (!layout_ok(dst) || chunk_tokens < 1 || !blob_ptrs || nranges < 1 || !layer_ends_h) return LMC_ERR_INVALID;
+  if (!layout_ok(dst, false) || chunk_tokens < 1 || !blob_ptrs || nranges < 1 || !layer_ends_h) return LMC_ERR_INVALID;
   for (int i = 0, prev = 0; i < nranges; prev = layer_ends_h[i], i++)  // the whole schedule is checked before anything is launched
     if (layer_ends_h[i] <= prev || layer_ends_h[i] > dst->num_layers) return LMC_ERR_INVALID;
   if (layer_ends_h[nranges - 1] != dst->num_layers) return LMC_ERR_INVALID;
@@ -633,7 +644,7 @@ int lmc_decode_chunks_schedule(lmc_ctx* c, const void* const* blob_ptrs, uint64_
 
 int lmc_decode_symbols(lmc_ctx* c, const void* blob, int32_t L, int32_t H, int32_t D, int8_t* sym_out,
                        lmc_stream_t stream) {
-  if (!sym_out || L < 1 || H < 1 || D < 8) return LMC_ERR_INVALID;
+  if (!sym_out || L < 1 || H < 1 || D < 1 || (H * (long long)D) % 8) return LMC_ERR_INVALID;
   DecodeArgs a;
   memset(&a, 0, sizeof a);
   int rc = decode_common(c, blob, 0, 1, L, H, D, nullptr, a);
@@ -648,20 +659,22 @@ int lmc_decode_symbols(lmc_ctx* c, const void* blob, int32_t L, int32_t H, int32
 
 int lmc_copy_kv(lmc_ctx* c, const lmc_kv_layout* src, int32_t tok_begin, int32_t ntok, const lmc_kv_layout* dst,
                 int32_t dst_tok0, lmc_stream_t stream) {
-  if (!c || !layout_ok(src) || !layout_ok(dst) || ntok < 1 || tok_begin < 0 || dst_tok0 < 0) return LMC_ERR_INVALID;
+  if (!c || !layout_ok(src, false) || !layout_ok(dst, false) || ntok < 1 || tok_begin < 0 || dst_tok0 < 0) return LMC_ERR_INVALID;
   if (src->num_layers != dst->num_layers || src->num_heads != dst->num_heads || src->head_size != dst->head_size ||
       src->dtype != dst->dtype)
     return LMC_ERR_INVALID;
+  const bool vec = layout_ok(src) && layout_ok(dst);  // else one element per thread (any strides, any head_size)
   CopyArgs a;
   memset(&a, 0, sizeof a);
   a.src = to_addr(src); a.dst = to_addr(dst);
   a.tok_begin = tok_begin; a.ntok = ntok; a.dst_tok0 = dst_tok0;
   a.P = 2 * src->num_layers; a.C = src->num_heads * src->head_size;
-  a.nvec = (long long)a.P * ntok * (a.C / 8);
+  a.nvec = (long long)a.P * ntok * (vec ? a.C / 8 : a.C);
   HIP_TRY(hipSetDevice(c->device));
   long long blocks = (a.nvec + 255) / 256;
   if (blocks > 256LL * 64) blocks = 256LL * 64;  // grid-stride beyond 64 blocks per CU
-  hipLaunchKernelGGL(k_copy_kv, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (vec) hipLaunchKernelGGL(k_copy_kv, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_copy_kv_elem, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return LMC_OK;
 }
@@ -797,7 +810,7 @@ static bool host_blob_ok(const u8* b, uint32_t size, int L, int H, int D, uint32
 int lmc_load_chunks(lmc_ctx* c, const void* const* host_blob_ptrs_h, const uint32_t* sizes_h, int32_t nchunks,
                     const lmc_kv_layout* dst, int32_t dst_tok0, int32_t chunk_tokens, int32_t layers_per_range,
                     lmc_event_t* range_events, uint32_t* job_status, lmc_stream_t stream) {
-  if (!c || !host_blob_ptrs_h || !sizes_h || nchunks < 1 || !layout_ok(dst) || chunk_tokens < 1 || layers_per_range < 0)
+  if (!c || !host_blob_ptrs_h || !sizes_h || nchunks < 1 || !layout_ok(dst, false) || chunk_tokens < 1 || layers_per_range < 0)
     return LMC_ERR_INVALID;
   const int L = dst->num_layers, H = dst->num_heads, D = dst->head_size;
   if (H * D > LMC_MAX_CHANNELS) return LMC_ERR_INVALID;
@@ -1035,7 +1048,7 @@ int lmc_load_pack(lmc_ctx* c, const void* pack_h, uint64_t pack_bytes, int32_t c
                   const lmc_kv_layout* dst, int32_t dst_tok0, int32_t layers_per_range, lmc_event_t* range_events,
                   uint32_t* job_status, lmc_stream_t stream) {
   lmc_pack_header h;
-  if (!c || !layout_ok(dst) || layers_per_range < 0 || nchunks < 0 || chunk_begin < 0 ||
+  if (!c || !layout_ok(dst, false) || layers_per_range < 0 || nchunks < 0 || chunk_begin < 0 ||
       !pack_ok((const u8*)pack_h, pack_bytes, &h))
     return LMC_ERR_INVALID;
   const int L = dst->num_layers, H = dst->num_heads, D = dst->head_size;

@@ -340,11 +340,27 @@ class KVLayout:
     def dtype(self):
         return self.struct.dtype
 
+    def vector_readable(self) -> bool:
+        """Whether the encoders can read this layout with their 16-byte vectors of 8 channels (the rule of layout_ok in
+        lmc_api.hip / include/lmc_hip.h): rows on 16-byte boundaries, strides multiples of 8 elements, and head_size a
+        multiple of 8 unless the heads of a token row lie back to back.  The decoders and lmc_copy_kv take any layout."""
+        s = self.struct
+        if s.head_size % 8:
+            if s.stride_head != s.head_size:
+                return False
+        elif s.stride_head % 8:
+            return False
+        if s.stride_token % 8 or (s.slot_mapping and s.stride_block % 8):
+            return False
+        if s.plane_ptrs:
+            return all(x.data_ptr() % 16 == 0 for x in self._keep if isinstance(x, torch.Tensor) and x.dtype in (torch.bfloat16, torch.float16))
+        return s.stride_layer % 8 == 0 and s.stride_kv % 8 == 0 and (s.base or 0) % 16 == 0
+
     @staticmethod
     def from_chunk(t: torch.Tensor, fmt: str) -> "KVLayout":
         """A chunk blob: [L,2,T,H,D] for "vllm", [L,2,H,T,D] for "huggingface"
         (cache_engine.py:137-140).  Any strides are fine (permuted views included) as long as
-        the head dimension is contiguous and strides are multiples of 8 elements."""
+        the head dimension is contiguous; what the ENCODERS read must also be vector_readable()."""
         assert t.is_cuda and t.dim() == 5 and t.shape[1] == 2, f"bad chunk shape {tuple(t.shape)}"
         s = KvLayoutStruct()
         st = t.stride()

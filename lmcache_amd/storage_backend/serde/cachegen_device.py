@@ -285,10 +285,24 @@ class CacheGenDeviceCodec:
         self._table_cache: dict = {}                         # blob-address tuple -> (device table, largest blob, upload stream)
 
     # ---- encode ------------------------------------------------------------------
+    def _readable(self, src: native.KVLayout, tok_begin: int, tok_end: int):
+        """The encoders read 16-byte vectors (native.KVLayout.vector_readable).  The reference's serde takes any shape
+        (torch_quant_vectorized, cachegen_encoder.py:40-61), so a range of a layout that is not -- a head_size that is no
+        multiple of 8 under a huggingface / NHBD layout, rows off a 16-byte boundary -- is first brought into a
+        contiguous vllm chunk on the device (lmc_copy_kv copies element-wise then) and encoded from there."""
+        if src.vector_readable():
+            return src, tok_begin, tok_end
+        n = tok_end - tok_begin
+        with torch.cuda.device(self.device):
+            chunk = torch.empty((src.L, 2, n, src.H, src.D), dtype=native.torch_dtype(src.dtype), device=src.device)
+            self.ctx.copy_kv(src, tok_begin, n, native.KVLayout.from_chunk(chunk, "vllm"), 0)
+        return native.KVLayout.from_chunk(chunk, "vllm"), 0, n
+
     def encode(self, src: native.KVLayout, tok_begin: int, tok_end: int, chunk_tokens: int,
                bins: Sequence[int]) -> EncodeJob:
         """Launch the fused encode of every chunk of [tok_begin, tok_end) on the CURRENT stream
         (so it is ordered after whatever produced the KV).  Asynchronous."""
+        src, tok_begin, tok_end = self._readable(src, tok_begin, tok_end)
         L, H, D = src.L, src.H, src.D
         n = (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
         stride = native.r16(native.blob_bound(L, chunk_tokens, H, D))
@@ -545,6 +559,7 @@ class CacheGenDeviceCodec:
         dma=False: the region IS the pinned arena and the copy kernel's stores cross PCIe themselves: one call, no host
         wait at all, but kernels that run beside 11 ms of shader stores to host memory were measured 4.3x slower
         (bench.py store_hidden), so this is for callers with an otherwise idle GPU."""
+        src, tok_begin, tok_end = self._readable(src, tok_begin, tok_end)
         L, H, D = src.L, src.H, src.D
         n = (tok_end - tok_begin + chunk_tokens - 1) // chunk_tokens
         with self._lock, torch.cuda.device(self.device):

@@ -283,6 +283,34 @@ def test_same_retrieve_store_cachegen_equals_oracle(fmt, backend, oracle):
 
 
 @pytest.mark.parametrize("fmt", ["vllm", "huggingface"])
+@pytest.mark.parametrize("backend", ["cachegen-host", "cachegen-hbm", "cuda"])
+def test_head_size_100_through_the_engine(fmt, backend, oracle):
+    """A head_size that is no multiple of 8 (the reference's serde and engine take any shape).  vllm tensors are read
+    as they are (heads back to back in a token row); huggingface tensors [H,T,D] have no 16-byte rows then: the codec
+    brings the range into a vllm chunk first, the raw tiers copy element-wise.  Results as for any other shape."""
+    num_tokens, cs, nl, H, D = 300, 128, 2, 2, 100
+    tokens = generate_tokens(num_tokens, "cuda")
+    kv_cache = generate_kv_cache(num_tokens, fmt, "cuda", num_layers=nl, num_heads=H, head_size=D)
+    engine = LMCacheEngine(make_cfg(backend, cs), dumb_metadata(fmt, MODEL))
+    try:
+        engine.store(tokens, kv_cache)
+        retrieved_cache, ret_mask = engine.retrieve(tokens)
+        assert int(torch.sum(ret_mask)) == num_tokens
+        if backend == "cuda":  # lossless tier
+            check_kv_cache_equal(retrieved_cache, kv_cache, num_tokens, fmt)
+            return
+        out_dt = torch.bfloat16 if fmt == "vllm" else torch.float16
+        for t0 in range(0, num_tokens, cs):
+            t1 = min(num_tokens, t0 + cs)
+            sl = (slice(t0, t1),) if fmt == "vllm" else (slice(None), slice(t0, t1))
+            want = oracle_roundtrip(oracle, tuple((k[sl], v[sl]) for k, v in kv_cache), fmt, MODEL, out_dt)
+            got = to_blob(tuple((k[sl], v[sl]) for k, v in retrieved_cache)).cpu()
+            assert torch.equal(got, want), f"chunk at {t0}"
+    finally:
+        engine.close()
+
+
+@pytest.mark.parametrize("fmt", ["vllm", "huggingface"])
 @pytest.mark.parametrize("chunk_size", [128, 256])
 @pytest.mark.parametrize("backend", ["cuda", "cpu", "cachegen-host"])
 def test_retrieve_prefix(fmt, chunk_size, backend):

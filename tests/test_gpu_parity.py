@@ -210,6 +210,50 @@ def test_huggingface_layout_and_skip(nat, ctx, oracle):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("H,D,T", [(2, 100, 70), (4, 30, 256), (2, 36, 33), (8, 12, 129)])
+def test_head_sizes_that_are_no_multiple_of_eight(nat, ctx, oracle, H, D, T):
+    """The reference's serde takes any [.., H, D] (torch_quant_vectorized works on the merged channels,
+    cachegen_encoder.py:40-61, 76-91).  Here a plane needs a multiple of 8 channels; the encoders read any head_size where
+    the heads of a token row lie back to back (vllm chunk), the decoder and lmc_copy_kv write any layout, and the codec
+    brings a huggingface chunk of such a head_size into a vllm chunk first (element-wise lmc_copy_kv)."""
+    from lmcache_amd.storage_backend.serde.cachegen_device import get_codec
+    L = 2
+    kv = make_kv(L, T, H, D, torch.bfloat16, "randn", seed=40 + D)  # vllm order
+    bins = default_bins(L)
+    b, code = oracle.torch_to_bits(kv.reshape(L, 2, T, H * D))
+    ref = oracle.encode_blob(b, code, H, D, np.array(bins, np.int32))
+    vl = nat.KVLayout.from_chunk(kv.to(DEV), "vllm")
+    assert vl.vector_readable()
+    blobs, blob_dev, stride = encode(nat, ctx, vl, 0, T, T, bins)
+    assert blobs[0] == ref
+    want = oracle.decode_blob(ref, oracle.BF16).reshape(L, 2, T, H, D)
+    # decode into a huggingface chunk (heads T * D apart: no 16-byte rows) and into a vllm chunk
+    out_hf = torch.zeros(L, 2, H, T, D, dtype=torch.bfloat16, device=DEV)
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out_hf, "huggingface"), 0, T)
+    out_v = torch.zeros(L, 2, T, H, D, dtype=torch.bfloat16, device=DEV)
+    ctx.decode_chunks(blob_dev.data_ptr(), stride, 1, nat.KVLayout.from_chunk(out_v, "vllm"), 0, T)
+    torch.cuda.synchronize()
+    ctx.raise_on_status("decode")
+    assert np.array_equal(bits_np(out_hf.permute(0, 1, 3, 2, 4)), want)
+    assert np.array_equal(bits_np(out_v), want)
+    # a huggingface chunk as the encoder's input: not vector-readable -> the C ABI refuses it, lmc_copy_kv moves it
+    # element-wise, and the codec does that by itself
+    hf = kv.permute(0, 1, 3, 2, 4).contiguous().to(DEV)
+    hl = nat.KVLayout.from_chunk(hf, "huggingface")
+    assert not hl.vector_readable()
+    with pytest.raises(nat.NativeError):
+        encode(nat, ctx, hl, 0, T, T, bins)
+    back = torch.zeros(L, 2, T, H, D, dtype=torch.bfloat16, device=DEV)
+    ctx.copy_kv(hl, 0, T, nat.KVLayout.from_chunk(back, "vllm"), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), kv)
+    codec = get_codec(torch.cuda.current_device())
+    job = codec.encode(hl, 0, T, T, bins)
+    sizes = codec.sizes_of(job)
+    got = job.arena[:sizes[0]].cpu().numpy().tobytes()
+    assert got == ref
+
+
 @pytest.mark.parametrize("layout", ["NBHD", "NHBD"])
 def test_paged_gather_encode_and_scatter_decode(nat, ctx, oracle, layout):
     """vLLM paged blocks through slot_mapping (LLM_Engine.rst:91-122), incl. BASELINE's
