@@ -315,9 +315,11 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
   // cnt lanes renormalise takes words [e - cnt, e), ascending with the lane (the encoder's append order).  The
   // words are staged in STREAM ORDER in a 256-word LDS ring, word j at slot j % 256, in blocks of 128 words
   // (block b = words [128 b, 128 b + 128), one coalesced dword per lane): two blocks are resident, the loads of
-  // the next lower one are ISSUED into a register when e <= 128 top + 64 (top = upper resident block; that is at
-  // least one token, normally 4-5, before its slots are free) and WRITTEN to the ring when e <= 128 top (the
-  // upper block is consumed; a token takes at most 64 words, so the block below covers the next token alone):
+  // next lower one are REQUESTED into a register the moment the block above them has been written to the ring, and
+  // WRITTEN to the ring when e <= 128 top (top = upper resident block: it is consumed; a token takes at most 64 words,
+  // so the block below covers the next token alone) -- a whole block, nine tokens or so, later (round 6; until then the
+  // request went out at e <= 128 top + 64, four or five tokens ahead, and under the kernel's own 2.6 TB/s of stores
+  // the words were late: -6 % decode time, and one ring event per block instead of two):
   // their latency is off the per-token dependency chain.  Slots 256..319 mirror slots 0..63, so a token's words
   // are at consecutive slots whatever e.  A corrupt stream cannot leave the ring (slot index masked, rank < 64,
   // loads guarded); the final state / count check reports it.
@@ -340,8 +342,8 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
   block_commit(top_blk, block_load(top_blk));
   block_commit(top_blk - 1, block_load(top_blk - 1));
   int e = (int)nwords;             // wave-uniform
-  int trig = 128 * top_blk + 64;   // next ring event when e <= trig
-  u32 pending = 0, pend = 0;       // the loads of block top_blk - 2 are in flight (in pend)
+  int trig = 128 * top_blk;        // next ring event when e <= trig: the upper block is consumed
+  u32 pend = block_load(top_blk - 2);  // the block below the resident two is in flight in a register
   wave_lds_fence();
 
   // The symbol search is a binary search over the lane's CDF column.  Symbols are 0 .. nsym-1 (nsym = bins - 1),
@@ -387,18 +389,12 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
 
   // the ring bookkeeping is wave-uniform (SGPRs: its tests are scalar branches); runs when e <= trig
   auto ring_event = [&]() {
-    if (pending == 0u) {
-      pend = block_load(top_blk - 2);
-      pending = 1u;
-      trig = 128 * top_blk;
-    } else {
-      wave_lds_fence();  // every lane's reads of the upper block are done
-      block_commit(top_blk - 2, pend);
-      top_blk = __builtin_amdgcn_readfirstlane(top_blk - 1);
-      pending = 0u;
-      trig = 128 * top_blk + 64;
-      wave_lds_fence();
-    }
+    wave_lds_fence();  // every lane's reads of the upper block are done
+    block_commit(top_blk - 2, pend);
+    top_blk = __builtin_amdgcn_readfirstlane(top_blk - 1);
+    pend = block_load(top_blk - 2);  // (round 6) requested a whole block -- nine tokens or so -- before it is written
+    trig = 128 * top_blk;
+    wave_lds_fence();
   };
   // The word pop of one token (after the state update): renormalising lanes take this step's words.  Branch
   // free: every lane reads a slot (rank < 64 keeps it inside ring + mirror), the renormalising ones keep it.
@@ -432,6 +428,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
 #define LMC_SEARCH_STEP(q, piv, slot, STEP_BYTES)                                                   \
   asm("v_cmpx_le_u32_e32 vcc, %1, %2\n\tv_add_u32_e32 %0, %3, %0\n\ts_mov_b64 exec, %4"            \
       : "+v"(q) : "v"(piv), "v"(slot), "i"(STEP_BYTES), "s"(full_exec) : "vcc")
+  bool defer_events = false;  // (LMC_EXP_EVENTS_AFTER_B: timing experiment)
   auto decode_token = [&](auto top_tag, auto model_tag, float& lv) -> u32 {
     constexpr int TOP = decltype(top_tag)::value;
     constexpr bool WIDE = TOP == 4;
@@ -501,7 +498,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
                      : [sl] "v"(sl), [e2] "v"(e4.z), [e3] "v"(e4.w), [L] "v"(Lv), [ring] "s"(ring_addr),
                        [sel] "s"(0x01000504u), [full] "s"(full_exec)
                      : "vcc", "scc", "memory");
-        if (__builtin_expect(e <= trig, 0)) ring_event();
+        if (__builtin_expect(e <= trig, 0) && !defer_events) ring_event();
         return r;
       } else {
       u32 sl, q, r, pm;
@@ -696,24 +693,71 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
         }
         if (all_runs) {
           const __attribute__((address_space(4))) u32x4_a4* sp = (const __attribute__((address_space(4))) u32x4_a4*)sc_addr;
+#ifdef LMC_EXP_SCALES_VGPR
+          u32x4_t cur = {0u, 0u, 0u, 0u};
+          (void)sp;
+#else
           u32x4_t cur = sp[0];
+#endif
           const u64 rbase = ubase + (PAGED ? 0ull : (u64)((long long)(tdst0 + (int)nskip) * row_step));
           u32x4_t desc = {(u32)rbase, (u32)(rbase >> 32) & 0xffffu, 0xfffffff0u, 0x00020000u};
           auto pair = [&](u32 s2) {
             float lva = 0.0f, lvb = 0.0f;
+#ifdef LMC_EXP_EVENTS_AFTER_B
+            defer_events = true;
+#endif
             (void)decode_token(top_tag, model_tag, lva);
+            defer_events = false;
             (void)decode_token(top_tag, model_tag, lvb);
             const float va = lva * __uint_as_float(s2 << 16), vb = lvb * __uint_as_float(s2 & 0xffff0000u);
             u32 w;
             asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(va), "v"(vb));
+#ifdef LMC_EXP_NO_STORE  // (timing experiment: what the stores and the waits behind them cost; output is wrong)
+            asm volatile("" :: "v"(w), "v"(voff), "s"(desc), "s"(soff));
+#elif defined(LMC_EXP_STORE_DWORD)  // one 4-byte store per pair (same bytes, half the instructions; wrong layout)
+            asm volatile("buffer_store_dword %0, %1, %2, %3 offen nt"
+                         :: "v"(w), "v"(voff - 2u * (u32)(lane & 63) + 4u * (u32)(lane & 31) + (u32)(lane >> 5) * (u32)row_step), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
+#elif defined(LMC_EXP_STORE_X2_PER4)  // one 8-byte store per FOUR tokens (same bytes, a quarter of the instructions)
+            if ((soff / (2u * (u32)row_step)) & 1u) {
+              u32x2_t w2 = {w, w};
+              asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen nt"
+                           :: "v"(w2), "v"(voff - 2u * (u32)(lane & 63) + 8u * (u32)(lane & 15) + (u32)(lane >> 4) * (u32)row_step), "s"(desc), "s"(soff - 2u * (u32)row_step), "s"(soff + (u32)row_step) : "memory");
+            }
+#elif defined(LMC_EXP_STORE_PLAIN)
+            asm volatile("buffer_store_short %0, %1, %2, %3 offen\n\t"
+                         "buffer_store_short_d16_hi %0, %1, %2, %4 offen"
+                         :: "v"(w), "v"(voff), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
+#elif defined(LMC_EXP_STORE_SC)
+            asm volatile("buffer_store_short %0, %1, %2, %3 offen sc0 sc1\n\t"
+                         "buffer_store_short_d16_hi %0, %1, %2, %4 offen sc0 sc1"
+                         :: "v"(w), "v"(voff), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
+#elif defined(LMC_EXP_ONE_STORE)
+            asm volatile("buffer_store_short %0, %1, %2, %3 offen nt"
+                         :: "v"(w), "v"(voff), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
+#else
             asm volatile("buffer_store_short %0, %1, %2, %3 offen nt\n\t"
                          "buffer_store_short_d16_hi %0, %1, %2, %4 offen nt"
                          :: "v"(w), "v"(voff), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
+#endif
             soff += 2u * (u32)row_step;
           };
+#ifdef LMC_EXP_SCALES_VGPR
+          u32 scv0 = (u32)lane < 4u * nblk ? ((const LMC_GLOBAL u32*)sc_addr)[lane] : 0u;
+          u32 scv1 = 64u + (u32)lane < 4u * nblk ? ((const LMC_GLOBAL u32*)sc_addr)[64 + lane] : 0u;
+#endif
           for (u32 b = 0; b < nblk; b++) {
+#ifdef LMC_EXP_SCALES_VGPR
+            if (b == 16u) scv0 = scv1;
+            const int pb = (int)((4u * b) & 63u);
+            cur.x = (u32)__builtin_amdgcn_readlane((int)scv0, pb);
+            cur.y = (u32)__builtin_amdgcn_readlane((int)scv0, pb + 1);
+            cur.z = (u32)__builtin_amdgcn_readlane((int)scv0, pb + 2);
+            cur.w = (u32)__builtin_amdgcn_readlane((int)scv0, pb + 3);
+            u32x4_t nxt = cur;
+#else
             u32x4_t nxt = cur;
             if (b + 1u < nblk) nxt = sp[b + 1u];
+#endif
             if constexpr (PAGED) {
               const u32 rlo = (u32)__builtin_amdgcn_readlane((int)glo, (int)b), rhi = (u32)__builtin_amdgcn_readlane((int)ghi, (int)b);
               const u64 rb = ubase + (((u64)rhi << 32) | (u64)rlo);
