@@ -72,6 +72,15 @@ struct DecodeArgs {
 #ifndef DEC_WAVES
 #define DEC_WAVES 1  // waves (= group streams) per workgroup: ONE (round 6) -- a slot is free again the moment its stream is done, not when the slowest of four is (resident waves 89 -> 97 %, decode -3 %: profiles/r06_timelines.md)
 #endif
+#ifndef LMC_DEC_RING_AGPR
+#define LMC_DEC_RING_AGPR 1  // the word ring's in-flight block waits in AGPR a0 behind s_waitcnt vmcnt(N): see block_request
+#endif
+// a0 is NOT declared to the compiler: a kernel that uses AGPRs gets its 64 registers split 32 VGPRs / 32 AGPRs by this
+// LLVM, and the decoder needs 53.  Instead every asm that touches a0 clobbers v59: the kernel then has exactly 60 VGPRs,
+// its allocation is 64 registers (granule 8) and the accumulation offset 60 -- a0 is physical register 60, inside the
+// wave's allocation and never touched by compiled code.  native.build() refuses a library whose k_decode kernels do not
+// report 60 VGPRs and 0 AGPRs (with 61..64 VGPRs a0 would lie OUTSIDE the allocation).
+#define LMC_DEC_A0_CLOBBER "v59"
 #define DEC_CDF_BYTES 4224
 #define DEC_RING_WORDS 256
 #define DEC_RING_BYTES (2 * (DEC_RING_WORDS + 64))
@@ -334,6 +343,41 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
     return (b >= 0 && (u32)(2 * d + 1) < nwords + 128u) ? words32[d] : 0u;
 #endif
   };
+#if LMC_DEC_RING_AGPR
+  // (round 6) The block in flight does not wait in a VGPR the compiler knows about but in AGPR a0, requested and read
+  // by inline asm.  Why: a register with a load outstanding costs the compiler an `s_waitcnt vmcnt(0)` where it is read,
+  // and on gfx9 vmcnt counts the stores too -- the commit of a block then also waits for the acknowledgement of the
+  // rows stored a token or two ago (a decode without its stores runs in 0.66 ms against 0.79).  Vector memory operations
+  // complete in the order they were issued, so `s_waitcnt vmcnt(N)` with N = the stores issued since the request
+  // (`nst`, counted by the block path; every other path leaves N too small, which only waits longer) is all the block
+  // needs.  The compiler never holds a value in a0 (tests/test_host_logic.py holds the kernels at one AGPR).
+  u32 nst = 0, nst_req = 0;
+  auto block_request = [&](int b) {
+    if (b >= 0) {  // (wave-uniform)
+      const int d = 64 * b + lane;
+      const bool in = (u32)(2 * d + 1) < nwords + 128u;
+      const LMC_GLOBAL u32* const ap = words32 + (in ? d : 0);
+      asm volatile("v_accvgpr_write_b32 a0, 0" ::: LMC_DEC_A0_CLOBBER);  // lanes behind the stream's end hold 0, as block_load returns
+      if (in) asm volatile("global_load_dword a0, %0, off nt" :: "v"(ap) : LMC_DEC_A0_CLOBBER, "memory");
+    } else {
+      asm volatile("v_accvgpr_write_b32 a0, 0" ::: LMC_DEC_A0_CLOBBER);
+    }
+    nst_req = nst;
+  };
+  auto block_take = [&]() -> u32 {
+    u32 v;
+    const u32 n = nst - nst_req;  // (wave-uniform)
+    // (a ladder, because s_waitcnt takes an immediate; a request is normally 8 - 10 stores old when its block is taken)
+    if (n >= 16u) asm volatile("s_waitcnt vmcnt(16)\n\tv_accvgpr_read_b32 %0, a0" : "=v"(v) :: LMC_DEC_A0_CLOBBER, "memory");
+    else if (n >= 12u) asm volatile("s_waitcnt vmcnt(12)\n\tv_accvgpr_read_b32 %0, a0" : "=v"(v) :: LMC_DEC_A0_CLOBBER, "memory");
+    else if (n >= 10u) asm volatile("s_waitcnt vmcnt(10)\n\tv_accvgpr_read_b32 %0, a0" : "=v"(v) :: LMC_DEC_A0_CLOBBER, "memory");
+    else if (n >= 8u) asm volatile("s_waitcnt vmcnt(8)\n\tv_accvgpr_read_b32 %0, a0" : "=v"(v) :: LMC_DEC_A0_CLOBBER, "memory");
+    else if (n >= 6u) asm volatile("s_waitcnt vmcnt(6)\n\tv_accvgpr_read_b32 %0, a0" : "=v"(v) :: LMC_DEC_A0_CLOBBER, "memory");
+    else if (n >= 4u) asm volatile("s_waitcnt vmcnt(4)\n\tv_accvgpr_read_b32 %0, a0" : "=v"(v) :: LMC_DEC_A0_CLOBBER, "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, a0" : "=v"(v) :: LMC_DEC_A0_CLOBBER, "memory");
+    return v;
+  };
+#endif
   auto block_commit = [&](int b, u32 v) {
     ring32[((b & 1) << 6) + lane] = v;
     if (!(b & 1) && lane < 32) ring32[128 + lane] = v;  // mirror of slots 0..63
@@ -343,7 +387,11 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
   block_commit(top_blk - 1, block_load(top_blk - 1));
   int e = (int)nwords;             // wave-uniform
   int trig = 128 * top_blk;        // next ring event when e <= trig: the upper block is consumed
+#if LMC_DEC_RING_AGPR
+  block_request(top_blk - 2);  // the block below the resident two is in flight (in a0)
+#else
   u32 pend = block_load(top_blk - 2);  // the block below the resident two is in flight in a register
+#endif
   wave_lds_fence();
 
   // The symbol search is a binary search over the lane's CDF column.  Symbols are 0 .. nsym-1 (nsym = bins - 1),
@@ -390,15 +438,21 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
   // the ring bookkeeping is wave-uniform (SGPRs: its tests are scalar branches); runs when e <= trig
   auto ring_event = [&]() {
     wave_lds_fence();  // every lane's reads of the upper block are done
+#if LMC_DEC_RING_AGPR
+    block_commit(top_blk - 2, block_take());
+    top_blk = __builtin_amdgcn_readfirstlane(top_blk - 1);
+    block_request(top_blk - 2);  // requested a whole block -- nine tokens or so -- before it is written to the ring
+#else
     block_commit(top_blk - 2, pend);
     top_blk = __builtin_amdgcn_readfirstlane(top_blk - 1);
     pend = block_load(top_blk - 2);  // (round 6) requested a whole block -- nine tokens or so -- before it is written
+#endif
     trig = 128 * top_blk;
     wave_lds_fence();
   };
   // The word pop of one token (after the state update): renormalising lanes take this step's words.  Branch
   // free: every lane reads a slot (rank < 64 keeps it inside ring + mirror), the renormalising ones keep it.
-  auto decode_pop = [&](u64 mask) {  // mask = lanes with x < L
+  auto decode_pop = [&](u64 mask, bool check) {  // mask = lanes with x < L; check: look after the ring behind this token
     e -= (int)__popcll(mask);
     // scalar: the slot of word e - cnt, ring_addr + 2 * (e % 256) -- as s_and + s_lshl1_add_u32 (left alone the compiler
     // shifts, masks and adds: three scalar instructions of a token step that has fifteen)
@@ -419,7 +473,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
                  : [m] "s"(mask), [mlo] "s"((u32)mask), [mhi] "s"((u32)(mask >> 32)), [sb] "s"(sbase),
                    [sel] "s"(0x01000504u), [full] "s"(full_exec)
                  : "memory");
-    if (__builtin_expect(e <= trig, 0)) ring_event();
+    if (check && __builtin_expect(e <= trig, 0)) ring_event();
   };
   // One token: search, state update, word pop.  Returns the symbol as an LDS address: of its dequantisation LUT
   // entry (wide) or of its CDF entry (narrow); `lv` receives the LUT value.
@@ -428,8 +482,12 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
 #define LMC_SEARCH_STEP(q, piv, slot, STEP_BYTES)                                                   \
   asm("v_cmpx_le_u32_e32 vcc, %1, %2\n\tv_add_u32_e32 %0, %3, %0\n\ts_mov_b64 exec, %4"            \
       : "+v"(q) : "v"(piv), "v"(slot), "i"(STEP_BYTES), "s"(full_exec) : "vcc")
-  bool defer_events = false;  // (LMC_EXP_EVENTS_AFTER_B: timing experiment)
-  auto decode_token = [&](auto top_tag, auto model_tag, float& lv) -> u32 {
+  // `check_tag`: whether the ring is looked after behind this token.  The block path does so behind every SECOND token
+  // (round 6): a token takes at most 64 words and a whole block lies below the upper one, so the token after the one
+  // that emptied the upper block still finds its words -- half the tests, and every ring event falls just in front of a
+  // pair's stores.
+  auto decode_token = [&](auto top_tag, auto model_tag, float& lv, auto check_tag) -> u32 {
+    constexpr bool CHECK = decltype(check_tag)::value;
     constexpr int TOP = decltype(top_tag)::value;
     constexpr bool WIDE = TOP == 4;
     constexpr bool COUNTS = decltype(model_tag)::value;  // LMC_MODEL_COUNTS: 9-bit slots, start << 23 | freq entries
@@ -498,7 +556,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
                      : [sl] "v"(sl), [e2] "v"(e4.z), [e3] "v"(e4.w), [L] "v"(Lv), [ring] "s"(ring_addr),
                        [sel] "s"(0x01000504u), [full] "s"(full_exec)
                      : "vcc", "scc", "memory");
-        if (__builtin_expect(e <= trig, 0) && !defer_events) ring_event();
+        if (CHECK && __builtin_expect(e <= trig, 0)) ring_event();
         return r;
       } else {
       u32 sl, q, r, pm;
@@ -540,7 +598,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
           : [e2] "v"(e4.z), [e3] "v"(e4.w), [sl] "v"(sl), [full] "s"(full_exec), [lv] "v"(Lv)
           : "vcc");
       if (!SYMOUT) lv = *(lds_f32p)(size_t)r;  // issued here: back by the time the word pop below has its word
-      return decode_pop(mask), r;
+      return decode_pop(mask, CHECK), r;
       }
     } else {
       constexpr u32 ESTRIDE = 128u;  // bytes between entries of a lane's column
@@ -616,7 +674,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
             : "vcc");
       }
       if (!SYMOUT) lv = *(lds_f32p)(size_t)((q - lut_bias) >> 5);
-      return decode_pop(mask), q;
+      return decode_pop(mask, CHECK), q;
     }
   };
 
@@ -626,7 +684,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
     constexpr bool WIDE = decltype(top_tag)::value == 4;
     for (u32 t = 0; t < nskip; t++) {  // retrieve()'s first-chunk trim: decode, do not store
       float lv_skip;
-      (void)decode_token(top_tag, model_tag, lv_skip);
+      (void)decode_token(top_tag, model_tag, lv_skip, BoolTag<true>{});
     }
     // !PAGED: the rows of this stream through a raw buffer descriptor: base = row of the first stored token,
     // soffset (scalar) = one stride_token further each token, voffset = the lane's channel.  The descriptor's range
@@ -693,44 +751,18 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
         }
         if (all_runs) {
           const __attribute__((address_space(4))) u32x4_a4* sp = (const __attribute__((address_space(4))) u32x4_a4*)sc_addr;
-#ifdef LMC_EXP_SCALES_VGPR
-          u32x4_t cur = {0u, 0u, 0u, 0u};
-          (void)sp;
-#else
           u32x4_t cur = sp[0];
-#endif
           const u64 rbase = ubase + (PAGED ? 0ull : (u64)((long long)(tdst0 + (int)nskip) * row_step));
           u32x4_t desc = {(u32)rbase, (u32)(rbase >> 32) & 0xffffu, 0xfffffff0u, 0x00020000u};
           auto pair = [&](u32 s2) {
             float lva = 0.0f, lvb = 0.0f;
-#ifdef LMC_EXP_EVENTS_AFTER_B
-            defer_events = true;
-#endif
-            (void)decode_token(top_tag, model_tag, lva);
-            defer_events = false;
-            (void)decode_token(top_tag, model_tag, lvb);
+            (void)decode_token(top_tag, model_tag, lva, BoolTag<false>{});
+            (void)decode_token(top_tag, model_tag, lvb, BoolTag<true>{});
             const float va = lva * __uint_as_float(s2 << 16), vb = lvb * __uint_as_float(s2 & 0xffff0000u);
             u32 w;
             asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(va), "v"(vb));
 #ifdef LMC_EXP_NO_STORE  // (timing experiment: what the stores and the waits behind them cost; output is wrong)
             asm volatile("" :: "v"(w), "v"(voff), "s"(desc), "s"(soff));
-#elif defined(LMC_EXP_STORE_DWORD)  // one 4-byte store per pair (same bytes, half the instructions; wrong layout)
-            asm volatile("buffer_store_dword %0, %1, %2, %3 offen nt"
-                         :: "v"(w), "v"(voff - 2u * (u32)(lane & 63) + 4u * (u32)(lane & 31) + (u32)(lane >> 5) * (u32)row_step), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
-#elif defined(LMC_EXP_STORE_X2_PER4)  // one 8-byte store per FOUR tokens (same bytes, a quarter of the instructions)
-            if ((soff / (2u * (u32)row_step)) & 1u) {
-              u32x2_t w2 = {w, w};
-              asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen nt"
-                           :: "v"(w2), "v"(voff - 2u * (u32)(lane & 63) + 8u * (u32)(lane & 15) + (u32)(lane >> 4) * (u32)row_step), "s"(desc), "s"(soff - 2u * (u32)row_step), "s"(soff + (u32)row_step) : "memory");
-            }
-#elif defined(LMC_EXP_STORE_PLAIN)
-            asm volatile("buffer_store_short %0, %1, %2, %3 offen\n\t"
-                         "buffer_store_short_d16_hi %0, %1, %2, %4 offen"
-                         :: "v"(w), "v"(voff), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
-#elif defined(LMC_EXP_STORE_SC)
-            asm volatile("buffer_store_short %0, %1, %2, %3 offen sc0 sc1\n\t"
-                         "buffer_store_short_d16_hi %0, %1, %2, %4 offen sc0 sc1"
-                         :: "v"(w), "v"(voff), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
 #elif defined(LMC_EXP_ONE_STORE)
             asm volatile("buffer_store_short %0, %1, %2, %3 offen nt"
                          :: "v"(w), "v"(voff), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
@@ -740,24 +772,13 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
                          :: "v"(w), "v"(voff), "s"(desc), "s"(soff), "s"(soff + (u32)row_step) : "memory");
 #endif
             soff += 2u * (u32)row_step;
-          };
-#ifdef LMC_EXP_SCALES_VGPR
-          u32 scv0 = (u32)lane < 4u * nblk ? ((const LMC_GLOBAL u32*)sc_addr)[lane] : 0u;
-          u32 scv1 = 64u + (u32)lane < 4u * nblk ? ((const LMC_GLOBAL u32*)sc_addr)[64 + lane] : 0u;
+#if LMC_DEC_RING_AGPR && !defined(LMC_EXP_NO_STORE) && !defined(LMC_EXP_ONE_STORE)
+            nst += 2u;  // (exactly the vector memory operations issued above: block_take's vmcnt(N) counts on it)
 #endif
+          };
           for (u32 b = 0; b < nblk; b++) {
-#ifdef LMC_EXP_SCALES_VGPR
-            if (b == 16u) scv0 = scv1;
-            const int pb = (int)((4u * b) & 63u);
-            cur.x = (u32)__builtin_amdgcn_readlane((int)scv0, pb);
-            cur.y = (u32)__builtin_amdgcn_readlane((int)scv0, pb + 1);
-            cur.z = (u32)__builtin_amdgcn_readlane((int)scv0, pb + 2);
-            cur.w = (u32)__builtin_amdgcn_readlane((int)scv0, pb + 3);
-            u32x4_t nxt = cur;
-#else
             u32x4_t nxt = cur;
             if (b + 1u < nblk) nxt = sp[b + 1u];
-#endif
             if constexpr (PAGED) {
               const u32 rlo = (u32)__builtin_amdgcn_readlane((int)glo, (int)b), rhi = (u32)__builtin_amdgcn_readlane((int)ghi, (int)b);
               const u64 rb = ubase + (((u64)rhi << 32) | (u64)rlo);
@@ -786,7 +807,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
       if (PAGED && !SYMOUT) tok_off2 = (t0 + (u32)lane < T) ? dec_tok_off(a.dst, tdst0 + (int)(t0 + (u32)lane)) * 2 : 0ll;
       auto one_token = [&](u32 i) {
         float lv = 0.0f;
-        const u32 sa = decode_token(top_tag, model_tag, lv);
+        const u32 sa = decode_token(top_tag, model_tag, lv, BoolTag<true>{});
         if (SYMOUT) {
           const u32 sym = WIDE ? (sa - lut_addr) >> 2 : (sa - col_addr) >> 7;
           if (active) *((LMC_GLOBAL int8_t*)(ubase + (u64)(t0 + i) * a.C) + lane_off) = (int8_t)sym;
@@ -814,6 +835,9 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
             __builtin_amdgcn_raw_buffer_store_b16((short)bits, rsrc, (int)voff, (int)soff, 2 /* nt */);
             soff += (u32)row_step;
           }
+#if LMC_DEC_RING_AGPR
+          nst += 1u;  // (one store per token on either branch; the loads of this loop only make block_take's N smaller than it could be)
+#endif
         }
       };
       // (four tokens per trip -- the back edge is a taken scalar branch per token -- measured the same within the box

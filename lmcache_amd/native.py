@@ -52,7 +52,25 @@ def build(force: bool = False) -> str:
         if "warning:" in proc.stderr or "error:" in proc.stderr:
             sys.stderr.write("\n".join(l for l in proc.stderr.splitlines() if "[-Rpass-analysis=kernel-resource-usage]" not in l) + "\n")
         _write_kernel_resources(proc.stderr)
+        _check_decoder_registers()
     return SO_PATH
+
+
+def _check_decoder_registers() -> None:
+    """k_decode keeps the word ring's in-flight block in AGPR a0 WITHOUT telling the compiler (k_decode.h,
+    LMC_DEC_A0_CLOBBER): that is only sound while the kernel has exactly 60 VGPRs and no AGPRs of the compiler's own --
+    a0 is then physical register 60 of a 64-register allocation.  A build that comes out differently is refused here,
+    loudly, instead of decoding with a register that belongs to another wave."""
+    import json
+    res = json.load(open(RESOURCES_PATH))
+    bad = {k: (v.get("VGPRs"), v.get("AGPRs")) for k, v in res.items()
+           if "k_decode" in k and (v.get("VGPRs") != 60 or v.get("AGPRs") != 0)}
+    if bad:
+        try:
+            os.remove(SO_PATH)
+        except OSError:
+            pass
+        raise RuntimeError(f"k_decode must compile to 60 VGPRs / 0 AGPRs (hidden a0, see k_decode.h); got {bad}")
 
 
 RESOURCES_PATH = os.path.join(CSRC, "kernel_resources.json")

@@ -447,6 +447,9 @@ def test_scratch_of_the_hot_kernels_is_what_design_md_says():
         assert v["VGPRs"] <= 64 and v["Occupancy"] == 8 and v["ScratchSize"] <= 96, (name, v)
     for name, v in one("k_decode").items():
         assert v["ScratchSize"] == 0 and v["Occupancy"] == 8, (name, v)
+        # the decoder parks its ring's in-flight block in AGPR a0 behind the compiler's back: sound only at exactly 60
+        # VGPRs (a0 = physical register 60 of 64) and no AGPR of the compiler's own (k_decode.h, native._check_decoder_registers)
+        assert v["VGPRs"] == 60 and v["AGPRs"] == 0, (name, v)
     for name, v in one("k_quantize").items():
         assert v["ScratchSize"] == 0, (name, v)
     for name, v in one("k_encode_fused").items():
