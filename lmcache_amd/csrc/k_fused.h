@@ -104,6 +104,23 @@ __device__ __forceinline__ u32 lookback_exclusive_epoch(unsigned long long* agg,
   return excl;
 }
 
+// The offset of token t's row.  PSRC (round 6): the kernel instance for a PAGED source whose block size is a power of
+// two.  lmc_tok_off reads the token's slot with a vector load, and the wait for it is an s_waitcnt vmcnt(0) -- which on
+// gfx9 also waits for the acknowledgement of every symbol store issued before: eight such stalls per row oct (the encode
+// reading a paged cache ran 4.5 - 7 % behind the contiguous one).  t is wave-uniform, so the slot comes by a scalar load
+// (lgkmcnt) and the row offset is scalar arithmetic.  The instances for every other source are compiled as before.
+template <bool PSRC>
+__device__ __forceinline__ long long fused_tok_off(const KvAddr& a, int t) {
+  if constexpr (!PSRC) return lmc_tok_off(a, t);
+  else {
+    const unsigned long long ad = uniform_ptr64(a.slot_mapping + t);
+    const u32 s = *(const __attribute__((address_space(4))) u32*)ad;  // (the low half: lmc_tok_off reads a slot as 32 bits too)
+    const u32 bs = (u32)a.block_size;
+    const u32 b = s >> (u32)__builtin_ctz(bs), w = s & (bs - 1u);
+    return (long long)b * a.stride_block + (long long)w * a.stride_token;
+  }
+}
+
 // One row oct (tokens t_first .. t_first + 7 of the plane) by one wave: quantize_task<64, NITER, DT, QUAD, NIB>
 // (k_quantize.h) re-staged for 64 VGPRs -- the same arithmetic (quant_z2 / v_cvt_pk_u8_f32 on regular rows,
 // quant_special on zero / inf / NaN rows), two rows in flight, one row quad of accumulators at a time: a byte
@@ -113,7 +130,7 @@ __device__ __forceinline__ u32 lookback_exclusive_epoch(unsigned long long* agg,
 // shapes), so no per-lane validity is tested and no register is zero-filled for absent channels.
 // ALLROWS: all eight rows of the oct are tokens of the chunk (every oct but the last one of a chunk whose length is no
 // multiple of 8): no per-row test, no zero fill -- what the kernel had when it only took 256-token chunks.
-template <int NITER, int DT, bool NIB, bool FULL = false, bool ALLROWS = true>
+template <int NITER, int DT, bool NIB, bool FULL = false, bool ALLROWS = true, bool PSRC = false>
 __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16* pbase, int tok0, int Tc, int t_first,
                                                    bool q1valid, int C, float maxf, u32* sym_out, u16* scale_out,
                                                    uint4* park, int lane) {
@@ -139,7 +156,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
       for (int r = 0; r < 2; r++) {
         const int t = t_first + 4 * hq + r0 + r;
         tv[r] = ALLROWS || t < Tc;
-        const u16* rowp = pbase + (tv[r] ? lmc_tok_off(src, tok0 + t) : 0);
+        const u16* rowp = pbase + (tv[r] ? fused_tok_off<PSRC>(src, tok0 + t) : 0);
 #pragma unroll
         for (int it = 0; it < NITER; it++) {
           if (tv[r] && (FULL || cval[it])) v[r][it] = ld_global_u4_nt(rowp + coff[it]);  // streamed once
@@ -269,7 +286,7 @@ __device__ __forceinline__ void quantize_oct_fused(const KvAddr& src, const u16*
 #endif
 // quantize_oct_fused with the histogram: one row oct by one wave, symbols to the workspace AND into the plane's counters.
 // skip0: the oct holds token 0 of the chunk (byte planes leave it out of the counters).
-template <int NITER, int DT, bool NIB, bool FULL, bool ALLROWS>
+template <int NITER, int DT, bool NIB, bool FULL, bool ALLROWS, bool PSRC = false>
 __device__ __forceinline__ void quantize_oct_hist(const KvAddr& src, const u16* pbase, int tok0, int Tc, int t_first,
                                                   bool q1valid, bool skip0, int C, float maxf, u32* sym_out, u16* scale_out,
                                                   int lane) {
@@ -302,7 +319,7 @@ __device__ __forceinline__ void quantize_oct_hist(const KvAddr& src, const u16* 
     for (int r = 0; r < 2; r++) {
       const int t = t_first + rowi[r];
       tv[r] = ALLROWS || t < Tc;
-      const u16* rowp = pbase + (tv[r] ? lmc_tok_off(src, tok0 + t) : 0);
+      const u16* rowp = pbase + (tv[r] ? fused_tok_off<PSRC>(src, tok0 + t) : 0);
 #pragma unroll
       for (int it = 0; it < NITER; it++) {
         if (tv[r] && (FULL || cval[it])) v[r][it] = ld_global_u4_nt(rowp + coff[it]);  // streamed once
@@ -409,7 +426,7 @@ __device__ __forceinline__ void quantize_oct_hist(const KvAddr& src, const u16* 
   }
 }
 
-template <int GL, int NITER, int DT, int NW>
+template <int GL, int NITER, int DT, int NW, bool PSRC = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_fused(FusedArgs fa) {
   static_assert(GL == 64 || NITER == 1, "narrow planes: one channel run per lane");
   const EncodeArgs& a = fa.e;
@@ -539,34 +556,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
           // round 6: symbols to the workspace AND into the plane's counters (quantize_oct_hist)
           u32* const so = sym_pc + (long long)oct * (nib ? 1 : 2) * a.C;
           if (!allrows) {
-            if (nib) quantize_oct_hist<NITER, DT, true, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
-            else quantize_oct_hist<NITER, DT, false, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+            if (nib) quantize_oct_hist<NITER, DT, true, false, false, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+            else quantize_oct_hist<NITER, DT, false, false, false, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
           } else if (full) {
-            if (nib) quantize_oct_hist<NITER, DT, true, true, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
-            else quantize_oct_hist<NITER, DT, false, true, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
-          } else if (nib) quantize_oct_hist<NITER, DT, true, false, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
-          else quantize_oct_hist<NITER, DT, false, false, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+            if (nib) quantize_oct_hist<NITER, DT, true, true, true, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+            else quantize_oct_hist<NITER, DT, false, true, true, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+          } else if (nib) quantize_oct_hist<NITER, DT, true, false, true, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
+          else quantize_oct_hist<NITER, DT, false, false, true, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, oct == 0, a.C, maxf, so, scl + oct * 8, lane);
         } else if constexpr (HISTA && LMC_FUSED_HIST_A_BYTE) {
           // (unreachable: every plane of a GL == 64 item takes the branch above)
         } else if (!allrows) {  // (the variant with per-lane channel validity takes the per-row test as well: two instances, not four)
           if (nib)
-            quantize_oct_fused<NITER, DT, true, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+            quantize_oct_fused<NITER, DT, true, false, false, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
                                                               sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
           else
-            quantize_oct_fused<NITER, DT, false, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+            quantize_oct_fused<NITER, DT, false, false, false, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
                                                                sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
         } else if (full) {  // wave-uniform
           if (nib)
-            quantize_oct_fused<NITER, DT, true, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+            quantize_oct_fused<NITER, DT, true, true, true, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
                                                       sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
           else
-            quantize_oct_fused<NITER, DT, false, true>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+            quantize_oct_fused<NITER, DT, false, true, true, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
                                                        sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
         } else if (nib)
-          quantize_oct_fused<NITER, DT, true, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+          quantize_oct_fused<NITER, DT, true, false, true, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
                                                      sym_pc + (long long)oct * a.C, scl + oct * 8, park, lane);
         else
-          quantize_oct_fused<NITER, DT, false, false>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
+          quantize_oct_fused<NITER, DT, false, false, true, PSRC>(fa.src, pbase, tok0, Tc, oct * 8, q1valid, a.C, maxf,
                                                       sym_pc + (long long)oct * 2 * a.C, scl + oct * 8, park, lane);
       }
     }

@@ -281,12 +281,20 @@ static int ws_grow(void** p, size_t* have, size_t need) {
 }
 
 // The fused encode for a plane width (k_fused.h: lanes per quantise task, channel runs per lane, waves per row).
+template <int DT, bool PSRC>
+static void launch_fused_src(int C, dim3 grid, dim3 block, hipStream_t s, const FusedArgs& fa) {
+  if (C <= 128) hipLaunchKernelGGL((k_encode_fused<16, 1, DT, FUSED_WAVES, PSRC>), grid, block, 0, s, fa);
+  else if (C <= 256) hipLaunchKernelGGL((k_encode_fused<32, 1, DT, FUSED_WAVES, PSRC>), grid, block, 0, s, fa);
+  else if (C <= 512) hipLaunchKernelGGL((k_encode_fused<64, 1, DT, FUSED_WAVES, PSRC>), grid, block, 0, s, fa);
+  else hipLaunchKernelGGL((k_encode_fused<64, 2, DT, FUSED_WAVES, PSRC>), grid, block, 0, s, fa);  // C <= LMC_FUSED_MAX_CHANNELS
+}
 template <int DT>
 static void launch_fused(int C, dim3 grid, dim3 block, hipStream_t s, const FusedArgs& fa) {
-  if (C <= 128) hipLaunchKernelGGL((k_encode_fused<16, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
-  else if (C <= 256) hipLaunchKernelGGL((k_encode_fused<32, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
-  else if (C <= 512) hipLaunchKernelGGL((k_encode_fused<64, 1, DT, FUSED_WAVES>), grid, block, 0, s, fa);
-  else hipLaunchKernelGGL((k_encode_fused<64, 2, DT, FUSED_WAVES>), grid, block, 0, s, fa);  // C <= LMC_FUSED_MAX_CHANNELS
+  // a paged source with a block size that is a power of two (every one vLLM offers) has kernel instances of its own: the
+  // tokens' slots by scalar loads (k_fused.h, fused_tok_off)
+  const u32 bs = (u32)fa.src.block_size;
+  if (fa.src.slot_mapping && bs != 0u && (bs & (bs - 1u)) == 0u) launch_fused_src<DT, true>(C, grid, block, s, fa);
+  else launch_fused_src<DT, false>(C, grid, block, s, fa);
 }
 
 // caller holds ctx->mu.  The symbol workspace and the look-back granules of `max_chunks` chunks, stream scratch for

@@ -442,7 +442,10 @@ def test_scratch_of_the_hot_kernels_is_what_design_md_says():
                 return hits
         raise AssertionError(prefixes)
     for name, v in one("k_encode_fused").items():
-        assert v["VGPRs"] <= 64 and v["Occupancy"] == 8 and v["ScratchSize"] <= 32, (name, v)
+        # (the instances for a paged source -- last template argument true: scalar slot loads, k_fused.h fused_tok_off --
+        # hold a few more scalars across phase A)
+        paged_src = "true>" in name or "ELb1EE" in name  # (demangled / mangled)
+        assert v["VGPRs"] <= 64 and v["Occupancy"] == 8 and v["ScratchSize"] <= (40 if paged_src else 32), (name, v)
     for name, v in one_of(("k_cdf_encodeILb1ELb1ELi8ELb1", "k_cdf_encode<true, true, 8, true>")).items():
         assert v["VGPRs"] <= 64 and v["Occupancy"] == 8 and v["ScratchSize"] <= 96, (name, v)
     for name, v in one("k_decode").items():
