@@ -485,7 +485,11 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
       const u32 up = *(lds_u32w)(size_t)(slot_addr + 256u);  // words 128 .. 255: whatever of them is in use moves down
       // (uniform base in the descriptor, the lane in the vector offset, the stream position in the scalar offset)
       const u32 voff = 4u * lane_here;
+#ifndef LMC_EXP_ENC_NO_FLUSH  // (timing experiment: the coder without its stream stores; blobs are wrong)
       __builtin_amdgcn_raw_buffer_store_b32((int)v, out_rsrc, (int)voff, (int)(flushed << 1), NT ? 2 : 0);
+#else
+      asm volatile("" :: "v"(v), "v"(voff));
+#endif
       if (voff < wb - wlimit) *(lds_u32w)(size_t)slot_addr = up;  // (a half-used last dword brings a stale upper half along: the next word overwrites it)
       flushed += 128u;
       wb -= 256u;
