@@ -1184,6 +1184,41 @@ def extras(res, args, ctx, native, dev, kv, layout, bins, blobs, sizes, stride, 
     res["seeds"] = {"dist": args.dist, "ms_per_step": per_seed, "min": min(per_seed), "median": median(per_seed),
                     "GBps_raw_median": round(raw_bytes / median(per_seed) / 1e6, 1)}
 
+    stage("two stores at a time")
+    # ---- two stores of the context in flight at a time (two requests on two streams, each with its own blob arena; the
+    # context owns two workspaces for exactly this).  NOT `value`: the timed region issues its steps on one stream, where
+    # a launch's last generation of workgroups (coding only, fabric idle) and the next launch's first one (fetching
+    # only, coders idle) cannot overlap -- ~0.1 ms per launch (profiles/r06_decoder_and_timelines.md section 3).
+    try:
+        s2 = torch.cuda.Stream(device=dev)
+        blobs2 = torch.empty_like(blobs)
+        sizes2 = torch.zeros_like(sizes)
+        pairs = 10
+
+        def two_at_a_time():
+            for _ in range(pairs):
+                ctx.encode_chunks(layout, 0, CTX, CHUNK, bins, blobs.data_ptr(), stride, sizes.data_ptr(), stream=sp)
+                ctx.encode_chunks(layout, 0, CTX, CHUNK, bins, blobs2.data_ptr(), stride, sizes2.data_ptr(), stream=s2.cuda_stream)
+        two_at_a_time()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        two_at_a_time()
+        torch.cuda.synchronize()
+        tt = (time.perf_counter() - t0) * 1e3 / (2 * pairs)
+        ctx.raise_on_status("bench two stores")
+        sz, sz2 = sizes.cpu().tolist(), sizes2.cpu().tolist()  # (the arenas are torch.empty: compare the blobs, not the slack)
+        same = sz == sz2 and all(bool(torch.equal(blobs[i * stride:i * stride + sz[i]], blobs2[i * stride:i * stride + sz[i]]))
+                                 for i in range(len(sz)))
+        res["two_stores_at_a_time"] = {"ms_per_context": round(tt, 4), "GBps_raw_kv": round(raw_bytes / tt / 1e6, 1),
+                                       "roofline_frac": round(algo_bytes / (tt / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "blobs_equal": same,
+                                       "note": "two lmc_encode_chunks of the 16k context in flight on two streams, wall clock over "
+                                               "20 contexts / 20: the fused kernel's steady state (not `value`: one request at a "
+                                               "time is what the timed region measures)"}
+        del blobs2, sizes2
+    except Exception as e:
+        res["two_stores_at_a_time"] = {"error": repr(e)}
+
     stage("other distributions")
     # ---- SURVEY.md 8d names three input distributions: the timed one (--dist, default rand) and the two others here ----
     try:
