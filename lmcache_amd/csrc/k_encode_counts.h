@@ -465,10 +465,22 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
   // CNT_RING_DWORDS.  What this removes from every token step: s_sub / s_cmpk / a TAKEN s_cbranch (now every second
   // step), s_lshl / s_and / s_add of the cursor -- 3.3 + 0.9 ns of the step's 24.2 in the issue-slot replica
   // (tools/probes/issue_model.py, profiles/r05_issue_model.md).
-  u32 wb = ring_addr;
+  // The 256-byte pieces leave ALIGNED to 256 bytes (round 6): a stream's words begin at a multiple of 16 bytes, and
+  // pieces cut from there straddle a 64-byte write granule at either end three times out of four -- the streams are
+  // stored non-temporal, the two halves of such a granule reach the fabric as two partial writes (WRITE_SIZE of the
+  // fused kernel: 0.557 GB for 0.464 GB of blob = the 4.75 / 4 granules per piece this predicts).  So the buffer starts
+  // out `pre` bytes full (pre = the distance of the first word from the 256-byte boundary below it: slots nobody
+  // writes), the descriptor's base is that boundary, and the FIRST piece leaves without its first `pre` bytes; every
+  // later piece is two whole 128-byte lines.  Same bytes in the blob.
+#ifndef LMC_FLUSH_ALIGN
+#define LMC_FLUSH_ALIGN 1
+#endif
+  const u32 pre = LMC_FLUSH_ALIGN ? (u32)__builtin_amdgcn_readfirstlane((int)((u32)(size_t)out & 255u)) : 0u;  // a multiple of 16 (the caller's contract)
+  u32 skip = pre;      // bytes at the front of the next piece that are not the stream's (pre until the first piece has left)
+  u32 wb = ring_addr + pre;
   const u32 wlimit = ring_addr + 256u;
-  u32 flushed = 0;     // words already in global memory (a multiple of 128), wave-uniform
-  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, (int)0xfffffff0u, 0x00020000);
+  u32 flushed = 0;     // words already in global memory (a multiple of 128, counted from the boundary), wave-uniform
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((u8*)out - pre), (short)0, (int)0xfffffff0u, 0x00020000);
   auto flush_ring = [&]() {
 #ifndef LMC_FLUSH_LIKELY
 #define LMC_FLUSH_LIKELY 0  // 0: the flush is laid out behind the loop (the common path falls through an untaken branch)
@@ -486,7 +498,8 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
       // (uniform base in the descriptor, the lane in the vector offset, the stream position in the scalar offset)
       const u32 voff = 4u * lane_here;
 #ifndef LMC_EXP_ENC_NO_FLUSH  // (timing experiment: the coder without its stream stores; blobs are wrong)
-      __builtin_amdgcn_raw_buffer_store_b32((int)v, out_rsrc, (int)voff, (int)(flushed << 1), NT ? 2 : 0);
+      if (!LMC_FLUSH_ALIGN || voff >= skip) __builtin_amdgcn_raw_buffer_store_b32((int)v, out_rsrc, (int)voff, (int)(flushed << 1), NT ? 2 : 0);
+      skip = 0;
 #else
       asm volatile("" :: "v"(v), "v"(voff));
 #endif
@@ -649,9 +662,13 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
   x = s.active ? x : LMC_COUNTS_L;  // idle lanes (channel >= C) carry the initial state
   // the words still in the buffer (< 128)
   wave_lds_fence();
-  const u32 pending = (wb - ring_addr) >> 1;
-  u32 wcur = flushed + pending;  // words of the stream
-  for (u32 k = (u32)lane; k < pending; k += 64) out[flushed + k] = ring[k];
+  const u32 pending = (wb - ring_addr) >> 1;   // (counted from the boundary, like `flushed`)
+  u32 wcur = flushed + pending - (pre >> 1);   // words of the stream
+  {
+    u16* const outb = reinterpret_cast<u16*>(reinterpret_cast<u8*>(out) - pre);
+    for (u32 k = (u32)lane; k < pending; k += 64)
+      if (2u * k >= skip) outb[flushed + k] = ring[k];
+  }
   // tail: states, pad
   out[wcur + 2 * lane] = (u16)x;
   out[wcur + 2 * lane + 1] = (u16)(x >> 16);
