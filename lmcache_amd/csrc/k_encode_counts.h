@@ -660,22 +660,32 @@ __device__ __forceinline__ u32 counts_code_stream(const EncodeArgs& a, const Cou
   if (s.nib) pass2(BoolTag<true>{});
   else pass2(BoolTag<false>{});
   x = s.active ? x : LMC_COUNTS_L;  // idle lanes (channel >= C) carry the initial state
-  // the words still in the buffer (< 128)
+  // The end of the stream -- the words still in the buffer, the 64 states, zeros up to a multiple of 16 bytes -- leaves
+  // through the buffer as well (round 6): the states are appended to it, and what it holds goes out as one dword per lane
+  // in two pieces that continue the 256-byte grid of the pieces before.  (Until then: two 16-bit stores per lane for the
+  // states, one or two for the words, one for the zeros -- a dozen partial write granules per stream, 35 MB of
+  // WRITE_SIZE per 16 k context.)
+  flush_ring();  // (fewer than 128 words are left, whatever test the loops ended on)
   wave_lds_fence();
-  const u32 pending = (wb - ring_addr) >> 1;   // (counted from the boundary, like `flushed`)
-  u32 wcur = flushed + pending - (pre >> 1);   // words of the stream
+  const u32 pend_b = wb - ring_addr;  // bytes in the buffer, counted from the boundary: < 256
   {
-    u16* const outb = reinterpret_cast<u16*>(reinterpret_cast<u8*>(out) - pre);
-    for (u32 k = (u32)lane; k < pending; k += 64)
-      if (2u * k >= skip) outb[flushed + k] = ring[k];
+    const u32 sa = wb + 4u * (u32)lane;  // (2 mod 4 when the stream's word count is odd: two 16-bit writes)
+    *(lds_u16w)(size_t)sa = (u16)x;
+    *(lds_u16w)(size_t)(sa + 2u) = (u16)(x >> 16);
   }
-  // tail: states, pad
-  out[wcur + 2 * lane] = (u16)x;
-  out[wcur + 2 * lane + 1] = (u16)(x >> 16);
-  wcur += 128;
-  const u32 exact = wcur * 2;
-  const u32 padw = ((16u - (exact & 15u)) & 15u) >> 1;
-  if ((u32)lane < padw) out[wcur + lane] = 0;
+  wave_lds_fence();
+  const u32 tot_b = pend_b + 256u;            // < 512 = the buffer
+  const u32 end_b = (tot_b + 15u) & ~15u;     // (pre is a multiple of 16: so is the stream's padded length)
+  const u32 exact = (flushed << 1) + tot_b - pre;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const u32 voff = 256u * (u32)h + 4u * (u32)lane;
+    if (voff < end_b && voff >= skip) {
+      u32 v = *(lds_u32w)(size_t)(ring_addr + voff);
+      v = voff >= tot_b ? 0u : (voff + 2u == tot_b ? (v & 0xffffu) : v);
+      __builtin_amdgcn_raw_buffer_store_b32((int)v, out_rsrc, (int)voff, (int)(flushed << 1), NT ? 2 : 0);
+    }
+  }
   return exact;
 }
 
