@@ -108,9 +108,25 @@ __global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform -> SGPRs
   // (32-bit work-item arithmetic: lmc_api.hip rejects a launch of 2^31 streams or more, and a 64-bit division costs
   // more than a hundred instructions per stream)
-  const u32 gid = blockIdx.x * (u32)DEC_WAVES + (u32)wave;
+  u32 gid = blockIdx.x * (u32)DEC_WAVES + (u32)wave;
   const int n = 2 * a.layer_count * a.G;  // streams of a chunk in this launch
   if (gid >= (u32)a.nchunks * (u32)n) return;
+#ifndef LMC_DEC_XCD_MAP
+#define LMC_DEC_XCD_MAP 1
+#endif
+  if constexpr (LMC_DEC_XCD_MAP && DEC_WAVES == 1 && !PAGED && !SYMOUT) {
+    // (round 6, late) Workgroups go to the eight XCDs round-robin, so the G streams of a plane -- consecutive work items,
+    // which write the G 128-byte pieces of the same rows, read the same scales and header -- landed on eight different L2s.
+    // Within every tile of 8 G consecutive work items, XCD x (workgroups x, x + 8, ...) takes plane x of the tile: a
+    // plane's streams share one L2.  The launch's last, partial tile keeps the plain order.  Only where a token's row is
+    // one run of bytes (heads back to back: contiguous decode -1.5 %); with the pieces of a row kilobytes apart -- paged
+    // NHBD blocks -- the same map costs 3 - 5 % (profiles/r06_experiments.md section 13), so those keep the plain order.
+    const u32 tile = 8u * (u32)a.G, t0 = gid / tile * tile;
+    if (a.dst.stride_head == (long long)a.dst.D && t0 + tile <= (u32)a.nchunks * (u32)n) {
+      const u32 i = gid - t0;
+      gid = t0 + (i & 7u) * (u32)a.G + (i >> 3);
+    }
+  }
   LMC_DTL(0, (unsigned long long)wall_clock64());
   u8* wl = lds_all + DEC_WAVES * DEC_LUT_BYTES + wave * DEC_WAVE_BYTES;
   u16* cdfT = reinterpret_cast<u16*>(wl);                           // [33][64]: entry-major, bank = lane/2
